@@ -1,0 +1,193 @@
+"""ctypes binding of the C ABI in include/clair_amd.h (libclair_amd.so, built by build.py).
+
+There is deliberately no fallback: if the shared library is missing or no HIP device is
+present, construction of an engine raises.  The HIP path is the product.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclair_amd.so")
+
+# every symbol include/clair_amd.h declares (tests/test_abi.py checks header <-> this list <-> .so)
+SYMBOLS = (
+    "clair_abi_version", "clair_device_count", "clair_last_error",
+    "clair_engine_create", "clair_engine_destroy",
+    "clair_set_tensor", "clair_finalize_weights",
+    "clair_predict", "clair_submit", "clair_wait",
+    "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
+    "clair_run_resident", "clair_sync",
+    "clair_timing_enable", "clair_kernel_times", "clair_timing_reset",
+    "clair_debug_read",
+)
+KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail")
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libclair_amd.so (CDLL: calls release the GIL, as TF's session.run does for the
+    reference's predict thread, clair/call_var.py:1343)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise EngineError(
+            "%s not found: build the HIP extension first (python -m clair_amd.build, or "
+            "__graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    lib.clair_abi_version.restype = c_int
+    lib.clair_device_count.restype = c_int
+    lib.clair_last_error.restype = ctypes.c_char_p
+    lib.clair_last_error.argtypes = [c_vp]
+    lib.clair_engine_create.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_vp)]
+    lib.clair_engine_destroy.argtypes = [c_vp]
+    lib.clair_engine_destroy.restype = None
+    lib.clair_set_tensor.argtypes = [c_vp, c_int, c_vp, c_i64]
+    lib.clair_finalize_weights.argtypes = [c_vp]
+    lib.clair_predict.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.clair_submit.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.clair_wait.argtypes = [c_vp, c_int]
+    lib.clair_dataset_alloc.argtypes = [c_vp, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]
+    lib.clair_dataset_free.argtypes = [c_vp, c_vp, c_vp]
+    lib.clair_dataset_upload.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64]
+    lib.clair_dataset_download.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64]
+    lib.clair_run_resident.argtypes = [c_vp, c_int, c_vp, c_vp, c_i64, c_int]
+    lib.clair_sync.argtypes = [c_vp]
+    lib.clair_timing_enable.argtypes = [c_vp, c_int]
+    lib.clair_kernel_times.argtypes = [c_vp, c_vp, c_vp]
+    lib.clair_timing_reset.argtypes = [c_vp]
+    lib.clair_debug_read.argtypes = [c_vp, c_int, c_int, c_vp, c_i64]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("clair_last_error", "clair_engine_destroy"):
+            fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Engine(object):
+    """Thin object wrapper over one clair_engine_t."""
+
+    def __init__(self, device=0, max_batch=1024, n_slots=1):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self.max_batch = int(max_batch)
+        self.n_slots = int(n_slots)
+        rc = self._lib.clair_engine_create(int(device), int(max_batch), int(n_slots), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.clair_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise EngineError("clair_engine_create failed: %s" % msg)
+        self._pending = {}
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed: %s" % (what, self._lib.clair_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.clair_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------
+    def load_weights(self, w):
+        from clair_amd.weights import TENSOR_IDS, check_weights
+        check_weights(w)
+        for key, tid in TENSOR_IDS.items():
+            a = np.ascontiguousarray(w[key], dtype=np.float32)
+            self._check(self._lib.clair_set_tensor(self._h, tid, _ptr(a), a.size), "clair_set_tensor(%s)" % key)
+        self._check(self._lib.clair_finalize_weights(self._h), "clair_finalize_weights")
+
+    # -- predict ---------------------------------------------------------------------------
+    @staticmethod
+    def _prep_x(x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim < 2 or x.size != x.shape[0] * 1056:
+            raise ValueError("input must be [n,33,8,4] float32, got shape %s" % (x.shape,))
+        return x
+
+    @staticmethod
+    def _alloc_out(n):
+        return [np.empty((n, m), dtype=np.float32) for m in (21, 3, 33, 33)]
+
+    def predict(self, x):
+        x = self._prep_x(x)
+        outs = self._alloc_out(x.shape[0])
+        self._check(self._lib.clair_predict(self._h, _ptr(x), x.shape[0], *[_ptr(o) for o in outs]), "clair_predict")
+        return outs
+
+    def submit(self, slot, x):
+        x = self._prep_x(x)
+        outs = self._alloc_out(x.shape[0])
+        self._check(self._lib.clair_submit(self._h, slot, _ptr(x), x.shape[0], *[_ptr(o) for o in outs]), "clair_submit")
+        self._pending[slot] = (x, outs)  # keep the buffers alive until wait()
+
+    def wait(self, slot):
+        self._check(self._lib.clair_wait(self._h, slot), "clair_wait")
+        _, outs = self._pending.pop(slot)
+        return outs
+
+    # -- resident data sets ------------------------------------------------------------------
+    def dataset_alloc(self, n):
+        xd, od = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self._lib.clair_dataset_alloc(self._h, int(n), ctypes.byref(xd), ctypes.byref(od)), "clair_dataset_alloc")
+        return xd, od
+
+    def dataset_free(self, xd, od):
+        self._check(self._lib.clair_dataset_free(self._h, xd, od), "clair_dataset_free")
+
+    def dataset_upload(self, xd, first, x):
+        x = self._prep_x(x)
+        self._check(self._lib.clair_dataset_upload(self._h, xd, int(first), _ptr(x), x.shape[0]), "clair_dataset_upload")
+
+    def dataset_download(self, od, first, n):
+        out = np.empty((n, 90), dtype=np.float32)
+        self._check(self._lib.clair_dataset_download(self._h, od, int(first), _ptr(out), int(n)), "clair_dataset_download")
+        return out
+
+    def run_resident(self, slot, xd, od, first, n):
+        self._check(self._lib.clair_run_resident(self._h, int(slot), xd, od, int(first), int(n)), "clair_run_resident")
+
+    def sync(self):
+        self._check(self._lib.clair_sync(self._h), "clair_sync")
+
+    # -- measurement ---------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._lib.clair_timing_enable(self._h, int(bool(on))), "clair_timing_enable")
+
+    def timing_reset(self):
+        self._check(self._lib.clair_timing_reset(self._h), "clair_timing_reset")
+
+    def kernel_times(self):
+        ms = np.zeros(len(KERNEL_NAMES), dtype=np.float64)
+        cnt = np.zeros(len(KERNEL_NAMES), dtype=np.int64)
+        self._check(self._lib.clair_kernel_times(self._h, _ptr(ms), _ptr(cnt)), "clair_kernel_times")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    def debug_read(self, slot, which, shape):
+        out = np.empty(shape, dtype=np.float32)
+        self._check(self._lib.clair_debug_read(self._h, int(slot), int(which), _ptr(out), out.size), "clair_debug_read")
+        return out
+
+
+def split_outputs(packed):
+    """[n,90] packed rows -> [gt21, genotype, len1, len2] (copies, C-contiguous)."""
+    return [np.ascontiguousarray(packed[:, a:b]) for a, b in ((0, 21), (21, 24), (24, 57), (57, 90))]

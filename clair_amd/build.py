@@ -1,0 +1,36 @@
+"""Build the HIP extension in-tree: hipcc --offload-arch=gfx950 -> clair_amd/libclair_amd.so.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
+git-ignored but travels to the GPU box with the source snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "engine.hip")
+OUT = os.path.join(HERE, "libclair_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def needs_build():
+    if not os.path.isfile(OUT):
+        return True
+    newest = max(os.path.getmtime(os.path.join(dp, f))
+                 for dp, _, fs in os.walk(os.path.join(HERE, "csrc")) for f in fs)
+    newest = max(newest, os.path.getmtime(os.path.join(HERE, "..", "include", "clair_amd.h")))
+    return newest > os.path.getmtime(OUT)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,44 @@
+// Shared device helpers for the Clair forward-pass kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace clair {
+
+constexpr int T_POS = 33;      // positions (shared/param.py:9 -> 2*16+1)
+constexpr int F_IN = 32;       // features per position (8 rows x 4 channels)
+constexpr int HID = 128;       // LSTM units per direction (clair/model.py:92-93)
+constexpr int GATES = 512;     // 4*HID, column order i | c~ | f | o
+constexpr int L3_UNITS = 30;   // clair/model.py:81
+constexpr int L3_OUT = 7680;   // 30*256, flat index u*256+c (clair/model.py:474-478)
+constexpr int L4_UNITS = 192;  // clair/model.py:82
+constexpr int L5_UNITS = 96;   // clair/model.py:84-91
+constexpr int OUT_FLOATS = 90; // 21 + 3 + 33 + 33
+constexpr int L4_SPLITS = 16;  // split-K factor of the 7680->192 GEMM
+
+// exp via v_exp_f32 (2^x); relative error ~1 ulp, enough for the 2e-6 probability tolerance.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sigmoid / tanh as the LSTMBlockCell gate non-linearities (TF 1.13 lstm_ops; reached from
+// clair/model.py:301).  Both saturate cleanly: exp -> inf gives rcp -> 0.
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
+
+// clair/selu.py:26-30 : scale * where(x >= 0, x, alpha * elu(x))
+__device__ __forceinline__ float selu_f(float x) {
+    constexpr float alpha = 1.6732632423543772848170429916717f;
+    constexpr float scale = 1.0507009873554804934193349852946f;
+    // expm1 for x<0: exp(x)-1 loses ~1e-7 absolute near 0, harmless after the scale.
+    float neg = alpha * (fast_exp(x) - 1.0f);
+    return scale * (x >= 0.0f ? x : neg);
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace clair

@@ -1,0 +1,492 @@
+// C ABI of the MI355X engine (include/clair_amd.h): host side -- weight packing, workspaces,
+// streams, launch sequence, timing.  gfx950 only; no CPU fallback: every entry point fails
+// loudly when no HIP device is present.
+#include "../../include/clair_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hip.h"
+#include "dense.hip.h"
+#include "gemm.hip.h"
+#include "lstm.hip.h"
+
+using namespace clair;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const int64_t TENSOR_COUNT[CLAIR_T_COUNT] = {
+    160 * 512, 512, 160 * 512, 512, 384 * 512, 512, 384 * 512, 512, 256 * 33 * 30, 256 * 30,
+    7680 * 192, 192, 4 * 192 * 96, 4 * 96, 96 * 21, 21, 96 * 3, 3, 96 * 33, 33, 96 * 33, 33};
+
+struct TimedLaunch {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    float *d_x = nullptr;     // [max_pad][1056]
+    float *zx = nullptr;      // fragment-major x-projection, reused by both layers
+    float *a1 = nullptr;      // [33][max_pad][256]
+    float *a2 = nullptr;      // [33][max_pad][256]
+    float *l3 = nullptr;      // [max_pad][7680]
+    float *l4part = nullptr;  // [16][max_pad][192]
+    float *d_out = nullptr;   // [max_pad][90]
+    float *h_out = nullptr;   // pinned [max_batch][90]
+    // pending host outputs of a submit
+    float *o_gt21 = nullptr, *o_gt = nullptr, *o_l1 = nullptr, *o_l2 = nullptr;
+    int pending_n = 0;
+    int last_n_pad = 0;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> free_events;
+};
+
+}  // namespace
+
+struct clair_engine {
+    int device = 0;
+    int max_batch = 0;
+    int max_pad = 0;
+    bool weights_ready = false;
+    bool timing = false;
+    std::string error;
+    std::vector<Slot> slots;
+    std::vector<float> host_tensors[CLAIR_T_COUNT];
+    // device weights
+    float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
+    float *wh1p = nullptr, *wh2p = nullptr;
+    float *w3p = nullptr, *b3p = nullptr, *w4p = nullptr, *b4 = nullptr;
+    float *w5p = nullptr, *b5p = nullptr, *whp = nullptr, *bhp = nullptr;
+    double ms_sum[CLAIR_K_COUNT] = {0};
+    int64_t launches[CLAIR_K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(clair_engine *e, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->error = buf; else g_create_error = buf;
+    return 1;
+}
+
+#define HIP_TRY(e, call)                                                                        \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess)                                                                \
+            return fail((e), "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+    } while (0)
+
+int upload(clair_engine *e, float **dst, const std::vector<float> &src) {
+    HIP_TRY(e, hipMalloc((void **)dst, src.size() * sizeof(float)));
+    HIP_TRY(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// x-part of the two directions' LSTM kernels -> Bp[slab][1024][16]  (gemm.hip.h)
+std::vector<float> pack_wx(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
+    std::vector<float> out((size_t)D * 1024);
+    for (int k = 0; k < D; ++k)
+        for (int col = 0; col < 1024; ++col) {
+            const std::vector<float> &src = col < 512 ? fw : bw;
+            out[((size_t)(k / 16) * 1024 + col) * 16 + (k % 16)] = src[(size_t)k * 512 + (col & 511)];
+        }
+    return out;
+}
+
+// h-part -> [dir][wave][nb][k4][lane][j] = W[D + lq*32 + k4*4 + j][g*128 + 32w + 16hh + li]  (lstm.hip.h)
+std::vector<float> pack_wh(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
+    std::vector<float> out((size_t)2 * 4 * 8 * 8 * 64 * 4);
+    size_t o = 0;
+    for (int d = 0; d < 2; ++d) {
+        const std::vector<float> &src = d ? bw : fw;
+        for (int w = 0; w < 4; ++w)
+            for (int nb = 0; nb < 8; ++nb)
+                for (int k4 = 0; k4 < 8; ++k4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
+                            int k = lq * 32 + k4 * 4 + j;
+                            int col = g * 128 + 32 * w + 16 * hh + li;
+                            out[o++] = src[(size_t)(D + k) * 512 + col];
+                        }
+    }
+    return out;
+}
+
+void free_slot(Slot &s) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    for (auto &t : s.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto ev : s.free_events) (void)hipEventDestroy(ev);
+    (void)hipFree(s.d_x); (void)hipFree(s.zx); (void)hipFree(s.a1); (void)hipFree(s.a2);
+    (void)hipFree(s.l3); (void)hipFree(s.l4part); (void)hipFree(s.d_out);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+}
+
+hipEvent_t get_event(Slot &s) {
+    if (!s.free_events.empty()) {
+        hipEvent_t ev = s.free_events.back();
+        s.free_events.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct KernelTimer {
+    clair_engine *e; Slot &s; int id; hipEvent_t start = nullptr, stop = nullptr;
+    KernelTimer(clair_engine *e_, Slot &s_, int id_) : e(e_), s(s_), id(id_) {
+        if (e->timing) { start = get_event(s); stop = get_event(s); (void)hipEventRecord(start, s.stream); }
+    }
+    ~KernelTimer() {
+        if (e->timing) { (void)hipEventRecord(stop, s.stream); s.timed.push_back({id, start, stop}); }
+    }
+};
+
+int drain_timers(clair_engine *e) {
+    for (auto &s : e->slots) {
+        HIP_TRY(e, hipStreamSynchronize(s.stream));
+        for (auto &t : s.timed) {
+            float ms = 0.f;
+            HIP_TRY(e, hipEventElapsedTime(&ms, t.start, t.stop));
+            e->ms_sum[t.kernel] += ms;
+            e->launches[t.kernel] += 1;
+            s.free_events.push_back(t.start);
+            s.free_events.push_back(t.stop);
+        }
+        s.timed.clear();
+    }
+    return 0;
+}
+
+// Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
+// zero or any finite value) writing packed outputs to out_dev ([n][90]).
+int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
+    const int n_pad = (n + 15) & ~15;
+    const int ntiles = n_pad / 16;
+    const int m_rows = T_POS * n_pad;
+    s.last_n_pad = n_pad;
+    {   // LSTM1 input projection
+        KernelTimer kt(e, s, CLAIR_K_PROJ1);
+        GemmArgs a{x_dev, e->wx1p, e->bx1, s.zx, n_pad, ntiles, m_rows, F_IN / 16};
+        dim3 grid((m_rows + 127) / 128, 8, 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ1, 4>), grid, dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_LSTM1);
+        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_PROJ2);
+        GemmArgs a{s.a1, e->wx2p, e->bx2, s.zx, n_pad, ntiles, m_rows, (2 * HID) / 16};
+        dim3 grid((m_rows + 127) / 128, 8, 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ2, 4>), grid, dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_LSTM2);
+        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_L3);
+        L3Args a{s.a2, e->w3p, e->b3p, s.l3, n_pad};
+        hipLaunchKernelGGL(l3_kernel, dim3(n_pad / L3_CAND), dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_L4);
+        GemmArgs a{s.l3, e->w4p, nullptr, s.l4part, n_pad, ntiles, n_pad, (L3_OUT / 16) / L4_SPLITS};
+        dim3 grid((n_pad + 127) / 128, 1, L4_SPLITS);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_L4, 6>), grid, dim3(256), 0, s.stream, a);
+    }
+    {
+        KernelTimer kt(e, s, CLAIR_K_TAIL);
+        TailArgs a{s.l4part, e->b4, e->w5p, e->b5p, e->whp, e->bhp, out_dev, n_pad, n};
+        hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_CAND), dim3(256), 0, s.stream, a);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return 0;
+}
+
+int check_slot(clair_engine *e, int slot) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(e, "slot %d out of range [0,%d)", slot, (int)e->slots.size());
+    if (!e->weights_ready) return fail(e, "weights not loaded: call clair_set_tensor for all tensors, then clair_finalize_weights");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clair_abi_version(void) { return CLAIR_ABI_VERSION; }
+
+int clair_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *clair_last_error(const clair_engine_t *e) { return e ? e->error.c_str() : g_create_error.c_str(); }
+
+int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t **out) {
+    if (!out) return fail(nullptr, "out is NULL");
+    *out = nullptr;
+    if (max_batch < 1 || max_batch > (1 << 20)) return fail(nullptr, "max_batch %d out of range [1, 2^20]", max_batch);
+    if (n_slots < 1 || n_slots > 64) return fail(nullptr, "n_slots %d out of range [1,64]", n_slots);
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0)
+        return fail(nullptr, "no HIP device available (hipGetDeviceCount: %s); the MI355X engine has no CPU fallback",
+                    hipGetErrorString(err));
+    if (device < 0 || device >= ndev) return fail(nullptr, "device %d out of range [0,%d)", device, ndev);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    clair_engine *e = new clair_engine();
+    e->device = device;
+    e->max_batch = max_batch;
+    e->max_pad = (max_batch + 15) & ~15;
+    e->slots.resize(n_slots);
+    const size_t mp = e->max_pad;
+    for (auto &s : e->slots) {
+        hipError_t r = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, (size_t)T_POS * mp * 256 * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.l3, mp * L3_OUT * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, (size_t)max_batch * OUT_FLOATS * sizeof(float), hipHostMallocDefault);
+        if (r != hipSuccess) {
+            fail(nullptr, "allocating slot workspaces for max_batch=%d failed: %s", max_batch, hipGetErrorString(r));
+            clair_engine_destroy(e);
+            return 1;
+        }
+    }
+    *out = e;
+    return 0;
+}
+
+void clair_engine_destroy(clair_engine_t *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (auto &s : e->slots) free_slot(s);
+    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->wh1p, e->wh2p, e->w3p, e->b3p, e->w4p, e->b4, e->w5p, e->b5p, e->whp, e->bhp};
+    for (float *p : w) (void)hipFree(p);
+    delete e;
+}
+
+int clair_set_tensor(clair_engine_t *e, int id, const float *host, int64_t count) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (id < 0 || id >= CLAIR_T_COUNT) return fail(e, "tensor id %d out of range", id);
+    if (!host) return fail(e, "tensor %d: host pointer is NULL", id);
+    if (count != TENSOR_COUNT[id]) return fail(e, "tensor %d: got %lld floats, expected %lld", id, (long long)count, (long long)TENSOR_COUNT[id]);
+    e->host_tensors[id].assign(host, host + count);
+    e->weights_ready = false;
+    return 0;
+}
+
+int clair_finalize_weights(clair_engine_t *e) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    for (int i = 0; i < CLAIR_T_COUNT; ++i)
+        if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
+    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->wh1p, &e->wh2p, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5p, &e->b5p, &e->whp, &e->bhp};
+    for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
+    auto &T = e->host_tensors;
+    auto cat = [](const std::vector<float> &a, const std::vector<float> &b) { std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end()); return r; };
+    if (upload(e, &e->wx1p, pack_wx(T[0], T[2], F_IN))) return 1;
+    if (upload(e, &e->bx1, cat(T[1], T[3]))) return 1;
+    if (upload(e, &e->wx2p, pack_wx(T[4], T[6], 2 * HID))) return 1;
+    if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
+    if (upload(e, &e->wh1p, pack_wh(T[0], T[2], F_IN))) return 1;
+    if (upload(e, &e->wh2p, pack_wh(T[4], T[6], 2 * HID))) return 1;
+    {   // W3p[t][u][c] = l3_kernel[c][t][u]; b3p[u][c]
+        std::vector<float> w3((size_t)T_POS * L3_UNITS * 256), b3((size_t)L3_UNITS * 256);
+        for (int c = 0; c < 256; ++c)
+            for (int t = 0; t < T_POS; ++t)
+                for (int u = 0; u < L3_UNITS; ++u) w3[((size_t)t * L3_UNITS + u) * 256 + c] = T[8][((size_t)c * T_POS + t) * L3_UNITS + u];
+        for (int c = 0; c < 256; ++c)
+            for (int u = 0; u < L3_UNITS; ++u) b3[(size_t)u * 256 + c] = T[9][(size_t)c * L3_UNITS + u];
+        if (upload(e, &e->w3p, w3) || upload(e, &e->b3p, b3)) return 1;
+    }
+    {   // W4p[slab][192][16]
+        std::vector<float> w4((size_t)L3_OUT * L4_UNITS);
+        for (int k = 0; k < L3_OUT; ++k)
+            for (int col = 0; col < L4_UNITS; ++col) w4[((size_t)(k / 16) * L4_UNITS + col) * 16 + (k % 16)] = T[10][(size_t)k * L4_UNITS + col];
+        if (upload(e, &e->w4p, w4) || upload(e, &e->b4, T[11])) return 1;
+    }
+    {   // W5p[k][k5*96+j]
+        std::vector<float> w5((size_t)L4_UNITS * 4 * L5_UNITS);
+        for (int k5 = 0; k5 < 4; ++k5)
+            for (int k = 0; k < L4_UNITS; ++k)
+                for (int j = 0; j < L5_UNITS; ++j) w5[(size_t)k * (4 * L5_UNITS) + k5 * L5_UNITS + j] = T[12][((size_t)k5 * L4_UNITS + k) * L5_UNITS + j];
+        if (upload(e, &e->w5p, w5) || upload(e, &e->b5p, T[13])) return 1;
+    }
+    {   // heads: Whp[k][o], o = packed output column
+        const int sizes[4] = {21, 3, 33, 33}, offs[4] = {0, 21, 24, 57};
+        std::vector<float> wh((size_t)L5_UNITS * OUT_FLOATS), bh(OUT_FLOATS);
+        for (int k5 = 0; k5 < 4; ++k5)
+            for (int j = 0; j < sizes[k5]; ++j) {
+                bh[offs[k5] + j] = T[15 + 2 * k5][j];
+                for (int k = 0; k < L5_UNITS; ++k) wh[(size_t)k * OUT_FLOATS + offs[k5] + j] = T[14 + 2 * k5][(size_t)k * sizes[k5] + j];
+            }
+        if (upload(e, &e->whp, wh) || upload(e, &e->bhp, bh)) return 1;
+    }
+    e->weights_ready = true;
+    return 0;
+}
+
+int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21, float *genotype, float *l1, float *l2) {
+    if (check_slot(e, slot)) return 1;
+    if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
+    if (!x || !gt21 || !genotype || !l1 || !l2) return fail(e, "NULL input/output pointer");
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
+    const int n_pad = (n + 15) & ~15;
+    HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+    if (n_pad > n)
+        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
+    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
+    HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
+    s.pending_n = n;
+    return 0;
+}
+
+int clair_wait(clair_engine_t *e, int slot) {
+    if (check_slot(e, slot)) return 1;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    const int n = s.pending_n;
+    for (int i = 0; i < n; ++i) {
+        const float *row = s.h_out + (size_t)i * OUT_FLOATS;
+        memcpy(s.o_gt21 + (size_t)i * 21, row, 21 * sizeof(float));
+        memcpy(s.o_gt + (size_t)i * 3, row + 21, 3 * sizeof(float));
+        memcpy(s.o_l1 + (size_t)i * 33, row + 24, 33 * sizeof(float));
+        memcpy(s.o_l2 + (size_t)i * 33, row + 57, 33 * sizeof(float));
+    }
+    s.pending_n = 0;
+    return 0;
+}
+
+int clair_predict(clair_engine_t *e, const float *x, int n, float *gt21, float *genotype, float *l1, float *l2) {
+    if (clair_submit(e, 0, x, n, gt21, genotype, l1, l2)) return 1;
+    return clair_wait(e, 0);
+}
+
+int clair_dataset_alloc(clair_engine_t *e, int64_t N, void **x_dev, void **out_dev) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (N < 1 || !x_dev || !out_dev) return fail(e, "bad arguments to clair_dataset_alloc");
+    HIP_TRY(e, hipSetDevice(e->device));
+    // +max_pad rows of zeroed slack so the last (padded) tile of a run never reads past the end
+    const size_t rows = (size_t)N + e->max_pad;
+    HIP_TRY(e, hipMalloc(x_dev, rows * CLAIR_INPUT_FLOATS * sizeof(float)));
+    HIP_TRY(e, hipMemset(*x_dev, 0, rows * CLAIR_INPUT_FLOATS * sizeof(float)));
+    HIP_TRY(e, hipMalloc(out_dev, rows * OUT_FLOATS * sizeof(float)));
+    HIP_TRY(e, hipMemset(*out_dev, 0, rows * OUT_FLOATS * sizeof(float)));
+    return 0;
+}
+
+int clair_dataset_free(clair_engine_t *e, void *x_dev, void *out_dev) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipFree(x_dev));
+    HIP_TRY(e, hipFree(out_dev));
+    return 0;
+}
+
+int clair_dataset_upload(clair_engine_t *e, void *x_dev, int64_t first, const float *x_host, int64_t n) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpy((float *)x_dev + (size_t)first * CLAIR_INPUT_FLOATS, x_host, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int clair_dataset_download(clair_engine_t *e, const void *out_dev, int64_t first, float *out_host, int64_t n) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    HIP_TRY(e, hipMemcpy(out_host, (const float *)out_dev + (size_t)first * OUT_FLOATS, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int clair_run_resident(clair_engine_t *e, int slot, const void *x_dev, void *out_dev, int64_t first, int n) {
+    if (check_slot(e, slot)) return 1;
+    if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
+    HIP_TRY(e, hipSetDevice(e->device));
+    return enqueue_forward(e, e->slots[slot], (const float *)x_dev + (size_t)first * CLAIR_INPUT_FLOATS,
+                           (float *)out_dev + (size_t)first * OUT_FLOATS, n);
+}
+
+int clair_sync(clair_engine_t *e) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+int clair_timing_enable(clair_engine_t *e, int on) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (drain_timers(e)) return 1;
+    e->timing = on != 0;
+    return 0;
+}
+
+int clair_kernel_times(clair_engine_t *e, double *ms_sum, int64_t *launches) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (drain_timers(e)) return 1;
+    for (int k = 0; k < CLAIR_K_COUNT; ++k) {
+        if (ms_sum) ms_sum[k] = e->ms_sum[k];
+        if (launches) launches[k] = e->launches[k];
+    }
+    return 0;
+}
+
+int clair_timing_reset(clair_engine_t *e) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (drain_timers(e)) return 1;
+    for (int k = 0; k < CLAIR_K_COUNT; ++k) { e->ms_sum[k] = 0; e->launches[k] = 0; }
+    return 0;
+}
+
+int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count) {
+    if (check_slot(e, slot)) return 1;
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    const float *src = nullptr;
+    int64_t avail = 0;
+    const int64_t np = s.last_n_pad;
+    switch (which) {
+        case 1: src = s.a1; avail = (int64_t)T_POS * np * 256; break;
+        case 2: src = s.a2; avail = (int64_t)T_POS * np * 256; break;
+        case 3: src = s.l3; avail = np * L3_OUT; break;
+        default: return fail(e, "clair_debug_read: unknown tap %d", which);
+    }
+    if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);
+    HIP_TRY(e, hipMemcpy(host, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

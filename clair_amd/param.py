@@ -1,0 +1,12 @@
+"""Tensor geometry and batch defaults (counterpart of /root/reference/shared/param.py:1-16).
+
+Only the values the inference path reads are kept; training hyper-parameters are out of scope.
+"""
+REPO_NAME = "Clair"
+NUM_THREADS = 12            # shared/param.py:3 (host-side threads; the GPU engine ignores it)
+flankingBaseNum = 16        # shared/param.py:9
+matrixRow = 8               # shared/param.py:10
+matrixNum = 4               # shared/param.py:11
+predictBatchSize = 1000     # shared/param.py:16
+no_of_positions = 2 * flankingBaseNum + 1
+input_tensor_size = no_of_positions * matrixRow * matrixNum  # 1056

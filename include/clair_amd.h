@@ -1,0 +1,143 @@
+/*
+ * clair_amd.h -- C ABI of the MI355X (gfx950) engine for Clair's call_var forward pass.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class
+ * clair.model.Clair (/root/reference/clair/model.py:24) as driven by
+ * clair/call_var.py:213-215, 1337, 1343.  Each entry point below names the reference
+ * member it stands behind; clair_amd/model.py is the ctypes shim that re-creates the
+ * Python interface on top of it (INTEGRATION.md shows the binding).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * non-zero code on failure, with a message available from clair_last_error(); float32
+ * everywhere (clair/model.py:167-168 forces tf.float32 for the LSTM structure).
+ * Functions taking an engine are not re-entrant on one engine (the reference never calls
+ * predict concurrently with itself, clair/call_var.py:1349-1352) but may be called from
+ * any thread: the HIP device is selected on every call.
+ */
+#ifndef CLAIR_AMD_H
+#define CLAIR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLAIR_ABI_VERSION 1
+
+/* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
+#define CLAIR_POSITIONS 33
+#define CLAIR_FEATURES 32
+#define CLAIR_INPUT_FLOATS (CLAIR_POSITIONS * CLAIR_FEATURES) /* 1056 */
+#define CLAIR_GT21 21
+#define CLAIR_GENOTYPE 3
+#define CLAIR_INDEL_LEN 33
+#define CLAIR_OUTPUT_FLOATS 90
+
+/* Weight tensors of the inference graph (clair/model.py:400-620), row-major, float32.
+ * TF variable names: clair_amd/weights.py:tf_variable_names(). */
+enum clair_tensor_id {
+    CLAIR_T_LSTM1_FW_KERNEL = 0, /* [160,512]  rows 0..31 multiply x, 32..159 multiply h; cols i|c~|f|o */
+    CLAIR_T_LSTM1_FW_BIAS = 1,   /* [512] */
+    CLAIR_T_LSTM1_BW_KERNEL = 2,
+    CLAIR_T_LSTM1_BW_BIAS = 3,
+    CLAIR_T_LSTM2_FW_KERNEL = 4, /* [384,512] */
+    CLAIR_T_LSTM2_FW_BIAS = 5,
+    CLAIR_T_LSTM2_BW_KERNEL = 6,
+    CLAIR_T_LSTM2_BW_BIAS = 7,
+    CLAIR_T_L3_KERNEL = 8,       /* [256,33,30]  L3/Unit_c/kernel stacked over c */
+    CLAIR_T_L3_BIAS = 9,         /* [256,30] */
+    CLAIR_T_L4_KERNEL = 10,      /* [7680,192]  input index u*256+c */
+    CLAIR_T_L4_BIAS = 11,        /* [192] */
+    CLAIR_T_L5_KERNEL = 12,      /* [4,192,96]  L5_1..L5_4 */
+    CLAIR_T_L5_BIAS = 13,        /* [4,96] */
+    CLAIR_T_HEAD_GT21_KERNEL = 14,     /* [96,21] */
+    CLAIR_T_HEAD_GT21_BIAS = 15,
+    CLAIR_T_HEAD_GENOTYPE_KERNEL = 16, /* [96,3] */
+    CLAIR_T_HEAD_GENOTYPE_BIAS = 17,
+    CLAIR_T_HEAD_LEN1_KERNEL = 18,     /* [96,33] */
+    CLAIR_T_HEAD_LEN1_BIAS = 19,
+    CLAIR_T_HEAD_LEN2_KERNEL = 20,     /* [96,33] */
+    CLAIR_T_HEAD_LEN2_BIAS = 21,
+    CLAIR_T_COUNT = 22
+};
+
+/* kernels of one forward pass, in launch order (index into clair_kernel_times) */
+enum clair_kernel_id {
+    CLAIR_K_PROJ1 = 0,  /* LSTM1 input projection GEMM  [33n,32]x[32,1024]   */
+    CLAIR_K_LSTM1 = 1,  /* LSTM1 recurrence, both directions                 */
+    CLAIR_K_PROJ2 = 2,  /* LSTM2 input projection GEMM  [33n,256]x[256,1024] */
+    CLAIR_K_LSTM2 = 3,  /* LSTM2 recurrence                                  */
+    CLAIR_K_L3 = 4,     /* slice dense 256 x (33->30) + selu                 */
+    CLAIR_K_L4 = 5,     /* split-K GEMM 7680->192                            */
+    CLAIR_K_TAIL = 6,   /* L4 reduce+selu, L5 x4, heads, selu, softmax       */
+    CLAIR_K_COUNT = 7
+};
+
+typedef struct clair_engine clair_engine_t;
+
+/* -- lifetime: Clair() + Clair.init()  (clair/model.py:58-192, 807-813) ------------------------
+ * device: HIP device ordinal.  max_batch: largest n accepted by one predict/submit.
+ * n_slots: number of independent pipeline slots (each has its own HIP stream and workspace);
+ * 1 is enough for the synchronous predict. */
+int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t **out);
+/* Clair.close() / __del__  (clair/model.py:872-876, 1149-1152) */
+void clair_engine_destroy(clair_engine_t *e);
+/* message of the last failure on this engine (e may be NULL: failure of clair_engine_create) */
+const char *clair_last_error(const clair_engine_t *e);
+int clair_abi_version(void);
+/* number of HIP devices visible (0 when there is none); negative never */
+int clair_device_count(void);
+
+/* -- weights: Clair.restore_parameters()  (clair/model.py:1016-1020) ----------------------------
+ * Hand over one tensor (host pointer, `count` floats, shape as in enum clair_tensor_id);
+ * after all CLAIR_T_COUNT tensors are set, clair_finalize_weights packs them into the
+ * device layouts the kernels read.  The host pointers are not retained. */
+int clair_set_tensor(clair_engine_t *e, int tensor_id, const float *host, int64_t count);
+int clair_finalize_weights(clair_engine_t *e);
+
+/* -- Clair.predict(batchX)  (clair/model.py:946-966; called at clair/call_var.py:1343) ----------
+ * x: host, C-contiguous [n,33,8,4] float32 (channels 1..3 already minus channel 0,
+ * clair/utils.py:96-98); 1 <= n <= max_batch.  Outputs: caller-allocated host arrays
+ * [n,21] [n,3] [n,33] [n,33].  Synchronous; x is not retained. */
+int clair_predict(clair_engine_t *e, const float *x, int n, float *gt21, float *genotype,
+                  float *indel_len1, float *indel_len2);
+
+/* -- pipelined form of the same call (what call_var's load/predict/output threads overlap,
+ *    clair/call_var.py:1331-1352): submit copies x to the device and enqueues the forward pass on
+ *    slot `slot`; wait blocks until that slot's outputs are in the caller's arrays.
+ *    x and the output arrays must stay valid until wait returns. */
+int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21, float *genotype,
+                 float *indel_len1, float *indel_len2);
+int clair_wait(clair_engine_t *e, int slot);
+
+/* -- device-resident candidate sets (benchmark / multi-GPU shard driver) ------------------------
+ * The candidate set lives in HBM: x_dev [N,33,8,4]; outputs out_dev [N,90] rows laid out
+ * gt21(21) | genotype(3) | len1(33) | len2(33).  clair_run_resident enqueues the forward pass
+ * for candidates [first, first+n) on slot `slot` (no host copies) and returns immediately;
+ * clair_sync waits for all slots. */
+int clair_dataset_alloc(clair_engine_t *e, int64_t n_candidates, void **x_dev, void **out_dev);
+int clair_dataset_free(clair_engine_t *e, void *x_dev, void *out_dev);
+int clair_dataset_upload(clair_engine_t *e, void *x_dev, int64_t first, const float *x_host, int64_t n);
+int clair_dataset_download(clair_engine_t *e, const void *out_dev, int64_t first, float *out_host, int64_t n);
+int clair_run_resident(clair_engine_t *e, int slot, const void *x_dev, void *out_dev, int64_t first, int n);
+int clair_sync(clair_engine_t *e);
+
+/* -- measurement ---------------------------------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by HIP events on the slot's own stream.
+ * clair_kernel_times returns, per kernel id, the summed duration in milliseconds and the number
+ * of launches since the last reset (it synchronises first). */
+int clair_timing_enable(clair_engine_t *e, int on);
+int clair_kernel_times(clair_engine_t *e, double *ms_sum /*[CLAIR_K_COUNT]*/, int64_t *launches /*[CLAIR_K_COUNT]*/);
+int clair_timing_reset(clair_engine_t *e);
+
+/* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
+ *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
+ *    3 = L3 output [n_pad,7680], 4 = L4 pre-activation partial sums reduced [n_pad,192] is not
+ *    materialised -- use the outputs.  n_pad = n rounded up to 16. */
+int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLAIR_AMD_H */

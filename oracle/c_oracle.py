@@ -1,0 +1,57 @@
+"""ctypes loader for oracle/libclair_oracle.so (TEST INFRASTRUCTURE ONLY, see clair_oracle.c)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+TENSOR_ORDER = (
+    "lstm1_fw_kernel", "lstm1_fw_bias", "lstm1_bw_kernel", "lstm1_bw_bias",
+    "lstm2_fw_kernel", "lstm2_fw_bias", "lstm2_bw_kernel", "lstm2_bw_bias",
+    "l3_kernel", "l3_bias", "l4_kernel", "l4_bias", "l5_kernel", "l5_bias",
+    "head_gt21_kernel", "head_gt21_bias", "head_genotype_kernel", "head_genotype_bias",
+    "head_len1_kernel", "head_len1_bias", "head_len2_kernel", "head_len2_bias",
+)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libclair_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libclair_oracle.so")
+        if not os.path.isfile(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.clair_oracle_forward_ex.restype = ctypes.c_int
+        _LIB.clair_oracle_max_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def max_threads():
+    return int(lib().clair_oracle_max_threads())
+
+
+def forward(w, x, threads=0, keep_intermediates=False):
+    """x [n,33,8,4] float32 -> [gt21, genotype, len1, len2] (+ dict of intermediates)."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    keep = [np.ascontiguousarray(w[k], dtype=np.float32) for k in TENSOR_ORDER]
+    ptrs = (ctypes.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+    outs = [np.empty((n, m), dtype=np.float32) for m in (21, 3, 33, 33)]
+    inter = {}
+    if keep_intermediates:
+        inter = dict(a1=np.empty((n, 33, 256), np.float32), a2=np.empty((n, 33, 256), np.float32),
+                     l3=np.empty((n, 7680), np.float32), l4=np.empty((n, 192), np.float32))
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    opt = lambda k: p(inter[k]) if keep_intermediates else ctypes.c_void_p(0)
+    rc = L.clair_oracle_forward_ex(ptrs, p(x), ctypes.c_int(n), *[p(o) for o in outs],
+                                   opt("a1"), opt("a2"), opt("l3"), opt("l4"), ctypes.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("clair_oracle_forward failed (rc=%d)" % rc)
+    return (outs, inter) if keep_intermediates else outs

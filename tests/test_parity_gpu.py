@@ -1,0 +1,84 @@
+"""GPU parity: the HIP forward pass (through the C ABI) against the CPU oracle.
+
+Tolerances (stated, absolute, on probabilities in [0,1]): 2e-6 against the float32 oracle.
+The oracle itself sits within ~3e-7 of a float64 evaluation of the same graph
+(tests/test_oracle.py), so 2e-6 covers fp32 summation-order and exp/rcp ulp differences.
+"""
+import numpy as np
+import pytest
+
+from clair_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 2e-6
+ACT_TOL = 5e-6   # LSTM / L3 activations, |a| <= ~2
+
+
+def _oracle(w, x, **kw):
+    from oracle import c_oracle
+    return c_oracle.forward(w, x, **kw)
+
+
+@pytest.mark.parametrize("n,platform", [(1, "ont"), (7, "ont"), (16, "pacbio_ccs"), (100, "illumina"), (1000, "ont"), (1024, "ont")])
+def test_predict_matches_oracle(engine, synth_weights, n, platform):
+    x, _ = synth.synthetic_input(n, platform, seed=1000 + n)
+    got = engine.predict(x)
+    want = _oracle(synth_weights, x)
+    for g, w_, name in zip(got, want, ("gt21", "genotype", "len1", "len2")):
+        assert g.shape == w_.shape and g.dtype == np.float32
+        assert np.isfinite(g).all()
+        err = np.abs(g - w_).max()
+        assert err <= PROB_TOL, "%s max abs err %g" % (name, err)
+        assert np.abs(g.sum(axis=1) - 1).max() < 1e-5
+
+
+def test_layerwise_taps(engine, synth_weights):
+    n = 48
+    x, _ = synth.synthetic_input(n, "ont", seed=77)
+    engine.predict(x)
+    want, inter = _oracle(synth_weights, x, keep_intermediates=True)
+    a1 = engine.debug_read(0, 1, (33, n, 256)).transpose(1, 0, 2)
+    a2 = engine.debug_read(0, 2, (33, n, 256)).transpose(1, 0, 2)
+    l3 = engine.debug_read(0, 3, (n, 7680))
+    assert np.abs(a1 - inter["a1"]).max() <= ACT_TOL
+    assert np.abs(a2 - inter["a2"]).max() <= ACT_TOL
+    assert np.abs(l3 - inter["l3"]).max() <= 2e-5
+
+
+def test_submit_wait_two_slots(engine, synth_weights):
+    xa, _ = synth.synthetic_input(300, "ont", seed=5)
+    xb, _ = synth.synthetic_input(513, "ont", seed=6)
+    engine.submit(0, xa)
+    engine.submit(1, xb)
+    ga, gb = engine.wait(0), engine.wait(1)
+    for g, w_ in zip(ga, _oracle(synth_weights, xa)):
+        assert np.abs(g - w_).max() <= PROB_TOL
+    for g, w_ in zip(gb, _oracle(synth_weights, xb)):
+        assert np.abs(g - w_).max() <= PROB_TOL
+
+
+def test_resident_dataset_matches_predict(engine, synth_weights):
+    from clair_amd._capi import split_outputs
+    n, batch = 2500, 1024
+    x, _ = synth.synthetic_input(n, "ont", seed=9)
+    xd, od = engine.dataset_alloc(n)
+    try:
+        engine.dataset_upload(xd, 0, x)
+        for k, first in enumerate(range(0, n, batch)):
+            engine.run_resident(k % 2, xd, od, first, min(batch, n - first))
+        engine.sync()
+        packed = engine.dataset_download(od, 0, n)
+    finally:
+        engine.dataset_free(xd, od)
+    want = _oracle(synth_weights, x)
+    for g, w_ in zip(split_outputs(packed), want):
+        assert np.abs(g - w_).max() <= PROB_TOL
+
+
+def test_run_to_run_deterministic(engine):
+    x, _ = synth.synthetic_input(200, "ont", seed=3)
+    a = engine.predict(x)
+    b = engine.predict(x)
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
