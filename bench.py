@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: candidate sites/sec of the call_var forward pass on N MI355X.
+
+A "step" is one pass of the hot path (BiLSTM x2 -> slice dense -> dense tail -> softmax
+heads) over one batch of synthetic pileup tensors already resident in HBM.  Default workload is
+BASELINE.json configs[1]: ONT-profile candidates, batch 1024, one GPU.  Candidate sites shard
+across ranks with no data-path collective (scaling: weak, per-rank work fixed); for N>1 the
+driver launches one rank per GPU through torch.distributed.run and RCCL is used only for the
+barrier / max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     -- the dominant kernel, timed with HIP events on its own stream inside the timed
+                  region: algorithmic FLOP per launch / mean launch duration vs the 157.3 TFLOP/s
+                  fp32-input MFMA peak (MI355X_MICROARCH.md)
+  cpu_baseline -- the C port of the same forward pass (oracle/clair_oracle.c, OpenMP) timed on the
+                  host cores of this box on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from clair_amd import _capi, synth, weights  # noqa: E402
+
+FLOP_PER_CANDIDATE = 40386432          # 2 x 20 193 216 MAC
+KERNEL_FLOP = {                         # algorithmic FLOP per candidate, per kernel
+    "proj1": 2 * 33 * 2 * 32 * 512,
+    "lstm1": 2 * 33 * 2 * 128 * 512,
+    "proj2": 2 * 33 * 2 * 256 * 512,
+    "lstm2": 2 * 33 * 2 * 128 * 512,
+    "l3": 2 * 256 * 33 * 30,
+    "l4": 2 * 7680 * 192,
+    "tail": 2 * (4 * 192 * 96 + 96 * 90),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
+PLATFORM = {"ont": "ONT 122HD34", "pacbio_ccs": "PacBio CCS 15", "illumina": "Illumina 12345"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=196)      # 196 x 1024 ~= 200k chr20 candidate sites
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--streams", type=int, default=4, help="pipeline slots (HIP streams) with batches in flight")
+    ap.add_argument("--platform", default="ont", choices=sorted(PLATFORM))
+    ap.add_argument("--unique-batches", type=int, default=8, help="distinct synthetic batches kept resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(w, x, seconds):
+    """Time the C port on all host cores on a bounded sample of the same workload."""
+    from oracle import c_oracle
+    cores = c_oracle.max_threads()
+    probe = min(256, x.shape[0])
+    t0 = time.perf_counter()
+    c_oracle.forward(w, x[:probe])
+    rate = probe / (time.perf_counter() - t0)
+    n = int(max(probe, min(x.shape[0], rate * seconds)))
+    t0 = time.perf_counter()
+    c_oracle.forward(w, x[:n])
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "%d candidates of the same synthetic batch, oracle/clair_oracle.c with OpenMP over %d threads, %.1f s"
+                      % (n, cores, dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    batch, streams = args.batch, max(1, args.streams)
+    w = weights.synthetic_weights(seed=20250928, head_gain=4.0)
+    eng = _capi.Engine(device=local_rank, max_batch=batch, n_slots=streams)
+    eng.load_weights(w)
+
+    nuniq = max(1, min(args.unique_batches, args.steps + args.warmup))
+    x, _ = synth.synthetic_input(nuniq * batch, args.platform, seed=20250928 + rank)
+    xd, od = eng.dataset_alloc(nuniq * batch)
+    eng.dataset_upload(xd, 0, x)
+
+    def run(steps):
+        for i in range(steps):
+            eng.run_resident(i % streams, xd, od, (i % nuniq) * batch, batch)
+
+    run(args.warmup)
+    eng.sync()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    barrier()
+    eng.sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    eng.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    times = eng.kernel_times()
+    eng.timing_enable(False)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity spot check of one resident batch against the oracle (outside the timed region)
+    parity = None
+    if rank == 0:
+        from oracle import c_oracle
+        got = _capi.split_outputs(eng.dataset_download(od, 0, min(256, batch)))
+        want = c_oracle.forward(w, x[:min(256, batch)])
+        parity = max(float(np.abs(g - t_).max()) for g, t_ in zip(got, want))
+
+    if rank == 0:
+        total = args.steps * batch * world
+        value = total / elapsed
+        kern = {k: {"ms_mean": (ms / cnt if cnt else None), "launches": cnt} for k, (ms, cnt) in times.items()}
+        dom = max(times, key=lambda k: times[k][0])
+        dom_ms = times[dom][0] / max(times[dom][1], 1)
+        achieved = KERNEL_FLOP[dom] * batch / (dom_ms * 1e-3) / 1e12
+        out = {
+            "metric": "candidate sites/sec (whole node)",
+            "value": round(value, 1),
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s weights-shape model (random init), synthetic %s-profile pileup tensors, "
+                                   "batch=%d, %d batches in flight per GPU, inputs resident in HBM"
+                                   % (PLATFORM[args.platform], args.platform, batch, streams),
+                       "batch": batch, "streams": streams, "candidates_per_gpu": args.steps * batch},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(dom_ms, 4),
+                         "flop_per_launch": KERNEL_FLOP[dom] * batch},
+            "roofline_path": {"achieved": round(value / world * FLOP_PER_CANDIDATE / 1e12, 2),
+                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(value / world * FLOP_PER_CANDIDATE / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+            "kernels": kern,
+            "parity_max_abs_err": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, x, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    eng.dataset_free(xd, od)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

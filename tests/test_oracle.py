@@ -1,0 +1,131 @@
+"""CPU tests of the oracle: the NumPy restatement, the C port, an independent torch-CPU
+implementation and a float64 evaluation must agree; the committed golden fixture must reproduce.
+
+The reference holds no golden vectors for this path ("parity unpinned"), so the
+pin is: two independent float32 implementations + float64 agreeing to <= 2e-6, plus structural
+properties of the reference graph (gate order, backward direction, L3 flat layout).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from clair_amd import synth, weights
+from oracle import c_oracle, model_np
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "nn_forward_64.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with np.load(GOLDEN) as z:
+        g = {k: z[k] for k in z.files}
+    w = weights.synthetic_weights(seed=int(g["seed_w"]), head_gain=float(g["head_gain"]),
+                                  lstm_bias_scale=float(g["lstm_bias_scale"]))
+    return g, w, synth.to_model_input(g["raw"].astype(np.int32))
+
+
+def test_numpy_oracle_reproduces_golden(golden):
+    g, w, x = golden
+    outs, inter = model_np.forward(w, x, keep_intermediates=True)
+    for got, key in zip(outs, ("gt21", "genotype", "len1", "len2")):
+        assert np.abs(got - g[key]).max() <= 1e-6
+    assert np.abs(inter["a1"][:, :4] - g["a1_first4"]).max() <= 1e-6
+    assert np.abs(inter["a2"][:, :4] - g["a2_first4"]).max() <= 1e-6
+    assert np.abs(inter["l3"][:4] - g["l3_first4"]).max() <= 2e-6
+    assert np.abs(inter["l4"] - g["l4"]).max() <= 2e-6
+
+
+def test_c_oracle_matches_golden_and_numpy(golden):
+    g, w, x = golden
+    outs, inter = c_oracle.forward(w, x, keep_intermediates=True)
+    for got, key in zip(outs, ("gt21", "genotype", "len1", "len2")):
+        assert got.dtype == np.float32
+        assert np.abs(got - g[key]).max() <= 2e-6
+        assert np.abs(got.sum(axis=1) - 1).max() < 1e-5
+    # C intermediates are batch-major [n,33,256]
+    assert np.abs(inter["a1"][:4].transpose(1, 0, 2) - g["a1_first4"]).max() <= 2e-6
+    assert np.abs(inter["a2"][:4].transpose(1, 0, 2) - g["a2_first4"]).max() <= 2e-6
+    assert np.abs(inter["l3"][:4].reshape(4, 30, 256) - g["l3_first4"]).max() <= 4e-6
+    assert np.abs(inter["l4"] - g["l4"]).max() <= 4e-6
+
+
+def test_torch_and_float64_agree(golden):
+    import torch_ref
+    g, w, x = golden
+    outs_t, _ = torch_ref.forward(w, x)
+    outs64 = model_np.forward(w, x, dtype=np.float64)
+    for key, a, b in zip(("gt21", "genotype", "len1", "len2"), outs_t, outs64):
+        assert np.abs(a - g[key]).max() <= 2e-6
+        assert np.abs(b - g[key]).max() <= 2e-6
+
+
+def test_c_oracle_thread_count_does_not_change_results():
+    w = weights.synthetic_weights(seed=3)
+    x, _ = synth.synthetic_input(37, "pacbio_ccs", seed=5)   # ragged last block (37 = 4*8 + 5)
+    a = c_oracle.forward(w, x, threads=1)
+    b = c_oracle.forward(w, x, threads=3)
+    for p, q in zip(a, b):
+        assert np.array_equal(p, q)
+
+
+def test_empty_and_single_candidate():
+    w = weights.synthetic_weights(seed=3)
+    x, _ = synth.synthetic_input(1, "ont", seed=1)
+    outs = c_oracle.forward(w, x)
+    assert [o.shape for o in outs] == [(1, 21), (1, 3), (1, 33), (1, 33)]
+    ref = model_np.forward(w, x)
+    for p, q in zip(outs, ref):
+        assert np.abs(p - q).max() <= 2e-6
+    empty = c_oracle.forward(w, np.zeros((0, 33, 8, 4), np.float32))
+    assert [o.shape for o in empty] == [(0, 21), (0, 3), (0, 33), (0, 33)]
+
+
+def test_candidates_are_independent():
+    """Each position is classified independently (docs/POST_PROCESSING.md:17): batch composition
+    must not change a candidate's result -- this is what makes the path shard across GPUs."""
+    w = weights.synthetic_weights(seed=8)
+    x, _ = synth.synthetic_input(24, "ont", seed=2)
+    full = c_oracle.forward(w, x)
+    part = c_oracle.forward(w, x[5:14])
+    for p, q in zip(full, part):
+        assert np.array_equal(p[5:14], q)
+
+
+def test_gate_order_and_backward_direction():
+    """Structural checks of the LSTM restatement (clair/model.py:299-312):
+    (1) the backward cell equals the forward cell run on the time-reversed input, reversed back;
+    (2) column blocks are (i, c~, f, o): with only the c~ block driven the cell state moves, with
+        only the f block driven from a zero state nothing moves."""
+    rng = np.random.default_rng(0)
+    inp = rng.standard_normal((33, 3, 32)).astype(np.float32)
+    k = (rng.standard_normal((160, 512)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    fw_on_reversed = model_np.lstm_direction(inp[::-1].copy(), k, b, False)[::-1]
+    bw = model_np.lstm_direction(inp, k, b, True)
+    assert np.array_equal(fw_on_reversed, bw)
+    only_f = np.zeros_like(k)
+    only_f[:, 256:384] = k[:, 256:384]
+    assert np.abs(model_np.lstm_direction(inp, only_f, np.zeros(512, np.float32), False)).max() == 0.0
+    only_g = np.zeros_like(k)
+    only_g[:, 128:256] = k[:, 128:256]
+    assert np.abs(model_np.lstm_direction(inp, only_g, np.zeros(512, np.float32), False)).max() > 0.0
+
+
+def test_l3_flat_layout_is_u_times_256_plus_c():
+    """clair/model.py:474-478: L3 [n,30,256] flattened row-major -> index u*256 + c.  With one-hot
+    L4 weights the L4 pre-activation picks exactly that L3 element."""
+    w = weights.synthetic_weights(seed=11)
+    x, _ = synth.synthetic_input(2, "ont", seed=4)
+    _, inter = model_np.forward(w, x, keep_intermediates=True)
+    u, c = 7, 133
+    w2 = dict(w)
+    k4 = np.zeros_like(w["l4_kernel"])
+    k4[u * 256 + c, 5] = 1.0
+    w2["l4_kernel"] = k4
+    _, inter2 = model_np.forward(w2, x, keep_intermediates=True)
+    assert np.allclose(inter2["l4"][:, 5], model_np.selu(inter["l3"][:, u, c]), atol=1e-7)
