@@ -1,0 +1,78 @@
+"""Tensor ingest: text records -> float32 batches [n,33,8,4] for Clair.predict.
+
+Counterpart of /root/reference/clair/utils.py:55-109 (``batches_from``,
+``tensor_generator_from``).  Record format (dataPrepScripts/CreateTensor.py:60-65):
+
+    ctg pos refseq33 v0 v1 ... v1055        (whitespace separated, %d)
+
+Behaviour kept identical to the reference (pinned by tests/golden/ingest_* minted from it):
+  * source is ``gzip -fdc <file>`` or stdin when the path is "PIPE"               utils.py:72-77
+  * the last 1056 columns become float32; the columns before must be exactly 3   utils.py:81-88
+  * rows whose centre base refseq[16] is not an IUPAC code are dropped           utils.py:90-91
+  * channels 1..3 get channel 0 subtracted                                       utils.py:96-98
+  * "Processed %d tensors" goes to stderr once per chunk, including the final
+    (possibly empty) chunk; empty chunks are not yielded                         utils.py:100-104
+  * a partial last batch is yielded as X[:n]                                     utils.py:105
+"""
+import shlex
+import sys
+from subprocess import PIPE, Popen
+
+import numpy as np
+
+from clair_amd import param
+from clair_amd.task import IUPAC_TO_NUM
+
+N_POS = param.no_of_positions
+N_ROW = param.matrixRow
+N_CH = param.matrixNum
+N_VALUES = param.input_tensor_size
+CENTER = param.flankingBaseNum
+
+
+def setup_environment():
+    """Reference: clair/utils.py:39-44 (TF log level, blosc threads).  Nothing to set up here."""
+    return None
+
+
+def _open_source(tensor_file_path):
+    if tensor_file_path == "PIPE":
+        return None, sys.stdin
+    proc = Popen(shlex.split("gzip -fdc %s" % tensor_file_path), stdout=PIPE,
+                 bufsize=8388608, universal_newlines=True)
+    return proc, proc.stdout
+
+
+def tensor_generator_from(tensor_file_path, batch_size):
+    """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size."""
+    proc, lines = _open_source(tensor_file_path)
+    processed = 0
+    exhausted = False
+    while not exhausted:
+        flat = np.empty((batch_size, N_VALUES), dtype=np.float32)
+        infos = []
+        taken = 0
+        while taken < batch_size:
+            row = lines.readline()
+            if not row:
+                exhausted = True
+                break
+            taken += 1
+            cols = row.split()
+            head = cols[:-N_VALUES]
+            values = np.array(cols[-N_VALUES:], dtype=np.float32)
+            _, _, seq = head                      # exactly three leading columns, as the reference requires
+            if seq[CENTER] not in IUPAC_TO_NUM:
+                continue
+            flat[len(infos)] = values
+            infos.append(head)
+        n = len(infos)
+        X = flat.reshape(batch_size, N_POS, N_ROW, N_CH)
+        X[:n, :, :, 1:] -= X[:n, :, :, 0:1]
+        processed += n
+        print("Processed %d tensors" % processed, file=sys.stderr)
+        if n > 0:
+            yield X[:n], infos
+    if proc is not None:
+        lines.close()
+        proc.wait()

@@ -1,0 +1,187 @@
+"""Ingest / decode / VCF writer / driver against goldens minted from the REAL reference
+(tools/make_ref_goldens.py imports /root/reference/clair/{utils,call_var}.py in the build
+container).  Byte-for-byte: every row string must be identical."""
+import gzip
+import io
+import json
+import os
+from contextlib import redirect_stderr
+
+import numpy as np
+import pytest
+
+from clair_amd import call_var as cvar
+from clair_amd import task, utils
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONFIGS = {
+    "default": (False, False, False, False, False, None),
+    "showref_qual": (True, False, False, False, False, 100),
+    "haploid_precision": (False, False, True, False, False, None),
+    "haploid_sensitive": (True, False, False, True, False, 50),
+    "debug": (False, True, False, False, False, None),
+    "ensemble": (False, False, False, False, True, None),
+}
+
+
+@pytest.fixture(scope="module")
+def decode_cases():
+    with np.load(os.path.join(GOLD, "decode_cases.npz")) as z:
+        X = z["x"].astype(np.float32)
+        P = z["probs"]
+        infos = json.loads(str(z["infos"]))
+        tags = json.loads(str(z["tags"]))
+    with gzip.open(os.path.join(GOLD, "decode_rows.json.gz"), "rt") as f:
+        rows = json.load(f)
+    return X, P, infos, tags, rows
+
+
+def _split(P):
+    return [P[:, 0:21], P[:, 21:24], P[:, 24:57], P[:, 57:90]]
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS) + ["default_pysam_all"])
+def test_decode_rows_byte_identical(decode_cases, name):
+    X, P, infos, tags, rows = decode_cases
+    cfg = cvar.OutputConfig(*CONFIGS[name.replace("_pysam_all", "")])
+    dec = cvar.VariantDecoder(cfg, always_use_bam=name.endswith("pysam_all"), arith="numpy2")
+    want = [ln for per in rows[name] for ln in per]
+    got = dec.decode_batch(X, infos, _split(P))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+    # one candidate at a time gives the same rows (no cross-candidate state)
+    for i in range(0, len(infos), 37):
+        assert dec.decode_batch(X[i:i + 1], infos[i:i + 1], _split(P[i:i + 1])) == rows[name][i]
+
+
+def test_every_decode_branch_is_covered(decode_cases):
+    X, P, infos, tags, rows = decode_cases
+    fams = cvar.OutcomeFamilies(*_split(P), ref_class=np.zeros(len(infos), dtype=np.int64))
+    first = fams.flags.argmax(axis=1)
+    assert set(range(cvar.N_FAMILIES)) <= set(first.tolist())
+    gts = {ln.split("\t")[-1].split(":")[0] for per in rows["showref_qual"] for ln in per}
+    assert gts == {"0/0", "1/1", "0/1", "1/2"}
+    sizes = [f.shape[1] for f in fams.fam]
+    assert sizes == [1, 4, 6, 16, 64, 256, 16, 64, 240, 512] and sum(sizes) == 1179
+
+
+def test_legacy_arithmetic_differs_only_in_qual_and_af(decode_cases):
+    X, P, infos, tags, rows = decode_cases
+    cfg = cvar.OutputConfig(*CONFIGS["showref_qual"])
+    a = cvar.VariantDecoder(cfg, arith="numpy2").decode_batch(X, infos, _split(P))
+    b = cvar.VariantDecoder(cfg, arith="legacy").decode_batch(X, infos, _split(P))
+    assert len(a) == len(b)
+    ndiff = 0
+    for ra, rb in zip(a, b):
+        ca, cb = ra.split("\t"), rb.split("\t")
+        assert ca[:5] == cb[:5]                                   # CHROM POS ID REF ALT
+        assert ca[-1].split(":")[0] == cb[-1].split(":")[0]       # GT
+        assert ca[-1].split(":")[2] == cb[-1].split(":")[2]       # DP
+        assert abs(int(ca[5]) - int(cb[5])) <= 1                  # QUAL: float32 vs float64 log argument
+        assert abs(float(ca[-1].split(":")[3]) - float(cb[-1].split(":")[3])) <= 1.0001e-4
+        ndiff += ra != rb
+    assert ndiff < len(a) // 10
+
+
+def test_legacy_quality_handles_certain_calls():
+    g = np.zeros(21, np.float32)
+    g[task.GT21_INDEX["AA"]] = 1.0
+    z = np.array([1, 0, 0], np.float32)
+    assert cvar.quality_score("A", "A", "0/0", g, z, "legacy") == 9096930 or cvar.quality_score("A", "A", "0/0", g, z, "legacy") > 9000000
+    with pytest.raises((ValueError, ZeroDivisionError)):
+        cvar.quality_score("A", "A", "0/0", g, z, "numpy2")      # the reference under NumPy 2 raises too
+
+
+@pytest.mark.parametrize("tag", list("abcde"))
+def test_ingest_matches_reference(tag):
+    with np.load(os.path.join(GOLD, "ingest_cases.npz")) as z:
+        gold = {k: z[k] for k in z.files}
+    batch = int(gold["%s_batch" % tag])
+    err = io.StringIO()
+    got = []
+    with redirect_stderr(err):
+        for X, infos in utils.tensor_generator_from(os.path.join(GOLD, "ingest_%s.txt.gz" % tag), batch):
+            got.append((np.array(X, copy=True), [list(i) for i in infos]))
+    assert len(got) == int(gold["%s_nbatches" % tag])
+    for k, (X, infos) in enumerate(got):
+        want = gold["%s_X%d" % (tag, k)]
+        assert X.dtype == np.float32 and X.shape == want.shape
+        assert X.tobytes() == want.tobytes()
+        assert infos == json.loads(str(gold["%s_info%d" % (tag, k)]))
+    assert err.getvalue() == str(gold["%s_stderr" % tag])
+
+
+@pytest.mark.parametrize("tag,sample", [("nofai", "HG002"), ("fai", "HG002")])
+def test_header_matches_reference(tmp_path, tag, sample):
+    ref = None
+    if tag == "fai":
+        ref = str(tmp_path / "ref.fa")
+        open(ref + ".fai", "w").write(open(os.path.join(GOLD, "header_fai.fai")).read())
+    out = str(tmp_path / "h.vcf")
+    w = cvar.VcfWriter(out, sample, ref, False)
+    w.write_header()
+    w.close()
+    assert open(out).read() == open(os.path.join(GOLD, "header_%s.vcf" % tag)).read()
+
+
+class _OracleModel(object):
+    """Same stand-in the golden generator used inside the reference driver."""
+
+    def __init__(self, w):
+        self.w = w
+        self.prediction = None
+
+    def predict(self, batchX):
+        from oracle import model_np
+        self.prediction = model_np.forward(self.w, batchX)
+        return self.prediction
+
+
+@pytest.mark.parametrize("tag,cfgname", [("default", "default"), ("showref", "showref_qual")])
+def test_driver_end_to_end_matches_reference_driver(tmp_path, tag, cfgname):
+    """tensor file -> (oracle probabilities) -> VCF must equal what the reference's own
+    call_variants wrote with the same probabilities, byte for byte."""
+    from clair_amd import weights
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    out = str(tmp_path / "o.vcf")
+    args = cvar.build_parser().parse_args(["--tensor_fn", os.path.join(GOLD, "e2e_230.txt.gz"), "--call_fn", out])
+    dec = cvar.VariantDecoder(cvar.OutputConfig(*CONFIGS[cfgname]), arith="numpy2")
+    wr = cvar.VcfWriter(out, "SAMPLE", None, False)
+    with redirect_stderr(io.StringIO()):
+        cvar.call_variants(args, _OracleModel(w), dec, wr, batch_size=100)
+    wr.close()
+    assert open(out).read() == open(os.path.join(GOLD, "e2e_230_%s.vcf" % tag)).read()
+
+
+def test_ensemble_roundtrip_through_input_probabilities(decode_cases, tmp_path):
+    """--output_for_ensemble lines fed back through --input_probabilities give the rows the decode
+    produces from the %.6f-rounded probabilities (call_var.py:950-1000, 1276-1309)."""
+    X, P, infos, tags, rows = decode_cases
+    lines = [ln for per in rows["ensemble"][:200] for ln in per]
+    out = str(tmp_path / "o.vcf")
+    cfg = cvar.OutputConfig(*CONFIGS["showref_qual"])
+    dec = cvar.VariantDecoder(cfg, arith="legacy")
+    wr = cvar.VcfWriter(out, "SAMPLE", None, False)
+    cvar.call_variants_with_probabilities_input(None, dec, wr, stream=io.StringIO("\n".join(lines) + "\n"))
+    wr.close()
+    body = [ln for ln in open(out).read().splitlines() if not ln.startswith("#")]
+    keep = [i for i in range(200) if rows["ensemble"][i]]
+    Pr = np.array([[float(v) for v in rows["ensemble"][i][0].split("\t")[3 + 1056:]] for i in keep], dtype=np.float32)
+    want = dec.decode_batch(X[keep], [infos[i] for i in keep], _split(Pr))
+    assert body == want
+
+
+def test_argparse_surface():
+    """Every flag of the reference CLI (call_var.py:1370-1429) is accepted with the same defaults."""
+    p = cvar.build_parser()
+    a = p.parse_args([])
+    assert (a.tensor_fn, a.chkpnt_fn, a.call_fn, a.bam_fn, a.qual, a.sampleName) == ("PIPE", None, None, "bam.bam", None, "SAMPLE")
+    assert (a.showRef, a.debug, a.ref_fn, a.threads, a.activation_only, a.max_plot, a.log_path) == (False, False, None, None, False, 10, None)
+    assert (a.parallel_level, a.fast_plotting, a.workers, a.pysam_for_all_indel_bases) == (2, False, 8, False)
+    assert (a.haploid_precision, a.haploid_sensitive, a.input_probabilities, a.output_for_ensemble) == (False, False, False, False)
+    a = p.parse_args("--tensor_fn t --chkpnt_fn c --call_fn o --bam_fn b --qual 7 --sampleName S --showRef --debug "
+                     "--ref_fn r --threads 3 --activation_only --max_plot 2 --log_path l -p 0 -w 2 --fast_plotting "
+                     "--pysam_for_all_indel_bases --haploid_precision --haploid_sensitive --input_probabilities "
+                     "--output_for_ensemble".split())
+    assert a.qual == 7 and a.threads == 3 and a.parallel_level == 0 and a.workers == 2

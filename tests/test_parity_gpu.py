@@ -82,3 +82,51 @@ def test_run_to_run_deterministic(engine):
     b = engine.predict(x)
     for p, q in zip(a, b):
         assert np.array_equal(p, q)
+
+
+def _vcf_fields(text):
+    rows = [ln.split("\t") for ln in text.splitlines() if not ln.startswith("#")]
+    return [(r[0], r[1], r[3], r[4], r[9].split(":")[0], r[9].split(":")[2]) for r in rows], rows
+
+
+def test_cli_end_to_end_gt_identical_to_reference_driver(tmp_path):
+    """python -m clair_amd.call_var on the MI355X vs the VCF the reference's own call_variants wrote
+    from oracle probabilities (tests/golden/e2e_230_*.vcf): CHROM/POS/REF/ALT/GT/DP identical for
+    100 % of rows ("bit-identical VCF GT calls"); QUAL/AF text may differ by float noise and is counted."""
+    import os
+    import subprocess
+    import sys
+    from clair_amd import weights
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    ck = weights.save_weights(str(tmp_path / "model"), w)
+    root = os.path.dirname(gold.rstrip("/").rsplit("/", 1)[0])
+    for tag, extra in (("default", []), ("showref", ["--showRef", "--qual", "100"])):
+        out = str(tmp_path / ("o_%s.vcf" % tag))
+        cmd = [sys.executable, "-m", "clair_amd.call_var", "--chkpnt_fn", ck[:-4], "--tensor_fn",
+               os.path.join(gold, "e2e_230.txt.gz"), "--call_fn", out, "--batch_size", "100", "--arith", "numpy2"] + extra
+        subprocess.check_call(cmd, cwd=root, stderr=subprocess.DEVNULL)
+        got, got_rows = _vcf_fields(open(out).read())
+        want, want_rows = _vcf_fields(open(os.path.join(gold, "e2e_230_%s.vcf" % tag)).read())
+        assert got == want
+        qual_diff = sum(a[5] != b[5] for a, b in zip(got_rows, want_rows))
+        assert qual_diff <= len(want_rows) // 20
+        assert open(out).read().splitlines()[:12] == open(os.path.join(gold, "e2e_230_%s.vcf" % tag)).read().splitlines()[:12]
+
+
+def test_gt_concordance_on_synthetic_set(engine, synth_weights):
+    """Decode of HIP probabilities vs decode of oracle probabilities on 4096 synthetic ONT candidates:
+    every VCF row identical in CHROM/POS/REF/ALT/GT (flip count must be 0)."""
+    from clair_amd import call_var as cvar
+    n = 4096
+    raw, infos = synth.synthetic_candidates(n, "ont", seed=2024)
+    x = synth.to_model_input(raw)
+    got = [np.concatenate([engine.predict(x[i:i + 1024])[k] for i in range(0, n, 1024)]) for k in range(4)]
+    want = _oracle(synth_weights, x)
+    dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
+    rows_g = dec.decode_batch(x, infos, got)
+    rows_w = dec.decode_batch(x, infos, want)
+    key = lambda r: (r.split("\t")[:5], r.split("\t")[-1].split(":")[0])  # noqa: E731
+    assert len(rows_g) == len(rows_w) > 0
+    flips = sum(key(a) != key(b) for a, b in zip(rows_g, rows_w))
+    assert flips == 0
