@@ -64,7 +64,7 @@ struct clair_engine {
     float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
     float *wh1p = nullptr, *wh2p = nullptr;
     float *w3p = nullptr, *b3p = nullptr, *w4p = nullptr, *b4 = nullptr;
-    float *w5p = nullptr, *b5p = nullptr, *whp = nullptr, *bhp = nullptr;
+    float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
     double ms_sum[CLAIR_K_COUNT] = {0};
     int64_t launches[CLAIR_K_COUNT] = {0};
 };
@@ -175,7 +175,7 @@ int drain_timers(clair_engine *e) {
 // Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
 // zero or any finite value) writing packed outputs to out_dev ([n][90]).
 int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
-    const int n_pad = (n + 15) & ~15;
+    const int n_pad = (n + 31) & ~31;   // two 16-candidate tiles per recurrent workgroup
     const int ntiles = n_pad / 16;
     const int m_rows = T_POS * n_pad;
     s.last_n_pad = n_pad;
@@ -183,22 +183,22 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         KernelTimer kt(e, s, CLAIR_K_PROJ1);
         GemmArgs a{x_dev, e->wx1p, e->bx1, s.zx, n_pad, ntiles, m_rows, F_IN / 16};
         dim3 grid((m_rows + 127) / 128, 8, 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ1, 4>), grid, dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ1, 4, 4>), grid, dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles};
+        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles, nullptr};
         hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
         GemmArgs a{s.a1, e->wx2p, e->bx2, s.zx, n_pad, ntiles, m_rows, (2 * HID) / 16};
         dim3 grid((m_rows + 127) / 128, 8, 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ2, 4>), grid, dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ2, 4, 4>), grid, dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles};
+        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles, nullptr};
         hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {
@@ -209,13 +209,13 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     {
         KernelTimer kt(e, s, CLAIR_K_L4);
         GemmArgs a{s.l3, e->w4p, nullptr, s.l4part, n_pad, ntiles, n_pad, (L3_OUT / 16) / L4_SPLITS};
-        dim3 grid((n_pad + 127) / 128, 1, L4_SPLITS);
-        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_L4, 6>), grid, dim3(256), 0, s.stream, a);
+        dim3 grid((n_pad + 63) / 64, 1, L4_SPLITS);
+        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_L4, 2, 6>), grid, dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
-        TailArgs a{s.l4part, e->b4, e->w5p, e->b5p, e->whp, e->bhp, out_dev, n_pad, n};
-        hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_CAND), dim3(256), 0, s.stream, a);
+        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n};
+        hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
     return 0;
@@ -257,7 +257,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     clair_engine *e = new clair_engine();
     e->device = device;
     e->max_batch = max_batch;
-    e->max_pad = (max_batch + 15) & ~15;
+    e->max_pad = (max_batch + 31) & ~31;
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
     for (auto &s : e->slots) {
@@ -285,7 +285,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->wh1p, e->wh2p, e->w3p, e->b3p, e->w4p, e->b4, e->w5p, e->b5p, e->whp, e->bhp};
+    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->wh1p, e->wh2p, e->w3p, e->b3p, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf};
     for (float *p : w) (void)hipFree(p);
     delete e;
 }
@@ -306,7 +306,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->wh1p, &e->wh2p, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5p, &e->b5p, &e->whp, &e->bhp};
+    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->wh1p, &e->wh2p, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
     auto cat = [](const std::vector<float> &a, const std::vector<float> &b) { std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end()); return r; };
@@ -331,22 +331,28 @@ int clair_finalize_weights(clair_engine_t *e) {
             for (int col = 0; col < L4_UNITS; ++col) w4[((size_t)(k / 16) * L4_UNITS + col) * 16 + (k % 16)] = T[10][(size_t)k * L4_UNITS + col];
         if (upload(e, &e->w4p, w4) || upload(e, &e->b4, T[11])) return 1;
     }
-    {   // W5p[k][k5*96+j]
-        std::vector<float> w5((size_t)L4_UNITS * 4 * L5_UNITS);
-        for (int k5 = 0; k5 < 4; ++k5)
-            for (int k = 0; k < L4_UNITS; ++k)
-                for (int j = 0; j < L5_UNITS; ++j) w5[(size_t)k * (4 * L5_UNITS) + k5 * L5_UNITS + j] = T[12][((size_t)k5 * L4_UNITS + k) * L5_UNITS + j];
-        if (upload(e, &e->w5p, w5) || upload(e, &e->b5p, T[13])) return 1;
-    }
-    {   // heads: Whp[k][o], o = packed output column
-        const int sizes[4] = {21, 3, 33, 33}, offs[4] = {0, 21, 24, 57};
-        std::vector<float> wh((size_t)L5_UNITS * OUT_FLOATS), bh(OUT_FLOATS);
-        for (int k5 = 0; k5 < 4; ++k5)
-            for (int j = 0; j < sizes[k5]; ++j) {
-                bh[offs[k5] + j] = T[15 + 2 * k5][j];
-                for (int k = 0; k < L5_UNITS; ++k) wh[(size_t)k * OUT_FLOATS + offs[k5] + j] = T[14 + 2 * k5][(size_t)k * sizes[k5] + j];
-            }
-        if (upload(e, &e->whp, wh) || upload(e, &e->bhp, bh)) return 1;
+    {   // tail B fragments (dense.hip.h: tail_kernel)
+        const int sizes[4] = {21, 3, 33, 33};
+        std::vector<float> w5f((size_t)4 * 12 * 6 * 64 * 4), whf((size_t)4 * 6 * 3 * 64 * 4, 0.0f), bhf(4 * 48, 0.0f);
+        for (int k5 = 0; k5 < 4; ++k5) {
+            for (int k4 = 0; k4 < 12; ++k4)
+                for (int nb = 0; nb < 6; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = (lane >> 4) * 48 + k4 * 4 + j, col = nb * 16 + (lane & 15);
+                            w5f[((((size_t)k5 * 12 + k4) * 6 + nb) * 64 + lane) * 4 + j] = T[12][((size_t)k5 * L4_UNITS + k) * L5_UNITS + col];
+                        }
+            for (int k4 = 0; k4 < 6; ++k4)
+                for (int nb = 0; nb < 3; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = (lane >> 4) * 24 + k4 * 4 + j, col = nb * 16 + (lane & 15);
+                            if (col < sizes[k5])
+                                whf[((((size_t)k5 * 6 + k4) * 3 + nb) * 64 + lane) * 4 + j] = T[14 + 2 * k5][(size_t)k * sizes[k5] + col];
+                        }
+            for (int j = 0; j < sizes[k5]; ++j) bhf[k5 * 48 + j] = T[15 + 2 * k5][j];
+        }
+        if (upload(e, &e->w5f, w5f) || upload(e, &e->b5, T[13]) || upload(e, &e->whf, whf) || upload(e, &e->bhf, bhf)) return 1;
     }
     e->weights_ready = true;
     return 0;
@@ -359,7 +365,7 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
     HIP_TRY(e, hipSetDevice(e->device));
     Slot &s = e->slots[slot];
     if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
-    const int n_pad = (n + 15) & ~15;
+    const int n_pad = (n + 31) & ~31;
     HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
     if (n_pad > n)
         HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));

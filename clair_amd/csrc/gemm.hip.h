@@ -5,8 +5,8 @@
 //   L4   :  part[s] = l3[n,7680(slice s)] . W4[7680(slice s),192]          (clair/model.py:482-488)
 //
 // The contraction runs on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate, bit-exact fmaf chain),
-// so results carry plain fp32 round-off.  Tile: 128 rows x (2*NI*16) columns per 256-thread
-// workgroup, 2x2 waves, each wave 4 x NI blocks of 16x16; K is consumed in slabs of 16 staged
+// so results carry plain fp32 round-off.  Tile: (2*MI*16) rows x (2*NI*16) columns per 256-thread
+// workgroup, 2x2 waves, each wave MI x NI blocks of 16x16; K is consumed in slabs of 16 staged
 // through LDS (rows padded to 20 floats so the ds_read_b128 fragment reads spread over banks).
 //
 // B operands are pre-packed on the host as Bp[slab][column][16] so a slab of the workgroup's
@@ -40,12 +40,13 @@ __device__ __forceinline__ size_t zx_block_offset(int rb, int cb, int ntiles) {
     return ((((size_t)(d * T_POS + t) * ntiles + tile) * 4 + w) * 8 + (g * 2 + hh)) * 256;
 }
 
-template <int MODE, int NI>
+template <int MODE, int MI, int NI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    constexpr int NROWS = 2 * MI * 16;
     constexpr int NCOLS = 2 * NI * 16;
     constexpr int NTOT = (MODE == GEMM_L4) ? L4_UNITS : 2 * GATES;
     constexpr int KTOT = (MODE == GEMM_PROJ1) ? F_IN : (MODE == GEMM_PROJ2 ? 2 * HID : L3_OUT);
-    __shared__ __attribute__((aligned(16))) float As[128 * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) float As[NROWS * LDS_ROW];
     __shared__ __attribute__((aligned(16))) float Bs[NCOLS * LDS_ROW];
 
     const int tid = threadIdx.x;
@@ -54,14 +55,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lq = lane >> 4;
 
-    const int row0 = blockIdx.x * 128;
+    const int row0 = blockIdx.x * NROWS;
     const int col0 = blockIdx.y * NCOLS;
     const int slab0 = blockIdx.z * p.slabs_per_wg;
 
-    // global source of this thread's two A float4s (rows tid>>2 and 64+(tid>>2), 16-B column tid&3)
-    const float *arow[2];
+    // global source of this thread's A float4s (rows h*64 + (tid>>2), 16-B column tid&3)
+    constexpr int A_PER_THREAD = NROWS / 64;
+    const float *arow[A_PER_THREAD];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < A_PER_THREAD; ++h) {
         int r = row0 + h * 64 + (tid >> 2);
         r = r < p.m_rows ? r : p.m_rows - 1;  // clamp: rows beyond M are computed but never stored
         if (MODE == GEMM_PROJ1) {
@@ -76,16 +78,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     constexpr int B_PER_THREAD = B_F4 / 256;      // 2 (NI=4) or 3 (NI=6)
     const f32x4 *bsrc = (const f32x4 *)(p.Bp + ((size_t)slab0 * NTOT + col0) * 16) + tid;
 
-    f32x4 acc[4][NI];
+    f32x4 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[2], rb[B_PER_THREAD];
+    f32x4 ra[A_PER_THREAD], rb[B_PER_THREAD];
     auto gload = [&](int s) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) ra[h] = *(const f32x4 *)(arow[h] + (size_t)(slab0 + s) * 16);
+        for (int h = 0; h < A_PER_THREAD; ++h) ra[h] = *(const f32x4 *)(arow[h] + (size_t)(slab0 + s) * 16);
 #pragma unroll
         for (int h = 0; h < B_PER_THREAD; ++h) rb[h] = bsrc[(size_t)s * NTOT * 4 + h * 256];
     };
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     for (int s = 0; s < p.slabs_per_wg; ++s) {
         __syncthreads();  // previous slab fully consumed
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < A_PER_THREAD; ++h)
             *(f32x4 *)&As[(h * 64 + (tid >> 2)) * LDS_ROW + (tid & 3) * 4] = ra[h];
 #pragma unroll
         for (int h = 0; h < B_PER_THREAD; ++h) {
@@ -102,23 +104,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
         __syncthreads();
         if (s + 1 < p.slabs_per_wg) gload(s + 1);  // in flight while the MFMAs run
-        f32x4 a[4], b[NI];
+        f32x4 a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = *(const f32x4 *)&As[(wm * 64 + mi * 16 + li) * LDS_ROW + lq * 4];
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4 *)&As[(wm * MI * 16 + mi * 16 + li) * LDS_ROW + lq * 4];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4 *)&Bs[(wn * NI * 16 + ni * 16 + li) * LDS_ROW + lq * 4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(a[mi][j], b[ni][j], acc[mi][ni]);
     }
 
     // epilogue
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int rblk = (row0 >> 4) + wm * 4 + mi;  // 16-row block index
+    for (int mi = 0; mi < MI; ++mi) {
+        const int rblk = (row0 >> 4) + wm * MI + mi;  // 16-row block index
         if (rblk * 16 >= p.m_rows) continue;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {

@@ -134,7 +134,7 @@ int clair_timing_reset(clair_engine_t *e);
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
  *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
  *    3 = L3 output [n_pad,7680], 4 = L4 pre-activation partial sums reduced [n_pad,192] is not
- *    materialised -- use the outputs.  n_pad = n rounded up to 16. */
+ *    materialised -- use the outputs.  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);
 
 #ifdef __cplusplus
