@@ -94,18 +94,26 @@ int upload(clair_engine *e, float **dst, const std::vector<float> &src) {
     return 0;
 }
 
+// Factor folded into every LSTM gate column (and bias) so the MFMA result is the exp2 argument of the
+// gate's activation (lstm.hip.h): columns are i | c~ | f | o, 128 each.
+inline float gate_scale(int col512) {
+    const float L2E = 1.44269504088896340736f;
+    return ((col512 >> 7) == 1) ? 2.0f * L2E : -L2E;
+}
+
 // x-part of the two directions' LSTM kernels -> Bp[slab][1024][16]  (gemm.hip.h)
 std::vector<float> pack_wx(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
     std::vector<float> out((size_t)D * 1024);
     for (int k = 0; k < D; ++k)
         for (int col = 0; col < 1024; ++col) {
             const std::vector<float> &src = col < 512 ? fw : bw;
-            out[((size_t)(k / 16) * 1024 + col) * 16 + (k % 16)] = src[(size_t)k * 512 + (col & 511)];
+            out[((size_t)(k / 16) * 1024 + col) * 16 + (k % 16)] = src[(size_t)k * 512 + (col & 511)] * gate_scale(col & 511);
         }
     return out;
 }
 
-// h-part -> [dir][wave][nb][k4][lane][j] = W[D + lq*32 + k4*4 + j][g*128 + 32w + 16hh + li]  (lstm.hip.h)
+// h-part -> [dir][wave][nb][k4][lane][j] = scale * W[D + lq*32 + k4*4 + j][g*128 + 32w + 16hh + li], nb = g*2 + hh
+// (lstm.hip.h: the register image of wave w)
 std::vector<float> pack_wh(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
     std::vector<float> out((size_t)2 * 4 * 8 * 8 * 64 * 4);
     size_t o = 0;
@@ -116,10 +124,9 @@ std::vector<float> pack_wh(const std::vector<float> &fw, const std::vector<float
                 for (int k4 = 0; k4 < 8; ++k4)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 4; ++j) {
-                            int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
-                            int k = lq * 32 + k4 * 4 + j;
-                            int col = g * 128 + 32 * w + 16 * hh + li;
-                            out[o++] = src[(size_t)(D + k) * 512 + col];
+                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
+                            const int col = g * 128 + 32 * w + 16 * hh + li;
+                            out[o++] = src[(size_t)(D + lq * 32 + k4 * 4 + j) * 512 + col] * gate_scale(col);
                         }
     }
     return out;
@@ -175,7 +182,7 @@ int drain_timers(clair_engine *e) {
 // Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
 // zero or any finite value) writing packed outputs to out_dev ([n][90]).
 int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
-    const int n_pad = (n + 31) & ~31;   // two 16-candidate tiles per recurrent workgroup
+    const int n_pad = (n + 31) & ~31;
     const int ntiles = n_pad / 16;
     const int m_rows = T_POS * n_pad;
     s.last_n_pad = n_pad;
@@ -187,8 +194,8 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles, nullptr};
-        hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles};
+        hipLaunchKernelGGL(lstm_rec_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
@@ -198,8 +205,8 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles, nullptr};
-        hipLaunchKernelGGL((lstm_rec_kernel<1>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles};
+        hipLaunchKernelGGL(lstm_rec_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_L3);
@@ -285,7 +292,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->wh1p, e->wh2p, e->w3p, e->b3p, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf};
+    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3p, e->b3p, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p};
     for (float *p : w) (void)hipFree(p);
     delete e;
 }
@@ -306,10 +313,13 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->wh1p, &e->wh2p, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
+    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
-    auto cat = [](const std::vector<float> &a, const std::vector<float> &b) { std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end()); return r; };
+    auto cat = [](const std::vector<float> &a, const std::vector<float> &b) {   // both directions' biases, gate-scaled
+        std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end());
+        for (size_t i = 0; i < r.size(); ++i) r[i] *= gate_scale((int)(i & 511));
+        return r; };
     if (upload(e, &e->wx1p, pack_wx(T[0], T[2], F_IN))) return 1;
     if (upload(e, &e->bx1, cat(T[1], T[3]))) return 1;
     if (upload(e, &e->wx2p, pack_wx(T[4], T[6], 2 * HID))) return 1;
