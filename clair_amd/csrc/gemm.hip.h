@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     constexpr int NCOLS = 2 * NI * 16;
     constexpr int NTOT = (MODE == GEMM_L4) ? L4_UNITS : 2 * GATES;
     constexpr int KTOT = (MODE == GEMM_PROJ1) ? F_IN : (MODE == GEMM_PROJ2 ? 2 * HID : L3_OUT);
-    __shared__ __attribute__((aligned(16))) float As[NROWS * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[NCOLS * LDS_ROW];
+    // double-buffered slab staging: one barrier per slab
+    __shared__ __attribute__((aligned(16))) float As[2][NROWS * LDS_ROW];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NCOLS * LDS_ROW];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,30 +92,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
         for (int h = 0; h < B_PER_THREAD; ++h) rb[h] = bsrc[(size_t)s * NTOT * 4 + h * 256];
     };
-    gload(0);
-    for (int s = 0; s < p.slabs_per_wg; ++s) {
-        __syncthreads();  // previous slab fully consumed
+    auto lstore = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < A_PER_THREAD; ++h)
-            *(f32x4 *)&As[(h * 64 + (tid >> 2)) * LDS_ROW + (tid & 3) * 4] = ra[h];
+            *(f32x4 *)&As[buf][(h * 64 + (tid >> 2)) * LDS_ROW + (tid & 3) * 4] = ra[h];
 #pragma unroll
         for (int h = 0; h < B_PER_THREAD; ++h) {
-            int f = h * 256 + tid;  // float4 index inside the slab chunk: column f>>2, quarter f&3
-            *(f32x4 *)&Bs[(f >> 2) * LDS_ROW + (f & 3) * 4] = rb[h];
+            const int f = h * 256 + tid;  // float4 index inside the slab chunk: column f>>2, quarter f&3
+            *(f32x4 *)&Bs[buf][(f >> 2) * LDS_ROW + (f & 3) * 4] = rb[h];
         }
-        __syncthreads();
-        if (s + 1 < p.slabs_per_wg) gload(s + 1);  // in flight while the MFMAs run
+    };
+    const int S = p.slabs_per_wg;
+    gload(0);
+    lstore(0);
+    if (S > 1) gload(1);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
         f32x4 a[MI], b[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4 *)&As[(wm * MI * 16 + mi * 16 + li) * LDS_ROW + lq * 4];
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f32x4 *)&As[buf][(wm * MI * 16 + mi * 16 + li) * LDS_ROW + lq * 4];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4 *)&Bs[(wn * NI * 16 + ni * 16 + li) * LDS_ROW + lq * 4];
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f32x4 *)&Bs[buf][(wn * NI * 16 + ni * 16 + li) * LDS_ROW + lq * 4];
+        // slab s+1 (in registers since the previous iteration) -> the other buffer, whose readers all
+        // passed the barrier that ended iteration s-1; then fetch slab s+2 under this slab's MFMAs
+        if (s + 1 < S) lstore(buf ^ 1);
+        if (s + 2 < S) gload(s + 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma16(a[mi][j], b[ni][j], acc[mi][ni]);
+        __syncthreads();
     }
 
     // epilogue
