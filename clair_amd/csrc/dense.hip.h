@@ -4,47 +4,128 @@
 
 namespace clair {
 
-// ---- L3: for every LSTM2 feature c, dense(33 -> 30) over the position axis + selu -------------
-// clair/model.py:225-244 (slice_dense_layer), :464-479: l3[n][u*256 + c] =
-//   selu( sum_t a2[t][n][c] * W3[c][t][u] + b3[c][u] ).
-// One thread per feature c, L3_CAND candidates per workgroup so every weight load (coalesced over
-// c from the host-packed W3p[t][u][c]) feeds L3_CAND FMAs.
-constexpr int L3_CAND = 4;
+// ---- L3 + L4 fused: slice dense (256 x dense 33->30, selu) feeding the split-K 7680->192 product --------
+// clair/model.py:225-244 (slice_dense_layer), :464-479 (L3 + flatten, flat index u*256 + c), :482-488 (L4).
+//   l3[n][u*256 + c] = selu( sum_t a2[t][n][c] * W3[c][t][u] + b3[c][u] )
+//   part[cg][n][j]   = sum_{u<30, c in group cg} l3[n][u*256 + c] * W4[u*256 + c][j]        (cg = 16 channels)
+// A workgroup owns 32 candidates x one channel group, i.e. the K-slice {u*256 + c}: for a fixed u its 16
+// channels are 16 CONSECUTIVE rows of W4, exactly one slab of the packed [K/16][192][16] operand.  So L3 is
+// computed on the MFMA ([32 cand x 36 t] x [36 t x 32 u] per channel, operands straight from global) into
+// an LDS tile laid out as L4's A operand, and L4 runs out of that tile with its B fragments read directly
+// from L2: the 30 KB/candidate l3 tensor never exists in HBM and a kernel launch disappears.
+constexpr int L34_CAND = 32;
+constexpr int L34_ROW = 30 * 16 + 4;   // 484 floats per candidate: 16-B aligned, conflict-free ds_read_b128 over candidates
 
-struct L3Args {
-    const float *a2;   // [33][n_pad][256]
-    const float *w3p;  // [33][30][256]
-    const float *b3p;  // [30][256]
-    float *l3;         // [n_pad][7680]
+struct L3L4Args {
+    const float *a2;    // [33][n_pad][256]
+    const float *w3f;   // [256][64][20]  B fragments of L3: slot kk*2 + nbk = W3[c][t = lq*9 + kk][u = nbk*16 + li] (0 beyond 33 / 30)
+    const float *b3;    // [256][30]
+    const float *w4p;   // [480][192][16] packed W4 (gemm.hip.h layout), slab = u*16 + cg
+    float *part;        // [16][n_pad][192]
     int n_pad;
 };
 
-__global__ __launch_bounds__(256) void l3_kernel(L3Args p) {
-    const int c = threadIdx.x;
-    const int n0 = blockIdx.x * L3_CAND;
-    float acc[L3_CAND][L3_UNITS];
+__global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
+    __shared__ __attribute__((aligned(16))) float l3s[L34_CAND][L34_ROW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * L34_CAND;
+    const int cg = blockIdx.y;                 // channels cg*16 .. cg*16+15; this wave: 4 of them, cg*16 + 4w ..
+
+    // ---- L3 for this wave's four channels --------------------------------------------------------------
+#ifndef L34_SKIP_L3
+    {
+        // A operands: candidate li (of block mb), positions t = lq*9 + kk, four channels per float4
+        f32x4 av[2][9];
 #pragma unroll
-    for (int u = 0; u < L3_UNITS; ++u) {
-        const float b = p.b3p[u * 256 + c];
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int j = 0; j < L3_CAND; ++j) acc[j][u] = b;
-    }
-    for (int t = 0; t < T_POS; ++t) {
-        float a[L3_CAND];
+            for (int kk = 0; kk < 9; ++kk) {
+                const int t = lq * 9 + kk;
+                av[mb][kk] = t < T_POS ? *(const f32x4 *)(p.a2 + ((size_t)t * p.n_pad + n0 + mb * 16 + li) * 256 + cg * 16 + w * 4)
+                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-        for (int j = 0; j < L3_CAND; ++j) a[j] = p.a2[((size_t)t * p.n_pad + n0 + j) * 256 + c];
-        const float *wt = p.w3p + (size_t)t * L3_UNITS * 256 + c;
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = cg * 16 + w * 4 + cc;
+            f32x4 bf[5];
+            const f32x4 *bp = (const f32x4 *)(p.w3f + ((size_t)c * 64 + lane) * 20);
 #pragma unroll
-        for (int u = 0; u < L3_UNITS; ++u) {
-            const float wv = wt[u * 256];
+            for (int i = 0; i < 5; ++i) bf[i] = bp[i];
+            f32x4 acc[2][2];
 #pragma unroll
-            for (int j = 0; j < L3_CAND; ++j) acc[j][u] = fmaf(a[j], wv, acc[j][u]);
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nbk = 0; nbk < 2; ++nbk) acc[mb][nbk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk)
+#pragma unroll
+                for (int nbk = 0; nbk < 2; ++nbk) {
+                    const float b = bf[(kk * 2 + nbk) >> 2][(kk * 2 + nbk) & 3];
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) acc[mb][nbk] = mfma16(av[mb][kk][cc], b, acc[mb][nbk]);
+                }
+#pragma unroll
+            for (int nbk = 0; nbk < 2; ++nbk) {
+                const int u = nbk * 16 + li;
+                if (u < L3_UNITS) {
+                    const float bias = p.b3[c * L3_UNITS + u];
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            l3s[mb * 16 + lq * 4 + r][u * 16 + w * 4 + cc] = selu_f(acc[mb][nbk][r] + bias);
+                }
+            }
         }
     }
+#endif
+    __syncthreads();
+
+    // ---- L4 over this K-slice: wave w owns output columns 48w .. 48w+47 (3 blocks), both 16-row blocks --------
+    f32x4 acc[2][3];
 #pragma unroll
-    for (int j = 0; j < L3_CAND; ++j)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int u = 0; u < L3_UNITS; ++u) p.l3[(size_t)(n0 + j) * L3_OUT + u * 256 + c] = selu_f(acc[j][u]);
+        for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 *bsrc = (const f32x4 *)(p.w4p + (((size_t)cg) * L4_UNITS + w * 48 + li) * 16) + lq;   // slab u adds u*16*192*16 floats
+    // B fragments stream from L2 with a prefetch distance of PF slabs (a slab of 24 MFMAs is only ~770
+    // cycles, shorter than an L2 round trip); the slab loop is fully unrolled so the ring is static
+    constexpr int PF = 4;
+    f32x4 bq[PF][3];
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) bq[i][nb] = bsrc[(size_t)i * (16 * L4_UNITS * 4) + nb * 64];
+#ifdef L34_SKIP_L4
+    if (p.n_pad < 0)
+#endif
+#pragma unroll
+    for (int u = 0; u < L3_UNITS; ++u) {
+        if (u + PF - 1 < L3_UNITS) {
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) bq[(u + PF - 1) % PF][nb] = bsrc[(size_t)(u + PF - 1) * (16 * L4_UNITS * 4) + nb * 64];
+        }
+        f32x4 a[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *(const f32x4 *)&l3s[mb * 16 + li][u * 16 + lq * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16(a[mb][j], bq[u % PF][nb][j], acc[mb][nb]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            float *dst = p.part + ((size_t)cg * p.n_pad + n0 + mb * 16 + lq * 4) * L4_UNITS + w * 48 + nb * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(size_t)r * L4_UNITS] = acc[mb][nb][r];
+        }
 }
 
 // ---- tail: L4 split-K reduce + selu, L5_1..4 + selu, heads + selu + softmax ---------------------

@@ -37,7 +37,6 @@ struct Slot {
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
     float *a1 = nullptr;      // [33][max_pad][256]
     float *a2 = nullptr;      // [33][max_pad][256]
-    float *l3 = nullptr;      // [max_pad][7680]
     float *l4part = nullptr;  // [16][max_pad][192]
     float *d_out = nullptr;   // [max_pad][90]
     float *h_out = nullptr;   // pinned [max_batch][90]
@@ -62,8 +61,8 @@ struct clair_engine {
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
     float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
-    float *wh1p = nullptr, *wh2p = nullptr;
-    float *w3p = nullptr, *b3p = nullptr, *w4p = nullptr, *b4 = nullptr;
+    float *wh1p = nullptr, *wh2p = nullptr, *wx1f = nullptr;
+    float *w3f = nullptr, *b3 = nullptr, *w4p = nullptr, *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
     double ms_sum[CLAIR_K_COUNT] = {0};
     int64_t launches[CLAIR_K_COUNT] = {0};
@@ -132,12 +131,31 @@ std::vector<float> pack_wh(const std::vector<float> &fw, const std::vector<float
     return out;
 }
 
+// x-part of LSTM1 for the fused kernel -> [dir][wave][nb][k4(2)][lane][j] = scale * W[lq*8 + k4*4 + j][col]
+std::vector<float> pack_wx_frag(const std::vector<float> &fw, const std::vector<float> &bw) {
+    std::vector<float> out((size_t)2 * 4 * 8 * 2 * 64 * 4);
+    size_t o = 0;
+    for (int d = 0; d < 2; ++d) {
+        const std::vector<float> &src = d ? bw : fw;
+        for (int w = 0; w < 4; ++w)
+            for (int nb = 0; nb < 8; ++nb)
+                for (int k4 = 0; k4 < 2; ++k4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j) {
+                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
+                            const int col = g * 128 + 32 * w + 16 * hh + li;
+                            out[o++] = src[(size_t)(lq * 8 + k4 * 4 + j) * 512 + col] * gate_scale(col);
+                        }
+    }
+    return out;
+}
+
 void free_slot(Slot &s) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     for (auto &t : s.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto ev : s.free_events) (void)hipEventDestroy(ev);
     (void)hipFree(s.d_x); (void)hipFree(s.zx); (void)hipFree(s.a1); (void)hipFree(s.a2);
-    (void)hipFree(s.l3); (void)hipFree(s.l4part); (void)hipFree(s.d_out);
+    (void)hipFree(s.l4part); (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.stream) (void)hipStreamDestroy(s.stream);
 }
@@ -186,16 +204,10 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     const int ntiles = n_pad / 16;
     const int m_rows = T_POS * n_pad;
     s.last_n_pad = n_pad;
-    {   // LSTM1 input projection
-        KernelTimer kt(e, s, CLAIR_K_PROJ1);
-        GemmArgs a{x_dev, e->wx1p, e->bx1, s.zx, n_pad, ntiles, m_rows, F_IN / 16};
-        dim3 grid((m_rows + 127) / 128, 8, 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_PROJ1, 4, 4>), grid, dim3(256), 0, s.stream, a);
-    }
-    {
+    {   // LSTM1 with its input projection fused in (no separate GEMM, no zx round trip)
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        LstmArgs a{s.zx, e->wh1p, s.a1, n_pad, ntiles};
-        hipLaunchKernelGGL(lstm_rec_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        Lstm1Args a{x_dev, e->wx1f, e->wh1p, e->bx1, s.a1, n_pad, ntiles};
+        hipLaunchKernelGGL(lstm1_fused_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
@@ -208,16 +220,10 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles};
         hipLaunchKernelGGL(lstm_rec_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
-    {
-        KernelTimer kt(e, s, CLAIR_K_L3);
-        L3Args a{s.a2, e->w3p, e->b3p, s.l3, n_pad};
-        hipLaunchKernelGGL(l3_kernel, dim3(n_pad / L3_CAND), dim3(256), 0, s.stream, a);
-    }
-    {
+    {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
-        GemmArgs a{s.l3, e->w4p, nullptr, s.l4part, n_pad, ntiles, n_pad, (L3_OUT / 16) / L4_SPLITS};
-        dim3 grid((n_pad + 63) / 64, 1, L4_SPLITS);
-        hipLaunchKernelGGL((gemm_f32_kernel<GEMM_L4, 2, 6>), grid, dim3(256), 0, s.stream, a);
+        L3L4Args a{s.a2, e->w3f, e->b3, e->w4p, s.l4part, n_pad};
+        hipLaunchKernelGGL(l3l4_kernel, dim3(n_pad / L34_CAND, L4_SPLITS), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
@@ -274,7 +280,6 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.a1, (size_t)T_POS * mp * 256 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.l3, mp * L3_OUT * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, (size_t)max_batch * OUT_FLOATS * sizeof(float), hipHostMallocDefault);
@@ -292,7 +297,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3p, e->b3p, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p};
+    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3f, e->b3, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p, e->wx1f};
     for (float *p : w) (void)hipFree(p);
     delete e;
 }
@@ -313,7 +318,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3p, &e->b3p, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p};
+    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3f, &e->b3, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p, &e->wx1f};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
     auto cat = [](const std::vector<float> &a, const std::vector<float> &b) {   // both directions' biases, gate-scaled
@@ -325,15 +330,19 @@ int clair_finalize_weights(clair_engine_t *e) {
     if (upload(e, &e->wx2p, pack_wx(T[4], T[6], 2 * HID))) return 1;
     if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
     if (upload(e, &e->wh1p, pack_wh(T[0], T[2], F_IN))) return 1;
+    if (upload(e, &e->wx1f, pack_wx_frag(T[0], T[2]))) return 1;
     if (upload(e, &e->wh2p, pack_wh(T[4], T[6], 2 * HID))) return 1;
-    {   // W3p[t][u][c] = l3_kernel[c][t][u]; b3p[u][c]
-        std::vector<float> w3((size_t)T_POS * L3_UNITS * 256), b3((size_t)L3_UNITS * 256);
+    {   // L3 B fragments (dense.hip.h: l3l4_kernel): w3f[c][lane][kk*2 + nbk] = W3[c][t = lq*9 + kk][u = nbk*16 + li]
+        std::vector<float> w3f((size_t)256 * 64 * 20, 0.0f);
         for (int c = 0; c < 256; ++c)
-            for (int t = 0; t < T_POS; ++t)
-                for (int u = 0; u < L3_UNITS; ++u) w3[((size_t)t * L3_UNITS + u) * 256 + c] = T[8][((size_t)c * T_POS + t) * L3_UNITS + u];
-        for (int c = 0; c < 256; ++c)
-            for (int u = 0; u < L3_UNITS; ++u) b3[(size_t)u * 256 + c] = T[9][(size_t)c * L3_UNITS + u];
-        if (upload(e, &e->w3p, w3) || upload(e, &e->b3p, b3)) return 1;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int kk = 0; kk < 9; ++kk)
+                    for (int nbk = 0; nbk < 2; ++nbk) {
+                        const int t = (lane >> 4) * 9 + kk, u = nbk * 16 + (lane & 15);
+                        if (t < T_POS && u < L3_UNITS)
+                            w3f[((size_t)c * 64 + lane) * 20 + kk * 2 + nbk] = T[8][((size_t)c * T_POS + t) * L3_UNITS + u];
+                    }
+        if (upload(e, &e->w3f, w3f) || upload(e, &e->b3, T[9])) return 1;
     }
     {   // W4p[slab][192][16]
         std::vector<float> w4((size_t)L3_OUT * L4_UNITS);
@@ -497,7 +506,6 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
     switch (which) {
         case 1: src = s.a1; avail = (int64_t)T_POS * np * 256; break;
         case 2: src = s.a2; avail = (int64_t)T_POS * np * 256; break;
-        case 3: src = s.l3; avail = np * L3_OUT; break;
         default: return fail(e, "clair_debug_read: unknown tap %d", which);
     }
     if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);

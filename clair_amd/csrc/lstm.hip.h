@@ -152,4 +152,119 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     store_h(T_POS - 1);
 }
 
+// ---- LSTM1 with the input projection fused in ------------------------------------------------------
+// Layer 1's x-part has K = 32 only: as a separate GEMM it is bound by writing (and re-reading) the
+// 135 KB/candidate x-projection, not by its 14 us of MFMA work.  Here the recurrent wave also holds its
+// [32 x 128] slice of Wx (64 more registers), reads x_t straight from the caller's [n][33][32] tensor
+// (one 128-byte line per candidate and position, fetched a step ahead) and runs 64 extra MFMAs per
+// step; the accumulators start from the (gate-scaled) bias.  No zx buffer, no DMA, one kernel less.
+struct Lstm1Args {
+    const float *x;     // [n_pad][33][32]  (rows >= n are zero)
+    const float *wxp;   // packed x-part  [2][4][8][2][64][4]  (dir, wave, nb, kk/4, lane, kk%4): Wx[lq*8 + kk][col], gate-scaled
+    const float *whp;   // packed h-part  [2][4][8][8][64][4]  as LstmArgs::whp
+    const float *bias;  // [2][512] gate-scaled
+    float *aout;        // [33][n_pad][256]
+    int n_pad;
+    int ntiles;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm1_fused_kernel(Lstm1Args p) {
+    __shared__ __attribute__((aligned(16))) float hbuf[2][16][H_LDS_ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int d = blockIdx.x & 1;
+    const int tile = blockIdx.x >> 1;
+
+    float Bw[8][32], Bx[8][8], bv[8];
+    {
+        const f32x4 *wp = (const f32x4 *)p.whp + (size_t)(d * 4 + w) * (8 * 8 * 64) + lane;
+        const f32x4 *xp = (const f32x4 *)p.wxp + (size_t)(d * 4 + w) * (8 * 2 * 64) + lane;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) {
+                const f32x4 v = wp[(nb * 8 + k4) * 64];
+                Bw[nb][k4 * 4 + 0] = v[0]; Bw[nb][k4 * 4 + 1] = v[1]; Bw[nb][k4 * 4 + 2] = v[2]; Bw[nb][k4 * 4 + 3] = v[3];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 2; ++k4) {
+                const f32x4 v = xp[(nb * 2 + k4) * 64];
+                Bx[nb][k4 * 4 + 0] = v[0]; Bx[nb][k4 * 4 + 1] = v[1]; Bx[nb][k4 * 4 + 2] = v[2]; Bx[nb][k4 * 4 + 3] = v[3];
+            }
+            bv[nb] = p.bias[d * GATES + (nb >> 1) * HID + 32 * w + 16 * (nb & 1) + li];
+        }
+    }
+    float cst[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cst[e] = 0.0f;
+
+    // this lane's 8 features (lq*8 .. lq*8+7) of candidate li at position t(s)
+    const float *xrow = p.x + ((size_t)tile * 16 + li) * (T_POS * F_IN) + lq * 8;
+    auto load_x = [&](f32x4 (&xf)[2], int s) {
+        const int t = d ? T_POS - 1 - s : s;
+        xf[0] = *(const f32x4 *)(xrow + t * F_IN);
+        xf[1] = *(const f32x4 *)(xrow + t * F_IN + 4);
+    };
+    auto store_h = [&](int s) {
+        const int t = d ? T_POS - 1 - s : s;
+        float *base = p.aout + ((size_t)t * p.n_pad + (size_t)tile * 16) * (2 * HID) + d * HID;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int f = h2 * 256 + tid, row = f >> 5, c4 = f & 31;
+            *(f32x4 *)(base + (size_t)row * (2 * HID) + c4 * 4) = *(const f32x4 *)&hbuf[s & 1][row][c4 * 4];
+        }
+    };
+
+    f32x4 xcur[2], xnext[2];
+    load_x(xcur, 0);
+    for (int s = 0; s < T_POS; ++s) {
+        if (s > 0) store_h(s - 1);
+        load_x(xnext, s + 1 < T_POS ? s + 1 : s);
+
+        f32x4 acc[8];
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) acc[nb] = (f32x4){bv[nb], bv[nb], bv[nb], bv[nb]};
+#pragma unroll
+        for (int k4 = 0; k4 < 2; ++k4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) acc[nb] = mfma16(xcur[k4][j], Bx[nb][k4 * 4 + j], acc[nb]);
+        if (s > 0) {
+            f32x4 afr[8];
+            const float *hrow = &hbuf[(s - 1) & 1][li][lq * 32];
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) afr[k4] = *(const f32x4 *)(hrow + k4 * 4);
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) acc[nb] = mfma16(afr[k4][j], Bw[nb][k4 * 4 + j], acc[nb]);
+        }
+        constexpr float K2 = 2.0f * 1.44269504088896340736f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ri = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[0 + hh][r]));
+                const float rg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[2 + hh][r]));
+                const float rf = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[4 + hh][r]));
+                const float ro = fast_rcp(1.0f + __builtin_amdgcn_exp2f(acc[6 + hh][r]));
+                const float kg = fmaf(rg, -2.0f * K2, K2);
+                const float c = fmaf(rf, cst[hh * 4 + r], ri * kg);
+                cst[hh * 4 + r] = c;
+                const float rc = fast_rcp(1.0f + __builtin_amdgcn_exp2f(c));
+                hbuf[s & 1][lq * 4 + r][w * 32 + hh * 16 + li] = fmaf(rc, -2.0f * ro, ro);
+            }
+        xcur[0] = xnext[0];
+        xcur[1] = xnext[1];
+        __syncthreads();
+    }
+    store_h(T_POS - 1);
+}
+
 }  // namespace clair

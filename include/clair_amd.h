@@ -64,12 +64,12 @@ enum clair_tensor_id {
 
 /* kernels of one forward pass, in launch order (index into clair_kernel_times) */
 enum clair_kernel_id {
-    CLAIR_K_PROJ1 = 0,  /* LSTM1 input projection GEMM  [33n,32]x[32,1024]   */
-    CLAIR_K_LSTM1 = 1,  /* LSTM1 recurrence, both directions                 */
+    CLAIR_K_PROJ1 = 0,  /* (unused since the LSTM1 input projection is fused into CLAIR_K_LSTM1) */
+    CLAIR_K_LSTM1 = 1,  /* LSTM1: input projection + recurrence, both directions */
     CLAIR_K_PROJ2 = 2,  /* LSTM2 input projection GEMM  [33n,256]x[256,1024] */
     CLAIR_K_LSTM2 = 3,  /* LSTM2 recurrence                                  */
-    CLAIR_K_L3 = 4,     /* slice dense 256 x (33->30) + selu                 */
-    CLAIR_K_L4 = 5,     /* split-K GEMM 7680->192                            */
+    CLAIR_K_L3 = 4,     /* (unused: slice dense is fused into CLAIR_K_L4)    */
+    CLAIR_K_L4 = 5,     /* slice dense 256 x (33->30) + selu, split-K GEMM 7680->192 */
     CLAIR_K_TAIL = 6,   /* L4 reduce+selu, L5 x4, heads, selu, softmax       */
     CLAIR_K_COUNT = 7
 };
@@ -132,9 +132,8 @@ int clair_kernel_times(clair_engine_t *e, double *ms_sum /*[CLAIR_K_COUNT]*/, in
 int clair_timing_reset(clair_engine_t *e);
 
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
- *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
- *    3 = L3 output [n_pad,7680], 4 = L4 pre-activation partial sums reduced [n_pad,192] is not
- *    materialised -- use the outputs.  n_pad = n rounded up to 32. */
+ *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256]
+ *    (L3/L4 activations only ever exist in LDS / split-K partials).  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);
 
 #ifdef __cplusplus

@@ -41,10 +41,8 @@ def test_layerwise_taps(engine, synth_weights):
     n_pad = (n + 31) // 32 * 32      # engine pads to two 16-candidate tiles (include/clair_amd.h)
     a1 = engine.debug_read(0, 1, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
     a2 = engine.debug_read(0, 2, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
-    l3 = engine.debug_read(0, 3, (n_pad, 7680))[:n]
     assert np.abs(a1 - inter["a1"]).max() <= ACT_TOL
     assert np.abs(a2 - inter["a2"]).max() <= ACT_TOL
-    assert np.abs(l3 - inter["l3"]).max() <= 2e-5
 
 
 def test_submit_wait_two_slots(engine, synth_weights):
