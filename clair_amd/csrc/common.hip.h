@@ -41,4 +41,16 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).
+// Inline asm on purpose: hipcc then neither counts it nor fences later ds_reads of the same __shared__
+// array behind it with vmcnt(0).  M0 carries the LDS base and is compiler-reserved, so it is
+// saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const f32x4 *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
 }  // namespace clair

@@ -14,7 +14,8 @@ namespace clair {
 // an LDS tile laid out as L4's A operand, and L4 runs out of that tile with its B fragments read directly
 // from L2: the 30 KB/candidate l3 tensor never exists in HBM and a kernel launch disappears.
 constexpr int L34_CAND = 32;
-constexpr int L34_ROW = 30 * 16 + 4;   // 484 floats per candidate: 16-B aligned, conflict-free ds_read_b128 over candidates
+constexpr int L34_U = 20;               // floats per (candidate, u): 16 channels + 4 pad -> conflict-free ds_write_b128 over u
+constexpr int L34_ROW = 30 * L34_U + 4;  // 604 floats per candidate (16-B aligned; spreads candidates over banks for the A reads)
 
 struct L3L4Args {
     const float *a2;    // [33][n_pad][256]
@@ -26,7 +27,10 @@ struct L3L4Args {
 };
 
 __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
-    __shared__ __attribute__((aligned(16))) float l3s[L34_CAND][L34_ROW];
+    // one LDS buffer, two lives: first the a2 tile [33 t][32 cand][16 ch] (67.6 KB, filled by LDS-DMA),
+    // then -- after every wave has pulled its A fragments out of it -- the l3 tile that feeds L4
+    __shared__ __attribute__((aligned(16))) float lds_buf[L34_CAND * L34_ROW];
+    float (*l3s)[L34_ROW] = (float (*)[L34_ROW])lds_buf;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -36,15 +40,29 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
 
     // ---- L3 for this wave's four channels --------------------------------------------------------------
 #ifndef L34_SKIP_L3
+    f32x4 acc3[4][2][2];   // [channel][m-block][u-block]
     {
-        // A operands: candidate li (of block mb), positions t = lq*9 + kk, four channels per float4
+        // a2 tile -> LDS: row q = t*32 + cand is the 64 bytes a2[t][n0 + cand][cg*16 .. +15]; one DMA piece moves
+        // 16 rows (lane l: row 16*piece + l/4, 16-byte chunk l%4), so every fetched half-line is fully used and
+        // fetched once per workgroup (per-lane float4 loads of 4 channels touched each line from all four waves)
+        constexpr int NPIECE = T_POS * L34_CAND / 16;   // 66
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds_buf);
+        for (int piece = w; piece < NPIECE; piece += 4) {
+            const int q = piece * 16 + (lane >> 2);
+            const int t = q >> 5, cand = q & 31;
+            const float *src = p.a2 + ((size_t)t * p.n_pad + n0 + cand) * 256 + cg * 16 + (lane & 3) * 4;
+            glds16((const f32x4 *)src, lds0 + piece * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // A operands: candidate li (of block mb), positions t = lq*9 + kk, this wave's four channels per float4
         f32x4 av[2][9];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int kk = 0; kk < 9; ++kk) {
                 const int t = lq * 9 + kk;
-                av[mb][kk] = t < T_POS ? *(const f32x4 *)(p.a2 + ((size_t)t * p.n_pad + n0 + mb * 16 + li) * 256 + cg * 16 + w * 4)
+                av[mb][kk] = t < T_POS ? *(const f32x4 *)&lds_buf[((t * 32 + mb * 16 + li) * 16) + w * 4]
                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -54,30 +72,38 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
             const f32x4 *bp = (const f32x4 *)(p.w3f + ((size_t)c * 64 + lane) * 20);
 #pragma unroll
             for (int i = 0; i < 5; ++i) bf[i] = bp[i];
-            f32x4 acc[2][2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nbk = 0; nbk < 2; ++nbk) acc[mb][nbk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int nbk = 0; nbk < 2; ++nbk) acc3[cc][mb][nbk] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 9; ++kk)
 #pragma unroll
                 for (int nbk = 0; nbk < 2; ++nbk) {
                     const float b = bf[(kk * 2 + nbk) >> 2][(kk * 2 + nbk) & 3];
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) acc[mb][nbk] = mfma16(av[mb][kk][cc], b, acc[mb][nbk]);
+                    for (int mb = 0; mb < 2; ++mb) acc3[cc][mb][nbk] = mfma16(av[mb][kk][cc], b, acc3[cc][mb][nbk]);
                 }
+        }
+        asm volatile("" : "+v"(acc3[3][1][1]));   // the MFMAs stay on this side of the barrier
+        __syncthreads();                              // every wave is done reading the a2 tile: the buffer becomes l3s
+        // bias + selu, then one 16-byte LDS store per (candidate row, u): the wave's four channels together
 #pragma unroll
-            for (int nbk = 0; nbk < 2; ++nbk) {
-                const int u = nbk * 16 + li;
-                if (u < L3_UNITS) {
-                    const float bias = p.b3[c * L3_UNITS + u];
+        for (int nbk = 0; nbk < 2; ++nbk) {
+            const int u = nbk * 16 + li;
+            if (u < L3_UNITS) {
+                float bias[4];
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                for (int cc = 0; cc < 4; ++cc) bias[cc] = p.b3[(cg * 16 + w * 4 + cc) * L3_UNITS + u];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            l3s[mb * 16 + lq * 4 + r][u * 16 + w * 4 + cc] = selu_f(acc[mb][nbk][r] + bias);
-                }
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        f32x4 o;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) o[cc] = selu_f(acc3[cc][mb][nbk][r] + bias[cc]);
+                        *(f32x4 *)&l3s[mb * 16 + lq * 4 + r][u * L34_U + w * 4] = o;
+                    }
             }
         }
     }
@@ -110,7 +136,7 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
         }
         f32x4 a[2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *(const f32x4 *)&l3s[mb * 16 + li][u * 16 + lq * 4];
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *(const f32x4 *)&l3s[mb * 16 + li][u * L34_U + lq * 4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll

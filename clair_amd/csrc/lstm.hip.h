@@ -42,18 +42,6 @@ constexpr int H_LDS_ROW = HID + 4;  // 132 floats: rows 16 B apart in bank space
 //     whole 512-byte rows at the start of the NEXT step -- all VMEM of a step is issued before its
 //     MFMAs, so the only vmcnt wait (before the DMA'd data is read, a step later) never stalls;
 //   * gates: 21 VALU/transcendental instructions per element thanks to the pre-scaled columns.
-typedef __attribute__((address_space(3))) void *lptr_t;
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).
-// Inline asm on purpose: hipcc then neither counts it nor fences later ds_reads of the same __shared__
-// array behind it with vmcnt(0).  M0 carries the LDS base and is compiler-reserved, so it is
-// saved/restored inside the statement.
-__device__ __forceinline__ void glds16(const f32x4 *gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
-
 struct LstmArgs {
     const float *zx;   // fragment-major x-projection [2][33][ntiles][4][8][64][4]  (gemm.hip.h), gate-scaled
     const float *whp;  // packed recurrent weights [2][4][8][8][64][4]  (dir, wave, nb, kk/4, lane, kk%4), gate-scaled
@@ -113,17 +101,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < T_POS; ++s) {
         // everything older than this step's VMEM has landed: z(s) (issued a whole step ago) in particular
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (s > 0) store_h(s - 1);
-        if (s + 1 < T_POS) fetch_zx(s + 1);
-
-        f32x4 acc[8];
+        // LDS reads first (they gate the MFMAs), then this step's VMEM issue under their latency
+        f32x4 acc[8], afr[8];
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) acc[nb] = *(const f32x4 *)&zlds[s & 1][w][nb][lane * 4];
         if (s > 0) {
-            f32x4 afr[8];
             const float *hrow = &hbuf[(s - 1) & 1][li][lq * 32];
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4) afr[k4] = *(const f32x4 *)(hrow + k4 * 4);
+        }
+        if (s + 1 < T_POS) fetch_zx(s + 1);
+        if (s > 0) {
+            store_h(s - 1);
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4)
 #pragma unroll
@@ -221,10 +210,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 xcur[2], xnext[2];
     load_x(xcur, 0);
     for (int s = 0; s < T_POS; ++s) {
-        if (s > 0) store_h(s - 1);
+        f32x4 acc[8], afr[8];
+        if (s > 0) {   // A fragments of h_{s-1} first: their LDS latency hides under the 64 x-part MFMAs
+            const float *hrow = &hbuf[(s - 1) & 1][li][lq * 32];
+#pragma unroll
+            for (int k4 = 0; k4 < 8; ++k4) afr[k4] = *(const f32x4 *)(hrow + k4 * 4);
+        }
         load_x(xnext, s + 1 < T_POS ? s + 1 : s);
-
-        f32x4 acc[8];
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) acc[nb] = (f32x4){bv[nb], bv[nb], bv[nb], bv[nb]};
 #pragma unroll
@@ -234,10 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb) acc[nb] = mfma16(xcur[k4][j], Bx[nb][k4 * 4 + j], acc[nb]);
         if (s > 0) {
-            f32x4 afr[8];
-            const float *hrow = &hbuf[(s - 1) & 1][li][lq * 32];
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) afr[k4] = *(const f32x4 *)(hrow + k4 * 4);
+            store_h(s - 1);
 #pragma unroll
             for (int k4 = 0; k4 < 8; ++k4)
 #pragma unroll
