@@ -41,6 +41,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- exact 3-way bf16 split of fp32 values (gemm_split.hip.h) -------------------------------------------
+// v_cvt_pk_bf16_f32 rounds two floats to nearest-even bf16 and packs them (lo | hi << 16); it has no builtin.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// x = p1 + p2 + p3 exactly, each a bf16; out[plane] = packed pair for (x0, x1)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&out)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const unsigned u = cvt_pk_bf16(x0, x1);
+        out[pl] = u;
+        x0 -= __uint_as_float(u << 16);
+        x1 -= __uint_as_float(u & 0xffff0000u);
+    }
+}
+
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).
