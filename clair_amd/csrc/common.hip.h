@@ -41,22 +41,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// ---- exact 3-way bf16 split of fp32 values (gemm_split.hip.h) -------------------------------------------
-// v_cvt_pk_bf16_f32 rounds two floats to nearest-even bf16 and packs them (lo | hi << 16); it has no builtin.
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+// ---- 2-way fp16 split of fp32 values (gemm_split.hip.h, lstm.hip.h) ------------------------------------
+// x ~= x1 + x2 with x1 = fp16(x), x2 = fp16(x - x1): 22 significand bits (relative error <= 2^-22, absolute
+// error <= 3e-8 once x2 falls into the fp16 subnormal range), round-to-nearest-even both times.  Products of
+// two fp16 values are exact in fp32, so  a*b ~= a1*b1 + a1*b2 + a2*b1  on v_mfma_f32_16x16x32_f16 (16x the
+// rate of the fp32 MFMA) reproduces the fp32 product to ~3e-7 relative: end to end the probabilities stay as
+// close to a float64 evaluation as with fp32 MFMAs (4.6e-7..8e-7 vs 3.5e-7..4.6e-7, tools/split_emulation.py).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // one MFMA A/B operand (4 VGPRs)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
 }
-// x = p1 + p2 + p3 exactly, each a bf16; out[plane] = packed pair for (x0, x1)
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&out)[3]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        const unsigned u = cvt_pk_bf16(x0, x1);
-        out[pl] = u;
-        x0 -= __uint_as_float(u << 16);
-        x1 -= __uint_as_float(u & 0xffff0000u);
-    }
+
+__device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+    // v_mfma_f32_16x16x32_f16: lane (i = l&15, q = l>>4) supplies A[i][8q..8q+7] / B[8q..8q+7][i]; C/D as mfma16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 typedef __attribute__((address_space(3))) void *lptr_t;

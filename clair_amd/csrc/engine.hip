@@ -36,7 +36,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     float *d_x = nullptr;     // [max_pad][1056]
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
-    unsigned short *a1 = nullptr;   // [3][33][max_pad][256] bf16: LSTM1 output as its exact 3-way split
+    unsigned short *a1 = nullptr;   // [2][33][max_pad][256] fp16: LSTM1 output as its 2-way split
     float *a2 = nullptr;      // [33][max_pad][256]
     float *l4part = nullptr;  // [16][max_pad][192]
     float *d_out = nullptr;   // [max_pad][90]
@@ -63,7 +63,7 @@ struct clair_engine {
     // device weights
     float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
     float *wh1p = nullptr, *wh2p = nullptr, *wx1f = nullptr;
-    unsigned short *wx2s = nullptr;   // [8][3][1024][32] bf16 planes of the gate-scaled Wx2
+    unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
     float *w3f = nullptr, *b3 = nullptr, *w4p = nullptr, *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
     double ms_sum[CLAIR_K_COUNT] = {0};
@@ -95,15 +95,14 @@ int upload(clair_engine *e, float **dst, const std::vector<float> &src) {
     return 0;
 }
 
-// host-side bf16 (round to nearest even), matching v_cvt_pk_bf16_f32 for finite values
-inline unsigned short bf16_rne(float f) {
-    uint32_t u; memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-inline float bf16_to_float(unsigned short b) {
-    uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4);
-    return f;
+// host-side 2-way fp16 split (round to nearest even; _Float16 conversions are IEEE on the host compiler too)
+inline unsigned short f16_bits(_Float16 h) { unsigned short u; memcpy(&u, &h, 2); return u; }
+inline float f16_value(unsigned short u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+inline void split2_host(float x, unsigned short &hi, unsigned short &lo) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    hi = f16_bits(h);
+    lo = f16_bits(l);
 }
 
 // Factor folded into every LSTM gate column (and bias) so the MFMA result is the exp2 argument of the
@@ -222,7 +221,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         Lstm1Args a{x_dev, e->wx1f, e->wh1p, e->bx1, s.a1, n_pad, ntiles};
         hipLaunchKernelGGL(lstm1_fused_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
-    {   // LSTM2 input projection on the bf16 matrix cores, fp32-grade via the exact 3-way split
+    {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
         GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows};
         dim3 grid((m_rows + 127) / 128, 8, 1);
@@ -291,7 +290,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, (size_t)3 * T_POS * mp * 256 * sizeof(unsigned short));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, (size_t)2 * T_POS * mp * 256 * sizeof(unsigned short));
         if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
@@ -342,20 +341,19 @@ int clair_finalize_weights(clair_engine_t *e) {
         return r; };
     if (upload(e, &e->wx1p, pack_wx(T[0], T[2], F_IN))) return 1;
     if (upload(e, &e->bx1, cat(T[1], T[3]))) return 1;
-    {   // Wx2 (gate-scaled) as three bf16 planes, [kstep][plane][col][32]  (gemm_split.hip.h)
-        std::vector<unsigned short> w3s((size_t)8 * 3 * 1024 * 32);
+    {   // Wx2 (gate-scaled) as two fp16 planes, [kstep][plane][col][32]  (gemm_split.hip.h)
+        std::vector<unsigned short> w2s((size_t)8 * 2 * 1024 * 32);
         for (int k = 0; k < 2 * HID; ++k)
             for (int col = 0; col < 1024; ++col) {
                 const std::vector<float> &src = col < 512 ? T[4] : T[6];
-                float v = src[(size_t)k * 512 + (col & 511)] * gate_scale(col & 511);
-                for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned short b = bf16_rne(v);
-                    w3s[(((size_t)(k / 32) * 3 + pl) * 1024 + col) * 32 + (k % 32)] = b;
-                    v -= bf16_to_float(b);
-                }
+                const float v = src[(size_t)k * 512 + (col & 511)] * gate_scale(col & 511);
+                unsigned short hi, lo;
+                split2_host(v, hi, lo);
+                w2s[(((size_t)(k / 32) * 2 + 0) * 1024 + col) * 32 + (k % 32)] = hi;
+                w2s[(((size_t)(k / 32) * 2 + 1) * 1024 + col) * 32 + (k % 32)] = lo;
             }
-        HIP_TRY(e, hipMalloc((void **)&e->wx2s, w3s.size() * sizeof(unsigned short)));
-        HIP_TRY(e, hipMemcpy(e->wx2s, w3s.data(), w3s.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMalloc((void **)&e->wx2s, w2s.size() * sizeof(unsigned short)));
+        HIP_TRY(e, hipMemcpy(e->wx2s, w2s.data(), w2s.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
     if (upload(e, &e->wh1p, pack_wh(T[0], T[2], F_IN))) return 1;
@@ -532,13 +530,12 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
     const float *src = nullptr;
     int64_t avail = 0;
     const int64_t np = s.last_n_pad;
-    if (which == 1) {   // LSTM1 output lives as three bf16 planes: hand back their (exact) fp32 sum
+    if (which == 1) {   // LSTM1 output lives as two fp16 planes: hand back their fp32 sum
         avail = (int64_t)T_POS * np * 256;
         if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap 1 holds %lld", (long long)count, (long long)avail);
-        std::vector<unsigned short> planes((size_t)3 * avail);
+        std::vector<unsigned short> planes((size_t)2 * avail);
         HIP_TRY(e, hipMemcpy(planes.data(), s.a1, planes.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < count; ++i)
-            host[i] = (bf16_to_float(planes[i]) + bf16_to_float(planes[avail + i])) + bf16_to_float(planes[2 * avail + i]);
+        for (int64_t i = 0; i < count; ++i) host[i] = f16_value(planes[i]) + f16_value(planes[avail + i]);
         return 0;
     }
     switch (which) {

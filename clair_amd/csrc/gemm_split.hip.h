@@ -1,31 +1,23 @@
 // LSTM2 input projection  zx2 = a1[33n,256] . Wx2[256,1024] + b2  (clair/model.py:443-450, x-part)
-// with fp32-grade accuracy on the bf16 matrix cores ("3-way split").
+// with fp32-grade accuracy on the fp16 matrix cores ("2-way split", common.hip.h):
+//     a*b ~= a1*b1 + a1*b2 + a2*b1,   x1 = fp16(x), x2 = fp16(x - x1)
+// Three v_mfma_f32_16x16x32_f16 per 16x16x32 block replace eight v_mfma_f32_16x16x4_f32 (51 instead of 256
+// matrix-pipe cycles), and -- unlike fp32 MFMAs -- they leave issue slots for the LDS reads in between.
 //
-// Every fp32 value is the exact sum of three bf16 values (8 + 8 + 8 significand bits):
-//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2).
-// A product a*b then equals the sum of nine bf16 x bf16 products, each exact in fp32; the six with
-// i + j <= 4 carry everything above 2^-26 |a b|:   a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2.
-// v_mfma_f32_16x16x32_bf16 runs at 16x the rate of v_mfma_f32_16x16x4_f32, so six of them per
-// 16x16x32 block cost ~0.4x of the eight fp32 MFMAs they replace, and -- unlike fp32 MFMAs -- they
-// leave issue slots for the LDS reads in between.  Measured error against float64: 1.1e-6 vs 2.3e-6 for
-// the plain fp32 product on the same operands (tools: see DESIGN.md section 3); end-to-end parity and GT
-// identity are checked by the same tests as before.
-//
-// Operands arrive pre-split: LSTM1 writes its output as three bf16 planes (lstm.hip.h: store_h3), the
-// host splits the gate-scaled Wx2 (engine.hip: pack_wx2_split).  Tile: 128 x 128 per 256-thread
-// workgroup, 2x2 waves of 64 x 64 (16 accumulator blocks), K in steps of 32 through LDS.
+// Operands arrive pre-split: LSTM1 writes its output as two fp16 planes (lstm.hip.h), the host splits the
+// gate-scaled Wx2 (engine.hip).  Tile: 128 x 128 per 256-thread workgroup, 2x2 waves of 64 x 64
+// (16 accumulator blocks), K in steps of 32 through LDS.
 #pragma once
 #include "common.hip.h"
 #include "gemm.hip.h"
 
 namespace clair {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 = one MFMA A/B operand (4 VGPRs)
-typedef unsigned short bf16_t;
+typedef unsigned short f16bits_t;   // raw fp16 storage
 
 struct GemmSplitArgs {
-    const bf16_t *A3;    // [3][33*n_pad][256]  bf16 planes of a1 (rows in (t, n) order)
-    const bf16_t *B3;    // [8 ksteps][3 planes][1024 cols][32 k]  bf16 planes of gate-scaled Wx2
+    const f16bits_t *A3;    // [2][33*n_pad][256]  fp16 planes of a1 (rows in (t, n) order)
+    const f16bits_t *B3;    // [8 ksteps][2 planes][1024 cols][32 k]  fp16 planes of gate-scaled Wx2
     const float *bias;   // [1024] gate-scaled
     float *C;            // fragment-major zx (gemm.hip.h: zx_block_offset)
     int n_pad;
@@ -33,14 +25,14 @@ struct GemmSplitArgs {
     int m_rows;          // 33 * n_pad
 };
 
-// LDS tile of one plane: 128 rows (or columns) x 32 bf16 = 64 B per row, four 16-byte chunks per row,
+// LDS tile of one plane: 128 rows (or columns) x 32 fp16 = 64 B per row, four 16-byte chunks per row,
 // chunk index XOR-swizzled with (row >> 2) & 3 so that the ds_read_b128 of 16 consecutive rows at one
 // k-chunk spreads over all banks (unswizzled: 4-way conflict, row pitch = 16 dwords).
-__device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }   // in bf16 units
+__device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }   // in fp16 units
 
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[3][128 * 32];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[3][128 * 32];
+__global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
+    __shared__ __attribute__((aligned(16))) f16bits_t As[2][128 * 32];
+    __shared__ __attribute__((aligned(16))) f16bits_t Bs[2][128 * 32];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -51,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
     const int col0 = blockIdx.y * 128;
 
     // staging map: chunk id f = tid + 256*h (h = 0,1) of a plane tile: row f>>2, 16-byte chunk f&3
-    const bf16_t *asrc[2];
+    const f16bits_t *asrc[2];
     int lds_dst[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -62,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
         lds_dst[h] = split_lds_off(r, c);
     }
     const size_t a_plane = (size_t)p.m_rows * 256;
-    const bf16_t *bsrc = p.B3 + ((size_t)col0 * 32) + (size_t)tid * 8;   // + (kstep*3 + plane)*1024*32 + h*256*8
+    const f16bits_t *bsrc = p.B3 + ((size_t)col0 * 32) + (size_t)tid * 8;   // + (kstep*2 + plane)*1024*32 + h*256*8
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -70,14 +62,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[3][2], rb[3][2];   // raw 16-byte chunks in flight (bf16x8 each)
+    f32x4 ra[2][2], rb[2][2];   // raw 16-byte chunks in flight (f16x8 each)
     auto gload = [&](int ks) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 ra[pl][h] = *(const f32x4 *)(asrc[h] + pl * a_plane + ks * 32);
-                rb[pl][h] = *(const f32x4 *)(bsrc + ((size_t)(ks * 3 + pl) * 1024 * 32) + h * 256 * 8);
+                rb[pl][h] = *(const f32x4 *)(bsrc + ((size_t)(ks * 2 + pl) * 1024 * 32) + h * 256 * 8);
             }
     };
     gload(0);
@@ -85,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
     for (int ks = 0; ks < KSTEPS; ++ks) {
         __syncthreads();   // previous step's fragments are all in registers / consumed
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 *(f32x4 *)&As[pl][lds_dst[h]] = ra[pl][h];
@@ -93,25 +85,21 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmSplitArgs p) {
             }
         __syncthreads();
         if (ks + 1 < KSTEPS) gload(ks + 1);
-        // A fragments of this wave's four 16-row blocks, three planes: lane (li, lq) = row li, k-chunk lq
-        bf16x8 af[3][4];
+        // A fragments of this wave's four 16-row blocks, both planes: lane (li, lq) = row li, k-chunk lq
+        f16x8 af[2][4];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[pl][mi] = *(const bf16x8 *)&As[pl][split_lds_off(wm * 64 + mi * 16 + li, lq)];
+            for (int mi = 0; mi < 4; ++mi) af[pl][mi] = *(const f16x8 *)&As[pl][split_lds_off(wm * 64 + mi * 16 + li, lq)];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            bf16x8 bfr[3];
+            f16x8 bfr[2];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bfr[pl] = *(const bf16x8 *)&Bs[pl][split_lds_off(wn * 64 + ni * 16 + li, lq)];
-            // six product terms, smallest first; the four row blocks alternate so that consecutive MFMAs
+            for (int pl = 0; pl < 2; ++pl) bfr[pl] = *(const f16x8 *)&Bs[pl][split_lds_off(wn * 64 + ni * 16 + li, lq)];
+            // three product terms, small ones first; the four row blocks alternate so that consecutive MFMAs
             // never wait on each other's accumulator
-#define SPLIT_TERM(PA, PB)                                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA][mi], bfr[PB], acc[mi][ni], 0, 0, 0);
-            SPLIT_TERM(2, 0)
-            SPLIT_TERM(0, 2)
-            SPLIT_TERM(1, 1)
+#define SPLIT_TERM(PA, PB)                                                    \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma16h(af[PA][mi], bfr[PB], acc[mi][ni]);
             SPLIT_TERM(1, 0)
             SPLIT_TERM(0, 1)
             SPLIT_TERM(0, 0)

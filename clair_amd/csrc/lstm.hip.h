@@ -152,7 +152,7 @@ struct Lstm1Args {
     const float *wxp;   // packed x-part  [2][4][8][2][64][4]  (dir, wave, nb, kk/4, lane, kk%4): Wx[lq*8 + kk][col], gate-scaled
     const float *whp;   // packed h-part  [2][4][8][8][64][4]  as LstmArgs::whp
     const float *bias;  // [2][512] gate-scaled
-    unsigned short *aout3;  // [3][33][n_pad][256] bf16: the output as its exact 3-way bf16 split, the form the
+    unsigned short *aout3;  // [2][33][n_pad][256] fp16: the output as its 2-way fp16 split, the form the
                             // LSTM2 projection GEMM consumes (gemm_split.hip.h); nothing else reads layer 1's output
     int n_pad;
     int ntiles;
@@ -199,19 +199,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         xf[1] = *(const f32x4 *)(xrow + t * F_IN + 4);
     };
     const size_t plane = (size_t)T_POS * p.n_pad * (2 * HID);
-    auto store_h = [&](int s) {   // h_s -> three bf16 planes, 8 bytes (4 units) per thread and plane, 256-byte row segments
+    auto store_h = [&](int s) {   // h_s -> two fp16 planes, 8 bytes (4 units) per thread and plane, 256-byte row segments
         const int t = d ? T_POS - 1 - s : s;
         unsigned short *base = p.aout3 + ((size_t)t * p.n_pad + (size_t)tile * 16) * (2 * HID) + d * HID;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int f = h2 * 256 + tid, row = f >> 5, c4 = f & 31;
             const f32x4 h = *(const f32x4 *)&hbuf[s & 1][row][c4 * 4];
-            unsigned lo[3], hi[3];
-            split3_pair(h[0], h[1], lo);
-            split3_pair(h[2], h[3], hi);
+            f16x4 hi, lo;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                *(uint2 *)(base + pl * plane + (size_t)row * (2 * HID) + c4 * 4) = make_uint2(lo[pl], hi[pl]);
+            for (int j = 0; j < 4; ++j) { _Float16 a, b; split2(h[j], a, b); hi[j] = a; lo[j] = b; }
+            *(f16x4 *)(base + (size_t)row * (2 * HID) + c4 * 4) = hi;
+            *(f16x4 *)(base + plane + (size_t)row * (2 * HID) + c4 * 4) = lo;
         }
     };
 
