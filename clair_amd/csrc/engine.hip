@@ -63,6 +63,7 @@ struct clair_engine {
     // device weights
     float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
     float *wh1p = nullptr, *wh2p = nullptr, *wx1f = nullptr;
+    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr;   // fp16 split register images (lstm_split_kernel)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
     float *w3f = nullptr, *b3 = nullptr, *w4p = nullptr, *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
@@ -162,6 +163,55 @@ std::vector<float> pack_wx_frag(const std::vector<float> &fw, const std::vector<
     return out;
 }
 
+// fp16 2-way split register images for the split recurrent kernels (lstm.hip.h: lstm_split_kernel)
+// h-part: [dir][wave][nb][kstep][plane][lane][8]: W[D + 32*ks + 8*lq + j][col(nb, li)] * gate_scale
+std::vector<unsigned short> pack_wh_split(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
+    std::vector<unsigned short> out((size_t)2 * 4 * 8 * 4 * 2 * 64 * 8);
+    for (int d = 0; d < 2; ++d) {
+        const std::vector<float> &src = d ? bw : fw;
+        for (int w = 0; w < 4; ++w)
+            for (int nb = 0; nb < 8; ++nb)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
+                            const int col = g * 128 + 32 * w + 16 * hh + li, k = 32 * ks + 8 * lq + j;
+                            unsigned short hi, lo;
+                            split2_host(src[(size_t)(D + k) * 512 + col] * gate_scale(col), hi, lo);
+                            const size_t base = (((((size_t)(d * 4 + w) * 8 + nb) * 4 + ks) * 2) * 64 + lane) * 8 + j;
+                            out[base] = hi;
+                            out[base + 64 * 8] = lo;
+                        }
+    }
+    return out;
+}
+// x-part of LSTM1: [dir][wave][nb][plane][lane][8]: W[8*lq + j][col(nb, li)] * gate_scale
+std::vector<unsigned short> pack_wx_split(const std::vector<float> &fw, const std::vector<float> &bw) {
+    std::vector<unsigned short> out((size_t)2 * 4 * 8 * 2 * 64 * 8);
+    for (int d = 0; d < 2; ++d) {
+        const std::vector<float> &src = d ? bw : fw;
+        for (int w = 0; w < 4; ++w)
+            for (int nb = 0; nb < 8; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
+                        const int col = g * 128 + 32 * w + 16 * hh + li, k = 8 * lq + j;
+                        unsigned short hi, lo;
+                        split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
+                        const size_t base = ((((size_t)(d * 4 + w) * 8 + nb) * 2) * 64 + lane) * 8 + j;
+                        out[base] = hi;
+                        out[base + 64 * 8] = lo;
+                    }
+    }
+    return out;
+}
+int upload16(clair_engine *e, unsigned short **dst, const std::vector<unsigned short> &src) {
+    (void)hipFree(*dst); *dst = nullptr;
+    HIP_TRY(e, hipMalloc((void **)dst, src.size() * sizeof(unsigned short)));
+    HIP_TRY(e, hipMemcpy(*dst, src.data(), src.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    return 0;
+}
+
 void free_slot(Slot &s) {
     if (s.stream) (void)hipStreamSynchronize(s.stream);
     for (auto &t : s.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -216,10 +266,10 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     const int ntiles = n_pad / 16;
     const int m_rows = T_POS * n_pad;
     s.last_n_pad = n_pad;
-    {   // LSTM1 with its input projection fused in (no separate GEMM, no zx round trip)
+    {   // LSTM1 with its input projection fused in (no separate GEMM, no zx round trip), fp16 split products
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        Lstm1Args a{x_dev, e->wx1f, e->wh1p, e->bx1, s.a1, n_pad, ntiles};
-        hipLaunchKernelGGL(lstm1_fused_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        LstmSplitArgs a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm_split_kernel<true>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
@@ -229,8 +279,8 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        LstmArgs a{s.zx, e->wh2p, s.a2, n_pad, ntiles};
-        hipLaunchKernelGGL(lstm_rec_kernel, dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        LstmSplitArgs a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm_split_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
@@ -311,7 +361,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     for (auto &s : e->slots) free_slot(s);
     float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3f, e->b3, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p, e->wx1f};
     for (float *p : w) (void)hipFree(p);
-    (void)hipFree(e->wx2s);
+    (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s);
     delete e;
 }
 
@@ -356,6 +406,8 @@ int clair_finalize_weights(clair_engine_t *e) {
         HIP_TRY(e, hipMemcpy(e->wx2s, w2s.data(), w2s.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     }
     if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
+    if (upload16(e, &e->wh1s, pack_wh_split(T[0], T[2], F_IN)) || upload16(e, &e->wh2s, pack_wh_split(T[4], T[6], 2 * HID)) ||
+        upload16(e, &e->wx1s, pack_wx_split(T[0], T[2]))) return 1;
     if (upload(e, &e->wh1p, pack_wh(T[0], T[2], F_IN))) return 1;
     if (upload(e, &e->wx1f, pack_wx_frag(T[0], T[2]))) return 1;
     if (upload(e, &e->wh2p, pack_wh(T[4], T[6], 2 * HID))) return 1;
