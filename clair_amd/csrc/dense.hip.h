@@ -14,14 +14,15 @@ namespace clair {
 // an LDS tile laid out as L4's A operand, and L4 runs out of that tile with its B fragments read directly
 // from L2: the 30 KB/candidate l3 tensor never exists in HBM and a kernel launch disappears.
 constexpr int L34_CAND = 32;
-constexpr int L34_U = 20;               // floats per (candidate, u): 16 channels + 4 pad -> conflict-free ds_write_b128 over u
-constexpr int L34_ROW = 30 * L34_U + 4;  // 604 floats per candidate (16-B aligned; spreads candidates over banks for the A reads)
+constexpr int L34_ROW = 30 * 16 + 8;    // fp16 units per candidate row of one l3 plane: 976 B, 16-B aligned, rows 52 banks apart
+constexpr int L34_LDS_BYTES = 33 * 32 * 16 * 4;   // the a2 staging tile (67 584 B) is the larger of the buffer's two lives
 
 struct L3L4Args {
     const float *a2;    // [33][n_pad][256]
     const float *w3f;   // [256][64][20]  B fragments of L3: slot kk*2 + nbk = W3[c][t = lq*9 + kk][u = nbk*16 + li] (0 beyond 33 / 30)
     const float *b3;    // [256][30]
-    const float *w4p;   // [480][192][16] packed W4 (gemm.hip.h layout), slab = u*16 + cg
+    const unsigned short *w4s;   // [16 cg][15 ks][12 nb][2 plane][64 lane][8] fp16 split of W4: row u*256 + cg*16 + ch with
+                                 // u = 2*ks + (lq>>1), ch = 8*(lq&1) + j; column nb*16 + li
     float *part;        // [16][n_pad][192]
     int n_pad;
 };
@@ -29,8 +30,8 @@ struct L3L4Args {
 __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
     // one LDS buffer, two lives: first the a2 tile [33 t][32 cand][16 ch] (67.6 KB, filled by LDS-DMA),
     // then -- after every wave has pulled its A fragments out of it -- the l3 tile that feeds L4
-    __shared__ __attribute__((aligned(16))) float lds_buf[L34_CAND * L34_ROW];
-    float (*l3s)[L34_ROW] = (float (*)[L34_ROW])lds_buf;
+    __shared__ __attribute__((aligned(16))) float lds_buf[L34_LDS_BYTES / 4];
+    _Float16 (*l3h)[L34_CAND][L34_ROW] = (_Float16 (*)[L34_CAND][L34_ROW])lds_buf;   // [plane][cand][u*16 + ch]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,7 +40,6 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
     const int cg = blockIdx.y;                 // channels cg*16 .. cg*16+15; this wave: 4 of them, cg*16 + 4w ..
 
     // ---- L3 for this wave's four channels --------------------------------------------------------------
-#ifndef L34_SKIP_L3
     f32x4 acc3[4][2][2];   // [channel][m-block][u-block]
     {
         // a2 tile -> LDS: row q = t*32 + cand is the 64 bytes a2[t][n0 + cand][cg*16 .. +15]; one DMA piece moves
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
         }
         asm volatile("" : "+v"(acc3[3][1][1]));   // the MFMAs stay on this side of the barrier
         __syncthreads();                              // every wave is done reading the a2 tile: the buffer becomes l3s
-        // bias + selu, then one 16-byte LDS store per (candidate row, u): the wave's four channels together
+        // bias + selu, 2-way fp16 split (the L4 product runs on the fp16 matrix cores), then one 8-byte LDS store
+        // per plane and (candidate row, u): the wave's four channels together
 #pragma unroll
         for (int nbk = 0; nbk < 2; ++nbk) {
             const int u = nbk * 16 + li;
@@ -99,50 +100,64 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        f32x4 o;
+                        f16x4 hi, lo;
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) o[cc] = selu_f(acc3[cc][mb][nbk][r] + bias[cc]);
-                        *(f32x4 *)&l3s[mb * 16 + lq * 4 + r][u * L34_U + w * 4] = o;
+                        for (int cc = 0; cc < 4; ++cc) {
+                            _Float16 a, b;
+                            split2(selu_f(acc3[cc][mb][nbk][r] + bias[cc]), a, b);
+                            hi[cc] = a;
+                            lo[cc] = b;
+                        }
+                        *(f16x4 *)&l3h[0][mb * 16 + lq * 4 + r][u * 16 + w * 4] = hi;
+                        *(f16x4 *)&l3h[1][mb * 16 + lq * 4 + r][u * 16 + w * 4] = lo;
                     }
             }
         }
     }
-#endif
     __syncthreads();
 
-    // ---- L4 over this K-slice: wave w owns output columns 48w .. 48w+47 (3 blocks), both 16-row blocks --------
+    // ---- L4 over this K-slice: wave w owns output columns 48w .. 48w+47 (3 blocks), both 16-row blocks ----------
+    // 2-way fp16 split product (common.hip.h): K = 480 = 15 k-steps of 32 = two u values x 16 channels each
     f32x4 acc[2][3];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 *bsrc = (const f32x4 *)(p.w4p + (((size_t)cg) * L4_UNITS + w * 48 + li) * 16) + lq;   // slab u adds u*16*192*16 floats
-    // B fragments stream from L2 with a prefetch distance of PF slabs (a slab of 24 MFMAs is only ~770
-    // cycles, shorter than an L2 round trip); the slab loop is fully unrolled so the ring is static
-    constexpr int PF = 4;
-    f32x4 bq[PF][3];
+    const f16x8 *bsrc = (const f16x8 *)p.w4s + ((size_t)cg * 15 * 12 + w * 3) * 2 * 64 + lane;   // + (ks*12 + nb)*2*64 + plane*64
+    // B fragments stream from L2 with a prefetch distance of PF k-steps; the loop is fully unrolled so the ring is static
+    constexpr int PF = 4, KS = 15;
+    f16x8 bq[PF][3][2];
 #pragma unroll
     for (int i = 0; i < PF - 1; ++i)
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) bq[i][nb] = bsrc[(size_t)i * (16 * L4_UNITS * 4) + nb * 64];
-#ifdef L34_SKIP_L4
-    if (p.n_pad < 0)
-#endif
+        for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-    for (int u = 0; u < L3_UNITS; ++u) {
-        if (u + PF - 1 < L3_UNITS) {
+            for (int pl = 0; pl < 2; ++pl) bq[i][nb][pl] = bsrc[((size_t)i * 12 + nb) * 128 + pl * 64];
 #pragma unroll
-            for (int nb = 0; nb < 3; ++nb) bq[(u + PF - 1) % PF][nb] = bsrc[(size_t)(u + PF - 1) * (16 * L4_UNITS * 4) + nb * 64];
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PF - 1 < KS) {
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bq[(ks + PF - 1) % PF][nb][pl] = bsrc[((size_t)(ks + PF - 1) * 12 + nb) * 128 + pl * 64];
         }
-        f32x4 a[2];
+        f16x8 a[2][2];   // [m-block][plane]: row li, k-chunk lq -> u = 2*ks + (lq>>1), channels 8*(lq&1) ..
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *(const f32x4 *)&l3s[mb * 16 + li][u * L34_U + lq * 4];
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int pl = 0; pl < 2; ++pl) a[mb][pl] = *(const f16x8 *)&l3h[pl][mb * 16 + li][(2 * ks + (lq >> 1)) * 16 + (lq & 1) * 8];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16(a[mb][j], bq[u % PF][nb][j], acc[mb][nb]);
+            for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16h(a[mb][1], bq[ks % PF][nb][0], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16h(a[mb][0], bq[ks % PF][nb][1], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16h(a[mb][0], bq[ks % PF][nb][0], acc[mb][nb]);
     }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)

@@ -63,9 +63,9 @@ struct clair_engine {
     // device weights
     float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
     float *wh1p = nullptr, *wh2p = nullptr, *wx1f = nullptr;
-    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr;   // fp16 split register images (lstm_split_kernel)
+    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr;   // fp16 split register images (lstm_split_kernel)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
-    float *w3f = nullptr, *b3 = nullptr, *w4p = nullptr, *b4 = nullptr;
+    float *w3f = nullptr, *b3 = nullptr, *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
     double ms_sum[CLAIR_K_COUNT] = {0};
     int64_t launches[CLAIR_K_COUNT] = {0};
@@ -284,7 +284,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
-        L3L4Args a{s.a2, e->w3f, e->b3, e->w4p, s.l4part, n_pad};
+        L3L4Args a{s.a2, e->w3f, e->b3, e->w4s, s.l4part, n_pad};
         hipLaunchKernelGGL(l3l4_kernel, dim3(n_pad / L34_CAND, L4_SPLITS), dim3(256), 0, s.stream, a);
     }
     {
@@ -359,9 +359,9 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3f, e->b3, e->w4p, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p, e->wx1f};
+    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3f, e->b3, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p, e->wx1f};
     for (float *p : w) (void)hipFree(p);
-    (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s);
+    (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s);
     delete e;
 }
 
@@ -381,7 +381,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3f, &e->b3, &e->w4p, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p, &e->wx1f};
+    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3f, &e->b3, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p, &e->wx1f};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(e->wx2s); e->wx2s = nullptr;
     auto &T = e->host_tensors;
@@ -423,11 +423,22 @@ int clair_finalize_weights(clair_engine_t *e) {
                     }
         if (upload(e, &e->w3f, w3f) || upload(e, &e->b3, T[9])) return 1;
     }
-    {   // W4p[slab][192][16]
-        std::vector<float> w4((size_t)L3_OUT * L4_UNITS);
-        for (int k = 0; k < L3_OUT; ++k)
-            for (int col = 0; col < L4_UNITS; ++col) w4[((size_t)(k / 16) * L4_UNITS + col) * 16 + (k % 16)] = T[10][(size_t)k * L4_UNITS + col];
-        if (upload(e, &e->w4p, w4) || upload(e, &e->b4, T[11])) return 1;
+    {   // W4 as fp16 split B fragments of the fused L3/L4 kernel (dense.hip.h): [cg][ks][nb][plane][lane][8]
+        std::vector<unsigned short> w4s((size_t)16 * 15 * 12 * 2 * 64 * 8);
+        for (int cg = 0; cg < 16; ++cg)
+            for (int ks = 0; ks < 15; ++ks)
+                for (int nb = 0; nb < 12; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int li = lane & 15, lq = lane >> 4;
+                            const int u = 2 * ks + (lq >> 1), ch = 8 * (lq & 1) + j;
+                            unsigned short hi, lo;
+                            split2_host(T[10][((size_t)u * 256 + cg * 16 + ch) * L4_UNITS + nb * 16 + li], hi, lo);
+                            const size_t base = (((((size_t)cg * 15 + ks) * 12 + nb) * 2) * 64 + lane) * 8 + j;
+                            w4s[base] = hi;
+                            w4s[base + 64 * 8] = lo;
+                        }
+        if (upload16(e, &e->w4s, w4s) || upload(e, &e->b4, T[11])) return 1;
     }
     {   // tail B fragments (dense.hip.h: tail_kernel)
         const int sizes[4] = {21, 3, 33, 33};
