@@ -13,7 +13,6 @@
 
 #include "common.hip.h"
 #include "dense.hip.h"
-#include "gemm.hip.h"
 #include "gemm_split.hip.h"
 #include "lstm.hip.h"
 
@@ -61,8 +60,7 @@ struct clair_engine {
     std::vector<Slot> slots;
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
-    float *wx1p = nullptr, *bx1 = nullptr, *wx2p = nullptr, *bx2 = nullptr;
-    float *wh1p = nullptr, *wh2p = nullptr, *wx1f = nullptr;
+    float *bx1 = nullptr, *bx2 = nullptr;   // gate-scaled biases [2][512] of the two layers
     unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr;   // fp16 split register images (lstm_split_kernel)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
     float *w3f = nullptr, *b3 = nullptr, *b4 = nullptr;
@@ -111,56 +109,6 @@ inline void split2_host(float x, unsigned short &hi, unsigned short &lo) {
 inline float gate_scale(int col512) {
     const float L2E = 1.44269504088896340736f;
     return ((col512 >> 7) == 1) ? 2.0f * L2E : -L2E;
-}
-
-// x-part of the two directions' LSTM kernels -> Bp[slab][1024][16]  (gemm.hip.h)
-std::vector<float> pack_wx(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
-    std::vector<float> out((size_t)D * 1024);
-    for (int k = 0; k < D; ++k)
-        for (int col = 0; col < 1024; ++col) {
-            const std::vector<float> &src = col < 512 ? fw : bw;
-            out[((size_t)(k / 16) * 1024 + col) * 16 + (k % 16)] = src[(size_t)k * 512 + (col & 511)] * gate_scale(col & 511);
-        }
-    return out;
-}
-
-// h-part -> [dir][wave][nb][k4][lane][j] = scale * W[D + lq*32 + k4*4 + j][g*128 + 32w + 16hh + li], nb = g*2 + hh
-// (lstm.hip.h: the register image of wave w)
-std::vector<float> pack_wh(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
-    std::vector<float> out((size_t)2 * 4 * 8 * 8 * 64 * 4);
-    size_t o = 0;
-    for (int d = 0; d < 2; ++d) {
-        const std::vector<float> &src = d ? bw : fw;
-        for (int w = 0; w < 4; ++w)
-            for (int nb = 0; nb < 8; ++nb)
-                for (int k4 = 0; k4 < 8; ++k4)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
-                            const int col = g * 128 + 32 * w + 16 * hh + li;
-                            out[o++] = src[(size_t)(D + lq * 32 + k4 * 4 + j) * 512 + col] * gate_scale(col);
-                        }
-    }
-    return out;
-}
-
-// x-part of LSTM1 for the fused kernel -> [dir][wave][nb][k4(2)][lane][j] = scale * W[lq*8 + k4*4 + j][col]
-std::vector<float> pack_wx_frag(const std::vector<float> &fw, const std::vector<float> &bw) {
-    std::vector<float> out((size_t)2 * 4 * 8 * 2 * 64 * 4);
-    size_t o = 0;
-    for (int d = 0; d < 2; ++d) {
-        const std::vector<float> &src = d ? bw : fw;
-        for (int w = 0; w < 4; ++w)
-            for (int nb = 0; nb < 8; ++nb)
-                for (int k4 = 0; k4 < 2; ++k4)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
-                            const int col = g * 128 + 32 * w + 16 * hh + li;
-                            out[o++] = src[(size_t)(lq * 8 + k4 * 4 + j) * 512 + col] * gate_scale(col);
-                        }
-    }
-    return out;
 }
 
 // fp16 2-way split register images for the split recurrent kernels (lstm.hip.h: lstm_split_kernel)
@@ -359,7 +307,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->wx1p, e->bx1, e->wx2p, e->bx2, e->w3f, e->b3, e->b4, e->w5f, e->b5, e->whf, e->bhf, e->wh1p, e->wh2p, e->wx1f};
+    float *w[] = {e->bx1, e->bx2, e->w3f, e->b3, e->b4, e->w5f, e->b5, e->whf, e->bhf};
     for (float *p : w) (void)hipFree(p);
     (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s);
     delete e;
@@ -381,7 +329,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->wx1p, &e->bx1, &e->wx2p, &e->bx2, &e->w3f, &e->b3, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf, &e->wh1p, &e->wh2p, &e->wx1f};
+    float **dev[] = {&e->bx1, &e->bx2, &e->w3f, &e->b3, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(e->wx2s); e->wx2s = nullptr;
     auto &T = e->host_tensors;
@@ -389,7 +337,6 @@ int clair_finalize_weights(clair_engine_t *e) {
         std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end());
         for (size_t i = 0; i < r.size(); ++i) r[i] *= gate_scale((int)(i & 511));
         return r; };
-    if (upload(e, &e->wx1p, pack_wx(T[0], T[2], F_IN))) return 1;
     if (upload(e, &e->bx1, cat(T[1], T[3]))) return 1;
     {   // Wx2 (gate-scaled) as two fp16 planes, [kstep][plane][col][32]  (gemm_split.hip.h)
         std::vector<unsigned short> w2s((size_t)8 * 2 * 1024 * 32);
@@ -408,9 +355,6 @@ int clair_finalize_weights(clair_engine_t *e) {
     if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
     if (upload16(e, &e->wh1s, pack_wh_split(T[0], T[2], F_IN)) || upload16(e, &e->wh2s, pack_wh_split(T[4], T[6], 2 * HID)) ||
         upload16(e, &e->wx1s, pack_wx_split(T[0], T[2]))) return 1;
-    if (upload(e, &e->wh1p, pack_wh(T[0], T[2], F_IN))) return 1;
-    if (upload(e, &e->wx1f, pack_wx_frag(T[0], T[2]))) return 1;
-    if (upload(e, &e->wh2p, pack_wh(T[4], T[6], 2 * HID))) return 1;
     {   // L3 B fragments (dense.hip.h: l3l4_kernel): w3f[c][lane][kk*2 + nbk] = W3[c][t = lq*9 + kk][u = nbk*16 + li]
         std::vector<float> w3f((size_t)256 * 64 * 20, 0.0f);
         for (int c = 0; c < 256; ++c)

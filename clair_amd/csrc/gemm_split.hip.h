@@ -9,9 +9,18 @@
 // (16 accumulator blocks), K in steps of 32 through LDS.
 #pragma once
 #include "common.hip.h"
-#include "gemm.hip.h"
 
 namespace clair {
+
+// Fragment-major address of the 16x16 block (row-block rb = t*ntiles+tile, column block cb):
+// zx[d][t][tile][w][nb][lane][4] with column cb*16 = d*512 + g*128 + w*32 + hh*16, nb = g*2+hh.
+__device__ __forceinline__ size_t zx_block_offset(int rb, int cb, int ntiles) {
+    int t = rb / ntiles, tile = rb - t * ntiles;
+    int d = cb >> 5, rem = cb & 31;
+    int g = rem >> 3, w = (rem >> 1) & 3, hh = rem & 1;
+    return ((((size_t)(d * T_POS + t) * ntiles + tile) * 4 + w) * 8 + (g * 2 + hh)) * 256;
+}
+
 
 typedef unsigned short f16bits_t;   // raw fp16 storage
 
@@ -19,7 +28,7 @@ struct GemmSplitArgs {
     const f16bits_t *A3;    // [2][33*n_pad][256]  fp16 planes of a1 (rows in (t, n) order)
     const f16bits_t *B3;    // [8 ksteps][2 planes][1024 cols][32 k]  fp16 planes of gate-scaled Wx2
     const float *bias;   // [1024] gate-scaled
-    float *C;            // fragment-major zx (gemm.hip.h: zx_block_offset)
+    float *C;            // fragment-major zx (zx_block_offset)
     int n_pad;
     int ntiles;
     int m_rows;          // 33 * n_pad
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
         }
     }
 
-    // epilogue: bias, fragment-major store (identical to gemm_f32_kernel's projection mode)
+    // epilogue: bias, fragment-major store: each accumulator block is one contiguous 1 KiB piece
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int rblk = (row0 >> 4) + wm * 4 + mi;

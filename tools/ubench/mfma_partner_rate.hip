@@ -4,8 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int KIND, int PRIO>
+template <int KIND, int PRIO, int F16>
 __global__ __launch_bounds__(512) void k2(float *out, float *gbuf, int iters, long long *res) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
     __shared__ volatile int flag;
@@ -20,8 +21,15 @@ __global__ __launch_bounds__(512) void k2(float *out, float *gbuf, int iters, lo
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0, 0, 0, 0};
         long long t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
+            if (F16) {
+                f16x8 ah, bh;
+                for (int i = 0; i < 8; ++i) { ah[i] = (_Float16)(a + i); bh[i] = (_Float16)(b - i); }
 #pragma unroll
-            for (int k = 0; k < 128; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k & 3], 0, 0, 0);
+                for (int k = 0; k < 128; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[k & 3], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 128; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k & 3], 0, 0, 0);
+            }
         }
         long long t1 = __builtin_readcyclecounter();
         for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -61,12 +69,12 @@ __global__ __launch_bounds__(512) void k2(float *out, float *gbuf, int iters, lo
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int KIND, int PRIO>
+template <int KIND, int PRIO, int F16>
 void run(const char *name) {
     float *out, *gbuf; long long *res;
     (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&gbuf, 1 << 20); (void)hipMalloc(&res, 256 * 16 * 8);
     const int iters = 200;
-    hipLaunchKernelGGL((k2<KIND, PRIO>), dim3(256), dim3(512), 0, 0, out, gbuf, iters, res);
+    hipLaunchKernelGGL((k2<KIND, PRIO, F16>), dim3(256), dim3(512), 0, 0, out, gbuf, iters, res);
     (void)hipDeviceSynchronize();
     long long c[16]; (void)hipMemcpy(c, res, 128, hipMemcpyDeviceToHost);
     printf("%-28s MFMA wave %6.1f cycles/MFMA | partner retired %.2f instr per MFMA (%.1f cycles each)\n", name,
@@ -74,12 +82,11 @@ void run(const char *name) {
     (void)hipFree(out); (void)hipFree(gbuf); (void)hipFree(res);
 }
 int main() {
-    run<0, 0>("partner v_fma_f32 prio0");
-    run<0, 1>("partner v_fma_f32 prio1");
-    run<0, 3>("partner v_fma_f32 prio3");
-    run<1, 3>("partner v_exp_f32 prio3");
-    run<2, 3>("partner s_mul_i32 prio3");
-    run<3, 3>("partner ds_read_b32(+add) prio3");
-    run<4, 3>("partner ds_write_b32 prio3");
+    run<0, 0, 0>("fp32 MFMA | partner v_fma");
+    run<0, 0, 1>("f16 MFMA  | partner v_fma");
+    run<1, 0, 1>("f16 MFMA  | partner v_exp");
+    run<3, 0, 1>("f16 MFMA  | partner ds_read(+add)");
+    run<4, 0, 1>("f16 MFMA  | partner ds_write");
+    run<0, 3, 1>("f16 MFMA  | partner v_fma prio3");
     return 0;
 }
