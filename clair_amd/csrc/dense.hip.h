@@ -36,8 +36,13 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const int n0 = blockIdx.x * L34_CAND;
-    const int cg = blockIdx.y;                 // channels cg*16 .. cg*16+15; this wave: 4 of them, cg*16 + 4w ..
+    // XCD-aware order (workgroups go round-robin over the 8 XCDs by linear id): XCD x owns channel groups 2x and
+    // 2x+1 for every candidate block, so (a) the two 64-byte halves of each 128-byte a2 line are fetched by
+    // neighbouring workgroups of ONE L2, and (b) each L2 holds only its own 1/8 of the W4 fragments (740 KB)
+    // instead of every L2 streaming all 5.9 MB.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int n0 = (seq >> 1) * L34_CAND;
+    const int cg = xcd * 2 + (seq & 1);        // channels cg*16 .. cg*16+15; this wave: 4 of them, cg*16 + 4w ..
 
     // ---- L3 for this wave's four channels --------------------------------------------------------------
     f32x4 acc3[4][2][2];   // [channel][m-block][u-block]

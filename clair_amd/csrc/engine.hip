@@ -222,8 +222,9 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
         GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows};
-        dim3 grid((m_rows + 127) / 128, 8, 1);
-        hipLaunchKernelGGL(gemm_split_kernel, grid, dim3(256), 0, s.stream, a);
+        const int row_tiles = (m_rows + 127) / 128;
+        dim3 grid(((row_tiles + 7) / 8) * 64, 1, 1);   // 8 XCDs x 8 column tiles x ceil(row_tiles / 8), see the kernel
+        hipLaunchKernelGGL(gemm_split_kernel<0>, grid, dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
@@ -233,7 +234,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
         L3L4Args a{s.a2, e->w3f, e->b3, e->w4s, s.l4part, n_pad};
-        hipLaunchKernelGGL(l3l4_kernel, dim3(n_pad / L34_CAND, L4_SPLITS), dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL(l3l4_kernel, dim3((n_pad / L34_CAND) * L4_SPLITS), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);

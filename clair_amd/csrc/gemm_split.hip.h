@@ -39,6 +39,10 @@ struct GemmSplitArgs {
 // k-chunk spreads over all banks (unswizzled: 4-way conflict, row pitch = 16 dwords).
 __device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3); }   // in fp16 units
 
+// PROBE != 0 only in tools/ubench/gemm_split_probe.hip: 1 = no zx store, 2 = no MFMAs, 3 = no global loads after the
+// first, 4 = per-workgroup phase timestamps
+__device__ long long *gemm_probe_stamps;
+template <int PROBE = 0>
 __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
     __shared__ __attribute__((aligned(16))) f16bits_t As[2][128 * 32];
     __shared__ __attribute__((aligned(16))) f16bits_t Bs[2][128 * 32];
@@ -48,8 +52,18 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 15, lq = lane >> 4;
-    const int row0 = blockIdx.x * 128;
-    const int col0 = blockIdx.y * 128;
+    // XCD-aware tile order.  Workgroups go round-robin over the 8 XCDs (one L2 each) by linear id, so the
+    // eight column tiles that share one 128-row A tile are given ids with the same id & 7 and consecutive
+    // id >> 3: they run back to back on ONE XCD and the A tile crosses the fabric once instead of up to eight
+    // times (PMC FETCH_SIZE of the (x = rows, y = cols) grid was 5x the A + B bytes, profiles/r01_pmc_hbm_traffic.txt).
+    const int wg = blockIdx.x;
+    long long stamp[4];
+    if (PROBE == 4) stamp[0] = __builtin_readcyclecounter();
+    const int xcd = wg & 7, seq = wg >> 3;
+    const int row_tile = (seq >> 3) * 8 + xcd;
+    if (row_tile * 128 >= p.m_rows) return;
+    const int row0 = row_tile * 128;
+    const int col0 = (seq & 7) * 128;
 
     // staging map: chunk id f = tid + 256*h (h = 0,1) of a plane tile: row f>>2, 16-byte chunk f&3
     const f16bits_t *asrc[2];
@@ -93,7 +107,8 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
                 *(f32x4 *)&Bs[pl][lds_dst[h]] = rb[pl][h];   // B tile: "row" = column index inside the tile
             }
         __syncthreads();
-        if (ks + 1 < KSTEPS) gload(ks + 1);
+        if (PROBE == 4 && ks == 0) stamp[1] = __builtin_readcyclecounter();
+        if (ks + 1 < KSTEPS && PROBE != 3) gload(ks + 1);
         // A fragments of this wave's four 16-row blocks, both planes: lane (li, lq) = row li, k-chunk lq
         f16x8 af[2][4];
 #pragma unroll
@@ -109,6 +124,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
             // never wait on each other's accumulator
 #define SPLIT_TERM(PA, PB)                                                    \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma16h(af[PA][mi], bfr[PB], acc[mi][ni]);
+            if (PROBE == 2) {
+                acc[ni][0] += (f32x4){(float)af[0][ni][0], (float)bfr[0][1], (float)af[1][ni][2], (float)bfr[1][3]};
+                continue;
+            }
             SPLIT_TERM(1, 0)
             SPLIT_TERM(0, 1)
             SPLIT_TERM(0, 0)
@@ -116,6 +135,10 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
         }
     }
 
+    if (PROBE == 4) {
+        asm volatile("" : "+v"(acc[3][3]));
+        stamp[2] = __builtin_readcyclecounter();
+    }
     // epilogue: bias, fragment-major store: each accumulator block is one contiguous 1 KiB piece
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -127,7 +150,17 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
             const float bv = p.bias[cblk * 16 + li];
             f32x4 v = acc[mi][ni];
             v += (f32x4){bv, bv, bv, bv};
+            if (PROBE == 1 && v[0] != 12345.678f) continue;
             *(f32x4 *)(p.C + zx_block_offset(rblk, cblk, p.ntiles) + lane * 4) = v;
+        }
+    }
+    if (PROBE == 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[3] = __builtin_readcyclecounter();
+        if (tid == 0) {
+            for (int i = 0; i < 4; ++i) gemm_probe_stamps[(size_t)wg * 6 + i] = stamp[i];
+            gemm_probe_stamps[(size_t)wg * 6 + 4] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+            gemm_probe_stamps[(size_t)wg * 6 + 5] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11));
         }
     }
 }
