@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclair_amd.so")
+LIB_PATH = os.environ.get("CLAIR_AMD_LIB") or os.path.join(_HERE, "libclair_amd.so")   # override: debugging builds only
 
 # every symbol include/clair_amd.h declares (tests/test_abi.py checks header <-> this list <-> .so)
 SYMBOLS = (

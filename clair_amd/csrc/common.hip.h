@@ -53,6 +53,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)x;
+    // ONE definition of hi.  Under hipcc's default -ffp-contract=fast the compiler may otherwise materialise hi twice --
+    // once as v_cvt_f16_f32 of the rounded fp32 value, once fused with the producing multiply (v_fma_mixlo_f16, single
+    // rounding) -- and the two disagree by one fp16 ulp about once in 30 000 values: the stored hi plane and the
+    // residual then belong to different splits (found as 1e-5 instead of 2e-6 error on L4, tools/debug_taps.py).
+    asm("" : "+v"(hi));
     lo = (_Float16)(x - (float)hi);
 }
 

@@ -25,6 +25,7 @@ struct L3L4Args {
                                  // u = 2*ks + (lq>>1), ch = 8*(lq&1) + j; column nb*16 + li
     float *part;        // [16][n_pad][192]
     int n_pad;
+    float *dbg;         // parity tap (NULL in production): l3 as this kernel holds it, hi + lo, [n_pad][7680]
 };
 
 __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
@@ -120,6 +121,12 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
         }
     }
     __syncthreads();
+    if (p.dbg) {   // debug tap: this workgroup's 32 x (30 u x 16 channels) slice of l3
+        for (int f = tid; f < L34_CAND * 480; f += 256) {
+            const int row = f / 480, k = f - row * 480, u = k >> 4, ch = k & 15;
+            p.dbg[(size_t)(n0 + row) * L3_OUT + u * 256 + cg * 16 + ch] = (float)l3h[0][row][k] + (float)l3h[1][row][k];
+        }
+    }
 
     // ---- L4 over this K-slice: wave w owns output columns 48w .. 48w+47 (3 blocks), both 16-row blocks ----------
     // 2-way fp16 split product (common.hip.h): K = 480 = 15 k-steps of 32 = two u values x 16 channels each

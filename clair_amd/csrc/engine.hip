@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,7 +15,7 @@
 #include "common.hip.h"
 #include "dense.hip.h"
 #include "gemm_split.hip.h"
-#include "lstm.hip.h"
+#include "lstm32.hip.h"
 
 using namespace clair;
 
@@ -56,6 +57,7 @@ struct clair_engine {
     int max_pad = 0;
     bool weights_ready = false;
     bool timing = false;
+    bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<Slot> slots;
     std::vector<float> host_tensors[CLAIR_T_COUNT];
@@ -111,46 +113,44 @@ inline float gate_scale(int col512) {
     return ((col512 >> 7) == 1) ? 2.0f * L2E : -L2E;
 }
 
-// fp16 2-way split register images for the split recurrent kernels (lstm.hip.h: lstm_split_kernel)
-// h-part: [dir][wave][nb][kstep][plane][lane][8]: W[D + 32*ks + 8*lq + j][col(nb, li)] * gate_scale
-std::vector<unsigned short> pack_wh_split(const std::vector<float> &fw, const std::vector<float> &bw, int D) {
-    std::vector<unsigned short> out((size_t)2 * 4 * 8 * 4 * 2 * 64 * 8);
+// Gate-row order of the recurrent kernels (lstm32.hip.h): row rho = 8a + 4h' + c of block b of wave w is
+// gate c (i | c~ | f | o) of hidden unit 32w + 8b + 4h' + a, i.e. column c*128 + unit of the reference's [K][512] kernel.
+inline int gate_col(int w, int b, int rho) {
+    const int a = rho >> 3, hq = (rho >> 2) & 1, c = rho & 3;
+    return c * 128 + 32 * w + 8 * b + 4 * hq + a;
+}
+
+// fp16 2-way split A fragments of W^T for v_mfma_f32_32x32x16_f16: [dir][wave][b][kk][plane][lane][8]:
+// W[k0 + 16*kk + 8*(lane/32) + j][gate_col(w, b, lane%32)] * gate_scale, kk < nkk
+std::vector<unsigned short> pack_wt32(const std::vector<float> &fw, const std::vector<float> &bw, int k0, int nkk) {
+    std::vector<unsigned short> out((size_t)2 * 4 * 4 * nkk * 2 * 64 * 8);
     for (int d = 0; d < 2; ++d) {
         const std::vector<float> &src = d ? bw : fw;
         for (int w = 0; w < 4; ++w)
-            for (int nb = 0; nb < 8; ++nb)
-                for (int ks = 0; ks < 4; ++ks)
+            for (int b = 0; b < 4; ++b)
+                for (int kk = 0; kk < nkk; ++kk)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
-                            const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
-                            const int col = g * 128 + 32 * w + 16 * hh + li, k = 32 * ks + 8 * lq + j;
+                            const int col = gate_col(w, b, lane & 31), k = k0 + 16 * kk + 8 * (lane >> 5) + j;
                             unsigned short hi, lo;
-                            split2_host(src[(size_t)(D + k) * 512 + col] * gate_scale(col), hi, lo);
-                            const size_t base = (((((size_t)(d * 4 + w) * 8 + nb) * 4 + ks) * 2) * 64 + lane) * 8 + j;
+                            split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
+                            const size_t base = (((((size_t)(d * 4 + w) * 4 + b) * nkk + kk) * 2) * 64 + lane) * 8 + j;
                             out[base] = hi;
                             out[base + 64 * 8] = lo;
                         }
     }
     return out;
 }
-// x-part of LSTM1: [dir][wave][nb][plane][lane][8]: W[8*lq + j][col(nb, li)] * gate_scale
-std::vector<unsigned short> pack_wx_split(const std::vector<float> &fw, const std::vector<float> &bw) {
-    std::vector<unsigned short> out((size_t)2 * 4 * 8 * 2 * 64 * 8);
-    for (int d = 0; d < 2; ++d) {
-        const std::vector<float> &src = d ? bw : fw;
+// gate-scaled bias of both directions in gate-row order: [dir][wave][b][rho]  (= [..][a][h'][c] accumulator quads)
+std::vector<float> pack_bias32(const std::vector<float> &fb, const std::vector<float> &bb) {
+    std::vector<float> out(1024);
+    for (int d = 0; d < 2; ++d)
         for (int w = 0; w < 4; ++w)
-            for (int nb = 0; nb < 8; ++nb)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int li = lane & 15, lq = lane >> 4, g = nb >> 1, hh = nb & 1;
-                        const int col = g * 128 + 32 * w + 16 * hh + li, k = 8 * lq + j;
-                        unsigned short hi, lo;
-                        split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
-                        const size_t base = ((((size_t)(d * 4 + w) * 8 + nb) * 2) * 64 + lane) * 8 + j;
-                        out[base] = hi;
-                        out[base + 64 * 8] = lo;
-                    }
-    }
+            for (int b = 0; b < 4; ++b)
+                for (int rho = 0; rho < 32; ++rho) {
+                    const int col = gate_col(w, b, rho);
+                    out[((d * 4 + w) * 4 + b) * 32 + rho] = (d ? bb : fb)[col] * gate_scale(col);
+                }
     return out;
 }
 int upload16(clair_engine *e, unsigned short **dst, const std::vector<unsigned short> &src) {
@@ -211,29 +211,29 @@ int drain_timers(clair_engine *e) {
 // zero or any finite value) writing packed outputs to out_dev ([n][90]).
 int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
     const int n_pad = (n + 31) & ~31;
-    const int ntiles = n_pad / 16;
+    const int ntiles = n_pad / L32_TILE;
     const int m_rows = T_POS * n_pad;
     s.last_n_pad = n_pad;
     {   // LSTM1 with its input projection fused in (no separate GEMM, no zx round trip), fp16 split products
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        LstmSplitArgs a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles};
-        hipLaunchKernelGGL((lstm_split_kernel<true>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        Lstm32Args a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm32_kernel<true>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
         GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows};
-        const int row_tiles = (m_rows + 127) / 128;
-        dim3 grid(((row_tiles + 7) / 8) * 64, 1, 1);   // 8 XCDs x 8 column tiles x ceil(row_tiles / 8), see the kernel
+        const int x_tiles = (m_rows + 127) / 128;
+        dim3 grid(((x_tiles + 7) / 8) * 64, 1, 1);   // 8 XCDs x 8 gate-row tiles x ceil(x_tiles / 8), see the kernel
         hipLaunchKernelGGL(gemm_split_kernel<0>, grid, dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        LstmSplitArgs a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles};
-        hipLaunchKernelGGL((lstm_split_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles};
+        hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
-        L3L4Args a{s.a2, e->w3f, e->b3, e->w4s, s.l4part, n_pad};
+        L3L4Args a{s.a2, e->w3f, e->b3, e->w4s, s.l4part, n_pad, e->tap_l3 ? s.zx : nullptr};   // zx is dead by now
         hipLaunchKernelGGL(l3l4_kernel, dim3((n_pad / L34_CAND) * L4_SPLITS), dim3(256), 0, s.stream, a);
     }
     {
@@ -282,6 +282,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     e->device = device;
     e->max_batch = max_batch;
     e->max_pad = (max_batch + 31) & ~31;
+    { const char *t = getenv("CLAIR_AMD_TAP_L3"); e->tap_l3 = t && t[0] == '1'; }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
     for (auto &s : e->slots) {
@@ -332,30 +333,24 @@ int clair_finalize_weights(clair_engine_t *e) {
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
     float **dev[] = {&e->bx1, &e->bx2, &e->w3f, &e->b3, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
-    (void)hipFree(e->wx2s); e->wx2s = nullptr;
     auto &T = e->host_tensors;
-    auto cat = [](const std::vector<float> &a, const std::vector<float> &b) {   // both directions' biases, gate-scaled
-        std::vector<float> r(a); r.insert(r.end(), b.begin(), b.end());
-        for (size_t i = 0; i < r.size(); ++i) r[i] *= gate_scale((int)(i & 511));
-        return r; };
-    if (upload(e, &e->bx1, cat(T[1], T[3]))) return 1;
-    {   // Wx2 (gate-scaled) as two fp16 planes, [kstep][plane][col][32]  (gemm_split.hip.h)
+    if (upload(e, &e->bx1, pack_bias32(T[1], T[3])) || upload(e, &e->bx2, pack_bias32(T[5], T[7]))) return 1;
+    {   // Wx2^T (gate-scaled, gate-row order) as two fp16 planes, [kstep][plane][gate row][32]  (gemm_split.hip.h)
         std::vector<unsigned short> w2s((size_t)8 * 2 * 1024 * 32);
-        for (int k = 0; k < 2 * HID; ++k)
-            for (int col = 0; col < 1024; ++col) {
-                const std::vector<float> &src = col < 512 ? T[4] : T[6];
-                const float v = src[(size_t)k * 512 + (col & 511)] * gate_scale(col & 511);
+        for (int R = 0; R < 1024; ++R) {
+            const int d = R >> 9, col = gate_col((R >> 7) & 3, (R >> 5) & 3, R & 31);
+            const std::vector<float> &src = d ? T[6] : T[4];
+            for (int k = 0; k < 2 * HID; ++k) {
                 unsigned short hi, lo;
-                split2_host(v, hi, lo);
-                w2s[(((size_t)(k / 32) * 2 + 0) * 1024 + col) * 32 + (k % 32)] = hi;
-                w2s[(((size_t)(k / 32) * 2 + 1) * 1024 + col) * 32 + (k % 32)] = lo;
+                split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
+                w2s[(((size_t)(k / 32) * 2 + 0) * 1024 + R) * 32 + (k % 32)] = hi;
+                w2s[(((size_t)(k / 32) * 2 + 1) * 1024 + R) * 32 + (k % 32)] = lo;
             }
-        HIP_TRY(e, hipMalloc((void **)&e->wx2s, w2s.size() * sizeof(unsigned short)));
-        HIP_TRY(e, hipMemcpy(e->wx2s, w2s.data(), w2s.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
+        if (upload16(e, &e->wx2s, w2s)) return 1;
     }
-    if (upload(e, &e->bx2, cat(T[5], T[7]))) return 1;
-    if (upload16(e, &e->wh1s, pack_wh_split(T[0], T[2], F_IN)) || upload16(e, &e->wh2s, pack_wh_split(T[4], T[6], 2 * HID)) ||
-        upload16(e, &e->wx1s, pack_wx_split(T[0], T[2]))) return 1;
+    if (upload16(e, &e->wh1s, pack_wt32(T[0], T[2], F_IN, 8)) || upload16(e, &e->wh2s, pack_wt32(T[4], T[6], 2 * HID, 8)) ||
+        upload16(e, &e->wx1s, pack_wt32(T[0], T[2], 0, 2))) return 1;
     {   // L3 B fragments (dense.hip.h: l3l4_kernel): w3f[c][lane][kk*2 + nbk] = W3[c][t = lq*9 + kk][u = nbk*16 + li]
         std::vector<float> w3f((size_t)256 * 64 * 20, 0.0f);
         for (int c = 0; c < 256; ++c)
@@ -548,6 +543,9 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
     }
     switch (which) {
         case 2: src = s.a2; avail = (int64_t)T_POS * np * 256; break;
+        case 4: if (!e->tap_l3) return fail(e, "clair_debug_read: tap 4 needs CLAIR_AMD_TAP_L3=1 at engine creation");
+                src = s.zx; avail = np * L3_OUT; break;
+        case 3: src = s.l4part; avail = (int64_t)L4_SPLITS * np * L4_UNITS; break;   // split-K partials of the 7680->192 product
         default: return fail(e, "clair_debug_read: unknown tap %d", which);
     }
     if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);

@@ -1,0 +1,414 @@
+// The two BiLSTM layers (both directions each), recurrence kept on chip for all 33 steps.
+//
+// Reference semantics: CudnnCompatibleLSTMCell(128) under stack_bidirectional_dynamic_rnn
+// (clair/model.py:299-312, 423-451): per step z = [x_t, h_{t-1}].W + b, gates (i, c~, f, o),
+// c_t = sig(f) c_{t-1} + sig(i) tanh(c~), h_t = sig(o) tanh(c_t); the backward direction walks
+// t = 32..0; zero initial state.
+//
+// Mapping to the CU.  One 256-thread workgroup (one wave per SIMD) owns one 32-candidate tile of one
+// direction for all 33 steps.  Wh of a direction (128 x 512; 256 KiB as two fp16 planes) is larger than the
+// 160 KiB LDS, so it lives in REGISTERS: wave w holds the slice for hidden units 32w..32w+31 of all four
+// gates -- in the 256 accumulation VGPRs, which hold nothing else; all working state is in the 256
+// architectural VGPRs.  c_t never leaves registers; h_t is exchanged between the four waves through a
+// double-buffered LDS tile, one barrier per step.
+//
+// Products run as the 2-way fp16 split of common.hip.h  (a*b ~= a1*b1 + a1*b2 + a2*b1)  on
+// v_mfma_f32_32x32x16_f16 with the WEIGHTS as the A operand (rows = gate rows) and the activations as B
+// (columns = candidates), i.e. the transposed product z^T = W^T h^T.  Measured facts that shape the kernel
+// (tools/ubench/mfma_filler.hip, mfma_regfile.hip, lstm32_probe.hip; profiles/r01_microbench.txt):
+//   * a wave hides about four VALU/transcendental instructions (at most three transcendental) in the
+//     32-cycle shadow of every v_mfma_f32_32x32x16_f16 it issues -- the 16x16x32 form hides 1-2 in 17 cycles,
+//     the fp32 MFMA none -- provided none of them waits on a result younger than the previous MFMA;
+//   * a single dependent accumulator chain of that MFMA still issues every 32 cycles, wherever A, B and the
+//     accumulator live (VGPR or AGPR);
+//   * an LDS-DMA piece costs 100+ issue cycles inside such a stream, a plain global_load_dwordx4 does not.
+// So the 128 gate rows of a wave are cut into four blocks of 32 rows = 8 hidden units x 4 gates, ordered so
+// that one lane's 16 accumulator registers of a block are the four gates of four units of ONE candidate
+// (row 8a + 4h' + c: element a = reg/4, gate c = reg%4, h' = lane/32, unit 8b + 4h' + a).  The gate
+// non-linearities of block b-1 (about 100 VALU instructions per lane) are threaded by hand through the 24
+// MFMAs of block b as a static schedule (L32_GAP below): three blocks out of four cost no time.
+//
+//   * h lives in LDS as its two fp16 planes (the gate code splits it once); layer 1 copies those planes to
+//     HBM unchanged -- they are the B operand of the LSTM2 projection GEMM (gemm_split.hip.h) -- layer 2 hands
+//     the fp32 sum p1 + p2, exactly the h its own recurrence used, to the L3/L4 kernel.  Copy-out happens
+//     from LDS as whole rows inside the MFMA stream of the NEXT step's first block.
+//   * layer 1 computes its input projection itself (K = 32: two k-steps of 16; x_t read straight from the
+//     caller's [n][33][32] tensor one step ahead, split on the fly; Wx1 fragments and bias quads in LDS).
+//   * layer 2 gets its x-projection (written by gemm_split.hip.h in exactly this kernel's accumulator
+//     layout, bias included) straight into registers one whole step ahead: the 16 values of a block are the
+//     C operand of that block's first MFMA.
+//
+// Gate pre-scaling: the host multiplies every gate row of Wx, Wh and the bias by the constant its
+// activation needs in front of v_exp_f32 (2^x): -log2(e) for the sigmoid gates i, f, o and 2*log2(e) for the
+// tanh gate c~ (engine.hip: gate_scale), and the cell state is carried as c' = 2*log2(e)*c.
+#pragma once
+#include "common.hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace clair {
+
+#ifndef L32_PROBE_GATES
+#define L32_PROBE_GATES 1   // 0 only in tools/ubench/lstm32_probe.hip variants: hidden gate math left out
+#endif
+#ifndef L32_PROBE_ZQ
+#define L32_PROBE_ZQ 1
+#endif
+#ifndef L32_PROBE_COPY
+#define L32_PROBE_COPY 1
+#endif
+#ifdef L32_PROBE   // tools/ubench/lstm32_probe.hip only: s_memtime stamps of workgroup 0, wave 0
+__device__ long long *l32_stamps;   // [33 steps][16]
+#define L32_STAMP(i) if (blockIdx.x == 0 && tid == 0) l32_stamps[s * 16 + (i)] = __builtin_readcyclecounter();
+#else
+#define L32_STAMP(i)
+#endif
+
+constexpr int L32_TILE = 32;      // candidates per workgroup
+constexpr int HP_ROW = HID + 8;   // fp16 units per LDS row of one h plane: 272 B, conflict-free ds_read_b128 over 32 rows
+constexpr int L32_HBUF_BYTES = 2 * 2 * L32_TILE * HP_ROW * 2;                 // 34 816
+constexpr int L32_LDS_FIRST = L32_HBUF_BYTES + 4 * 4 * 2 * 2 * 64 * 16 + 4 * 4 * 4 * 2 * 16;   // + Wx1 fragments (64 KiB) + bias quads (2 KiB)
+constexpr int L32_LDS_SECOND = L32_HBUF_BYTES;
+
+struct Lstm32Args {
+    const float *x;             // FIRST: [n_pad][33][32] network input
+    const unsigned short *wxs;  // FIRST: [2 dir][4 wave][4 b][2 kk][2 plane][64 lane][8] fp16  A fragments of Wx1^T, gate-scaled
+    const float *biasq;         // FIRST: [2 dir][4 wave][4 b][4 a][2 h'][4 c]  gate-scaled bias as accumulator quads
+    const float *zx;            // !FIRST: [2 dir][n_pad/32][33][4 wave][4 b][4 a][64 lane][4 c]  x-projection, bias included;
+                                // tile-major: a workgroup streams one contiguous 2.1 MB piece (with t outermost every step
+                                // opened a new page for every CU: ~1100 cycles of translation latency per step, lstm32_probe)
+    const unsigned short *whs;  // [2 dir][4 wave][4 b][8 kk][2 plane][64 lane][8] fp16  A fragments of Wh^T, gate-scaled
+    unsigned short *aout2;      // FIRST: [2 plane][33][n_pad][256] fp16 planes of the layer output
+    float *aout;                // !FIRST: [33][n_pad][256] fp32
+    int n_pad;
+    int ntiles;                 // n_pad / 32
+};
+
+__device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
+    // v_mfma_f32_32x32x16_f16: lane (i = l%32, q = l/32) supplies A[i][8q..8q+7] / B[8q..8q+7][i];
+    // C/D: column l%32, rows 8*(reg/4) + 4*(l/32) + reg%4
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// The same MFMA as inline asm, accumulating in VGPRs, the resident weight operand pinned to the AGPR half of
+// the register file ("a").  hipcc pads no hazards around an asm statement (cdna_hip_programming.md 5.7):
+//   * A/B operands are never VALU-written right before (LDS loads; layer 1's converted features get an s_nop 1);
+//   * accumulator chains (D of one MFMA = C of the next) need no wait states;
+//   * the first reader of a finished accumulator is kept 12 wait states away by construction (see the step).
+__device__ __forceinline__ void mfma32_av(f32x16 &acc, const f16x8 &w, const f16x8 &b) {
+#ifndef L32_PROBE_NO_MFMA
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+#else
+    asm volatile("" : "+v"(acc) : "a"(w), "v"(b));
+#endif
+}
+__device__ __forceinline__ void mfma32_av_first(f32x16 &acc, const f16x8 &w, const f16x8 &b, const f32x16 &c) {   // D = A.B + C, D != C
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma32_vv(f32x16 &acc, const f16x8 &a, const f16x8 &b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_vv_first(f32x16 &acc, const f16x8 &a, const f16x8 &b, const f32x16 &c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+}
+
+constexpr float GATE_K2 = 2.0f * 1.44269504088896340736f;
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm32_kernel(Lstm32Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FIRST ? L32_LDS_FIRST : L32_LDS_SECOND];
+    _Float16 (*hbuf)[2][L32_TILE][HP_ROW] = (_Float16 (*)[2][L32_TILE][HP_ROW])lds_raw;   // [step parity][plane][cand][unit]
+    _Float16 *wxl = (_Float16 *)(lds_raw + L32_HBUF_BYTES);             // FIRST: [wave][b][kk][plane][lane][8]
+    float *bql = (float *)(lds_raw + L32_HBUF_BYTES + (FIRST ? 4 * 4 * 2 * 2 * 64 * 16 : 0));   // FIRST: [wave][b][a][h'][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cand = lane & 31, hq = lane >> 5;
+    const int d = blockIdx.x & 1;
+    const int tile = blockIdx.x >> 1;
+
+    // resident weights: Aw[b][kk][plane] = 8 fp16 of gate row (b, lane%32), k = 16*kk + 8*(lane/32) + j
+    f16x8 Aw[4][8][2];
+    {
+        const f16x8 *wp = (const f16x8 *)p.whs + (size_t)(d * 4 + w) * (4 * 8 * 2 * 64) + lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) Aw[b][kk][pl] = wp[((b * 8 + kk) * 2 + pl) * 64];
+        // asm-defined AGPR values (after ALL loads are in flight): hipcc can neither re-load them from memory inside
+        // the step loop (it does, given the chance) nor park them in architectural VGPRs
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+a"(Aw[b][kk][pl]));
+    }
+    if (FIRST) {   // this wave's Wx1 fragments and bias quads -> LDS (read back by this wave only)
+        const f32x4 *src = (const f32x4 *)p.wxs + (size_t)(d * 4 + w) * (4 * 2 * 2 * 64) + lane;
+        f32x4 *dst = (f32x4 *)wxl + (size_t)w * (4 * 2 * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i * 64] = src[i * 64];
+        if (lane < 32) ((f32x4 *)bql)[w * 32 + lane] = ((const f32x4 *)p.biasq)[(d * 4 + w) * 32 + lane];
+    }
+    float cst[4][4];   // c' = 2 log2(e) c of (block b, element a): unit 32w + 8b + 4h' + a of candidate lane%32
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cst[b][a] = 0.0f;
+
+    // ---- layer 1 input: this lane's 16 features (16*kk + 8*h' .. +7, kk = 0,1) of its candidate at step s
+    const float *xrow = FIRST ? p.x + ((size_t)tile * L32_TILE + cand) * (T_POS * F_IN) + hq * 8 : nullptr;
+    auto load_x = [&](f32x4 (&xf)[4], int s) {
+        const int t = d ? T_POS - 1 - s : s;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            xf[kk * 2 + 0] = *(const f32x4 *)(xrow + t * F_IN + kk * 16);
+            xf[kk * 2 + 1] = *(const f32x4 *)(xrow + t * F_IN + kk * 16 + 4);
+        }
+    };
+    // ---- accumulator seeds (the C operand of a block's first MFMA)
+    // layer 2: block b of step s of the x-projection, 4 x 16 bytes per lane; layer 1: the block's bias quads from LDS
+    const float *zx0 = FIRST ? nullptr : p.zx + ((((size_t)d * p.ntiles + tile) * T_POS * 4 + w) * 4) * 1024 + lane * 4;
+    auto load_seed = [&](f32x16 &z, int s, int b) {
+        if (FIRST) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = *(const f32x4 *)&bql[((w * 4 + b) * 4 + a) * 8 + hq * 4];
+                z[4 * a + 0] = v[0]; z[4 * a + 1] = v[1]; z[4 * a + 2] = v[2]; z[4 * a + 3] = v[3];
+            }
+        } else {
+            const int sc = s < T_POS ? s : T_POS - 1;   // the prefetch past the last step re-reads the last one
+#ifdef L32_PROBE_SAMEPAGE
+            const int t = 0 * sc;
+#else
+            const int t = d ? T_POS - 1 - sc : sc;
+#endif
+            const float *src = zx0 + ((size_t)t * 16 + b) * 1024;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = *(const f32x4 *)(src + a * 256);
+                z[4 * a + 0] = v[0]; z[4 * a + 1] = v[1]; z[4 * a + 2] = v[2]; z[4 * a + 3] = v[3];
+            }
+        }
+    };
+    // ---- h_s (both planes complete in LDS) -> HBM; thread: row tid>>3, 16-unit chunk tid&7; split into an LDS
+    //      read and two convert+store halves so that the pieces can sit in different MFMA shadows
+    f16x8 ch[2][2];   // [half][plane]
+    auto copy_read = [&](int s) {
+        const int row = tid >> 3, c16 = tid & 7;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) ch[half][pl] = *(const f16x8 *)&hbuf[s & 1][pl][row][c16 * 16 + half * 8];
+    };
+    auto copy_write = [&](int s, int half) {
+        const int t = d ? T_POS - 1 - s : s;
+        const int row = tid >> 3, c16 = tid & 7;
+        const size_t off = ((size_t)t * p.n_pad + (size_t)tile * L32_TILE + row) * (2 * HID) + d * HID + c16 * 16 + half * 8;
+        if (FIRST) {
+            const size_t plane = (size_t)T_POS * p.n_pad * (2 * HID);
+            *(f16x8 *)(p.aout2 + off) = ch[half][0];
+            *(f16x8 *)(p.aout2 + plane + off) = ch[half][1];
+        } else {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o0[j] = (float)ch[half][0][j] + (float)ch[half][1][j];
+                o1[j] = (float)ch[half][0][4 + j] + (float)ch[half][1][4 + j];
+            }
+            *(f32x4 *)(p.aout + off) = o0;
+            *(f32x4 *)(p.aout + off + 4) = o1;
+        }
+    };
+
+    f32x16 acc[2];        // block b accumulates in acc[b & 1]
+    f32x16 zq[FIRST ? 1 : 4];   // seeds: layer 2 [b] = block b of the next step it is needed in; layer 1 [0] = next block's bias
+    f32x4 xraw[4];        // layer 1: next step's raw features
+    f16x8 xh[2], xl[2];   // layer 1: this step's B fragments (k-step kk), hi / lo plane
+    f16x8 hf[8][2];       // B fragments of h_{s-1}: [kk][plane]
+
+    // h_{-1} = 0: step 0 runs the same code as every other step (its h-part MFMAs add zero)
+    for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) ((f32x4 *)&hbuf[1][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (FIRST) {
+        load_x(xraw, 0);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load_seed(zq[b], 0, b);
+    }
+    __syncthreads();   // zeros, Wx1 fragments and bias quads visible
+    if (FIRST) load_seed(zq[0], 0, 0);
+
+    // Gate math of one block (4 elements per lane), as a static schedule of 24 "gaps" of 3-5 instructions: gap G
+    // is issued right after MFMA G of the next block.  Within a gap all instructions are independent, every
+    // operand was produced at least one gap earlier (no dependency stalls for the in-order wave) and at most
+    // three are transcendental.
+    //   acc holds exp2 arguments (pre-scaled rows): 2^-i, 2^(2 g), 2^-f, 2^-o  ->  registers eg/ei/ef/eo are
+    //   reused as 1+e (A), its reciprocal (R) and k = K2 - 2 K2 rg (K); cell state c' = rf c' + ri k (T, C);
+    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HI, HF, D, LO).  Gap 24 packs the lane's four h
+    //   values into one 8-byte LDS store per plane.
+    // Placement control.  A sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that
+    // opens its gap; pinning its OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking
+    // below the MFMA that closes it.  (Pinning inputs as well costs an s_nop per op: hipcc pads every asm output
+    // that the next VALU touches.)
+#define L32_PIN(x) asm volatile("" : "+v"(x));
+#define L32_OP_E(R, C, e) { R[e] = __builtin_amdgcn_exp2f(Z[4 * (e) + (C)]); L32_PIN(R[e]) }
+#define L32_OP_A(R, e) { R[e] += 1.0f; L32_PIN(R[e]) }
+#define L32_OP_R(R, e) { R[e] = fast_rcp(R[e]); L32_PIN(R[e]) }
+#define L32_OP_K(e) { eg[e] = fmaf(eg[e], -2.0f * GATE_K2, GATE_K2); L32_PIN(eg[e]) }
+#define L32_OP_T(e) { tt[e] = ei[e] * eg[e]; L32_PIN(tt[e]) }
+#define L32_OP_C(e) { C_[e] = fmaf(ef[e], C_[e], tt[e]); L32_PIN(C_[e]) }
+#define L32_OP_M(e) { m2[e] = -2.0f * eo[e]; L32_PIN(m2[e]) }
+#define L32_OP_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); L32_PIN(ei[e]) }
+#define L32_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); L32_PIN(hh[e]) }
+#define L32_OP_HI(e) { hhi[e] = (_Float16)hh[e]; L32_PIN(hhi[e]) }
+#define L32_OP_HF(e) { tt[e] = (float)hhi[e]; L32_PIN(tt[e]) }
+#define L32_OP_D(e) { tt[e] = hh[e] - tt[e]; L32_PIN(tt[e]) }
+#define L32_OP_LO(e) { hlo[e] = (_Float16)tt[e]; L32_PIN(hlo[e]) }
+#define L32_GAP(G, PB)                                                                                            \
+    {                                                                                                             \
+        const f32x16 &Z = acc[(PB) & 1];                                                                          \
+        float (&C_)[4] = cst[PB];                                                                                 \
+        switch (G) {                                                                                              \
+            case 1: L32_OP_E(eg, 1, 0) L32_OP_E(eg, 1, 1) L32_OP_E(eg, 1, 2) break;                               \
+            case 2: L32_OP_E(eg, 1, 3) L32_OP_E(ei, 0, 0) L32_OP_E(ei, 0, 1) L32_OP_A(eg, 0) break;               \
+            case 3: L32_OP_E(ei, 0, 2) L32_OP_E(ei, 0, 3) L32_OP_A(eg, 1) L32_OP_A(eg, 2) break;                  \
+            case 4: L32_OP_E(ef, 2, 0) L32_OP_E(ef, 2, 1) L32_OP_A(eg, 3) L32_OP_A(ei, 0) break;                  \
+            case 5: L32_OP_E(ef, 2, 2) L32_OP_E(ef, 2, 3) L32_OP_A(ei, 1) L32_OP_A(ei, 2) break;                  \
+            case 6: L32_OP_E(eo, 3, 0) L32_OP_E(eo, 3, 1) L32_OP_R(eg, 0) L32_OP_A(ei, 3) break;                  \
+            case 7: L32_OP_E(eo, 3, 2) L32_OP_E(eo, 3, 3) L32_OP_R(eg, 1) L32_OP_A(ef, 0) break;                  \
+            case 8: L32_OP_R(eg, 2) L32_OP_R(eg, 3) L32_OP_A(ef, 1) L32_OP_A(ef, 2) break;                        \
+            case 9: L32_OP_R(ei, 0) L32_OP_R(ei, 1) L32_OP_A(ef, 3) L32_OP_A(eo, 0) break;                        \
+            case 10: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_A(eo, 1) L32_OP_A(eo, 2) break;                       \
+            case 11: L32_OP_R(ef, 0) L32_OP_R(ef, 1) L32_OP_A(eo, 3) L32_OP_K(0) break;                           \
+            case 12: L32_OP_R(ef, 2) L32_OP_R(ef, 3) L32_OP_K(1) L32_OP_K(2) break;                               \
+            case 13: L32_OP_R(eo, 0) L32_OP_R(eo, 1) L32_OP_K(3) L32_OP_T(0) break;                               \
+            case 14: L32_OP_R(eo, 2) L32_OP_R(eo, 3) L32_OP_T(1) L32_OP_T(2) break;                               \
+            case 15: L32_OP_T(3) L32_OP_C(0) L32_OP_C(1) L32_OP_M(0) L32_OP_M(1) break;                           \
+            case 16: L32_OP_C(2) L32_OP_C(3) L32_OP_X(0) L32_OP_X(1) L32_OP_M(2) break;                           \
+            case 17: L32_OP_X(2) L32_OP_X(3) L32_OP_A(ei, 0) L32_OP_A(ei, 1) L32_OP_M(3) break;                   \
+            case 18: L32_OP_A(ei, 2) L32_OP_A(ei, 3) L32_OP_R(ei, 0) L32_OP_R(ei, 1) break;                       \
+            case 19: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_H(0) L32_OP_H(1) break;                               \
+            case 20: L32_OP_H(2) L32_OP_H(3) L32_OP_HI(0) L32_OP_HI(1) break;                                     \
+            case 21: L32_OP_HI(2) L32_OP_HI(3) L32_OP_HF(0) L32_OP_HF(1) break;                                   \
+            case 22: L32_OP_HF(2) L32_OP_HF(3) L32_OP_D(0) L32_OP_D(1) break;                                     \
+            case 23: L32_OP_D(2) L32_OP_D(3) L32_OP_LO(0) L32_OP_LO(1) break;                                     \
+            default: L32_OP_LO(2) L32_OP_LO(3)                                                                    \
+                     *(f16x4 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hhi[0], hhi[1], hhi[2], hhi[3]}; \
+                     *(f16x4 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hlo[0], hlo[1], hlo[2], hlo[3]}; \
+                     break;                                                                                       \
+        }                                                                                                         \
+    }
+    // What goes into the gap after MFMA number M (0-based, NM per block) of block B: the previous block's gate
+    // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), its gap 24 behind the last MFMA, and in block 0 the copy-out of h_{s-1}.
+#define L32_AFTER_MFMA(M, NM, B)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if ((B) == 0 && (M) % 3 == 0) { L32_STAMP(8 + (M) / 3) }                                                      \
+    if ((M) == 3) {   /* after the keep-alive below: the refill can land in the very registers it replaces */     \
+        if (FIRST) load_seed(zq[0], 0, ((B) + 1) & 3);                                                            \
+        else if (L32_PROBE_ZQ) load_seed(zq[B], s + 1, B);                                                        \
+    }                                                                                                             \
+    if (L32_PROBE_GATES && (B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                  \
+    if (L32_PROBE_GATES && (B) > 0 && (M) == (NM) - 1) L32_GAP(24, (B) - 1)                                       \
+    if ((M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */    \
+    if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
+        if ((M) == 1) copy_read(s_prev);                                                                          \
+        if ((M) == 8) copy_write(s_prev, 0);                                                                      \
+        if ((M) == 10) copy_write(s_prev, 1);                                                                     \
+    }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+#define L32_BLOCK(b)                                                                                              \
+    {                                                                                                             \
+            constexpr int NM = FIRST ? 30 : 24;                                                                  \
+            const f32x16 zold = zq[FIRST ? 0 : b];                                                               \
+            if (FIRST) {                                                                                         \
+                f16x8 wxa[2][2];                                                                                 \
+_Pragma("unroll")                                                                                                \
+                for (int kk = 0; kk < 2; ++kk)                                                                   \
+_Pragma("unroll")                                                                                                \
+                    for (int pl = 0; pl < 2; ++pl)                                                               \
+                        wxa[kk][pl] = *(const f16x8 *)&wxl[((((size_t)w * 4 + b) * 2 + kk) * 2 + pl) * 512 + lane * 8]; \
+_Pragma("unroll")                                                                                                \
+                for (int m = 0; m < 6; ++m) {                                                                    \
+                    const int kk = m / 3, term = m % 3;                                                          \
+                    if (m == 0) mfma32_vv_first(acc[b & 1], wxa[kk][1], xh[kk], zold);                           \
+                    else mfma32_vv(acc[b & 1], wxa[kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);         \
+                    L32_AFTER_MFMA(m, NM, b)                                                                     \
+                }                                                                                                \
+            }                                                                                                    \
+_Pragma("unroll")                                                                                                \
+            for (int m = 0; m < 24; ++m) {                                                                       \
+                const int kk = m / 3, term = m % 3;                                                              \
+                if (!FIRST && m == 0) mfma32_av_first(acc[b & 1], Aw[b][kk][1], hf[kk][0], zold);                \
+                else mfma32_av(acc[b & 1], Aw[b][kk][term == 0 ? 1 : 0], hf[kk][term == 1 ? 1 : 0]);             \
+                L32_AFTER_MFMA((FIRST ? 6 : 0) + m, NM, b)                                                       \
+            }                                                                                                    \
+            L32_STAMP(1 + b)                                                                                     \
+    }
+
+    for (int s = 0; s < T_POS; ++s) {
+        L32_STAMP(0)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
+        if (FIRST) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 u, v;
+                    split2(xraw[kk * 2 + (j >> 2)][j & 3], u, v);
+                    xh[kk][j] = u;
+                    xl[kk][j] = v;
+                }
+            load_x(xraw, s + 1 < T_POS ? s + 1 : s);
+        }
+        L32_STAMP(7)
+        _Float16 hhi[4], hlo[4];
+        float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
+        const int s_prev = s > 0 ? s - 1 : 0;
+        // x-part first (layer 1: K = 32 = two k-steps, Wx1 fragments from LDS), then the h-part (K = 128 = eight k-steps);
+        // terms per k-step: w_lo.h_hi, w_hi.h_lo, w_hi.h_hi.  The C operand of a block's first MFMA (D != C there) is kept alive
+        // two MFMAs longer by L32_AFTER_MFMA: hipcc knows nothing about the asm MFMA still reading it and would hand the
+        // registers to the next VALU result.
+        L32_BLOCK(0)
+        L32_BLOCK(1)
+        L32_BLOCK(2)
+        L32_BLOCK(3)
+        // the last block's gates have no MFMAs left to hide behind (12 wait states after its last MFMA)
+        asm volatile("s_nop 11" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 1; g <= 24; ++g) L32_GAP(g, 3)
+        L32_STAMP(5)
+        __syncthreads();
+        L32_STAMP(6)
+    }
+#undef L32_BLOCK
+#undef L32_AFTER_MFMA
+#undef L32_GAP
+#undef L32_OP_E
+#undef L32_OP_A
+#undef L32_OP_R
+#undef L32_OP_K
+#undef L32_OP_T
+#undef L32_OP_C
+#undef L32_OP_M
+#undef L32_OP_X
+#undef L32_OP_H
+#undef L32_OP_HI
+#undef L32_OP_HF
+#undef L32_OP_D
+#undef L32_OP_LO
+#undef L32_PIN
+    copy_read(T_POS - 1);
+    copy_write(T_POS - 1, 0);
+    copy_write(T_POS - 1, 1);
+}
+
+}  // namespace clair

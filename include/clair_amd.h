@@ -132,7 +132,8 @@ int clair_kernel_times(clair_engine_t *e, double *ms_sum /*[CLAIR_K_COUNT]*/, in
 int clair_timing_reset(clair_engine_t *e);
 
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
- *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256]
+ *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
+ *    3 = split-K partials of the L4 product [16,n_pad,192]
  *    (L3/L4 activations only ever exist in LDS / split-K partials).  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);
 

@@ -25,12 +25,17 @@ __global__ __launch_bounds__(256) void k_fill(float *out, int iters, long long *
             if (SHAPE == 0) acc[m & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m & 7], 0, 0, 0);
             if (SHAPE == 1) acc[m & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[m & 7], 0, 0, 0);
             if (SHAPE == 2) big[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, big[m & 3], 0, 0, 0);
+            if (SHAPE == 3) big[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, big[0], 0, 0, 0);   // one dependent chain
+            if (SHAPE == 4) big[(m >> 3) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, big[(m >> 3) & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int r = (m * NF + f) & 7;
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[r]) : "v"(b));
-                else asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+                else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+                else if (KIND == 2) { if (f & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r])); else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[r]) : "v"(b)); }
+                else if (KIND == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[r]));
+                else if (KIND == 4) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(v[r]));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -69,5 +74,11 @@ int main() {
     row<1, 1>("16x16x32 f16  + v_exp_f32");
     row<2, 0>("32x32x16 f16  + v_fma_f32");
     row<2, 1>("32x32x16 f16  + v_exp_f32");
+    row<2, 2>("32x32x16 f16  + fma,exp alternating");
+    row<2, 3>("32x32x16 f16  + v_rcp_f32");
+    row<2, 4>("32x32x16 f16  + v_cvt_f16_f32");
+    row<3, 0>("32x32x16 f16 one acc chain + v_fma_f32");
+    row<3, 2>("32x32x16 f16 one acc chain + fma,exp");
+    row<4, 2>("32x32x16 f16 chains of 8 + fma,exp");
     return 0;
 }
