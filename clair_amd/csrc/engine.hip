@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,7 @@ struct clair_engine {
     int max_pad = 0;
     bool weights_ready = false;
     bool timing = false;
+    int proj2_groups = 4;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 8 gate tiles x 4 = one workgroup per CU
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<Slot> slots;
@@ -216,19 +218,19 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     s.last_n_pad = n_pad;
     {   // LSTM1 with its input projection fused in (no separate GEMM, no zx round trip), fp16 split products
         KernelTimer kt(e, s, CLAIR_K_LSTM1);
-        Lstm32Args a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles};
+        Lstm32Args a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles, -1};
         hipLaunchKernelGGL((lstm32_kernel<true>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
-    {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split
+    {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split; weight-stationary persistent workgroups
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
-        GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows};
         const int x_tiles = (m_rows + 127) / 128;
-        dim3 grid(((x_tiles + 7) / 8) * 64, 1, 1);   // 8 XCDs x 8 gate-row tiles x ceil(x_tiles / 8), see the kernel
-        hipLaunchKernelGGL(gemm_split_kernel<0>, grid, dim3(256), 0, s.stream, a);
+        const int groups = std::min(e->proj2_groups, (x_tiles + 7) / 8);
+        GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows, groups};
+        hipLaunchKernelGGL(gemm_split_kernel, dim3(64 * groups), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles};
+        Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1};
         hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
@@ -283,6 +285,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     e->max_batch = max_batch;
     e->max_pad = (max_batch + 31) & ~31;
     { const char *t = getenv("CLAIR_AMD_TAP_L3"); e->tap_l3 = t && t[0] == '1'; }
+    { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
     for (auto &s : e->slots) {
@@ -290,7 +293,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, (size_t)2 * T_POS * mp * 256 * sizeof(unsigned short));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, ((size_t)2 * T_POS * mp * 256 + 128 * 256) * sizeof(unsigned short));   // + slack rows read (never used) by gemm_split's ragged last tile
         if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
@@ -335,18 +338,23 @@ int clair_finalize_weights(clair_engine_t *e) {
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
     if (upload(e, &e->bx1, pack_bias32(T[1], T[3])) || upload(e, &e->bx2, pack_bias32(T[5], T[7]))) return 1;
-    {   // Wx2^T (gate-scaled, gate-row order) as two fp16 planes, [kstep][plane][gate row][32]  (gemm_split.hip.h)
-        std::vector<unsigned short> w2s((size_t)8 * 2 * 1024 * 32);
-        for (int R = 0; R < 1024; ++R) {
-            const int d = R >> 9, col = gate_col((R >> 7) & 3, (R >> 5) & 3, R & 31);
-            const std::vector<float> &src = d ? T[6] : T[4];
-            for (int k = 0; k < 2 * HID; ++k) {
-                unsigned short hi, lo;
-                split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
-                w2s[(((size_t)(k / 32) * 2 + 0) * 1024 + R) * 32 + (k % 32)] = hi;
-                w2s[(((size_t)(k / 32) * 2 + 1) * 1024 + R) * 32 + (k % 32)] = lo;
-            }
-        }
+    {   // Wx2^T (gate-scaled, gate-row order) as A fragments of the weight-stationary projection GEMM (gemm_split.hip.h):
+        // [gate tile][wm][mi][kk][plane][lane][8]
+        std::vector<unsigned short> w2s((size_t)8 * 2 * 2 * 16 * 2 * 64 * 8);
+        for (int gt = 0; gt < 8; ++gt)
+            for (int wm = 0; wm < 2; ++wm)
+                for (int mi = 0; mi < 2; ++mi)
+                    for (int kk = 0; kk < 16; ++kk)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int R = gt * 128 + wm * 64 + mi * 32 + (lane & 31), k = 16 * kk + 8 * (lane >> 5) + j;
+                                const int d = R >> 9, col = gate_col((R >> 7) & 3, (R >> 5) & 3, R & 31);
+                                unsigned short hi, lo;
+                                split2_host((d ? T[6] : T[4])[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
+                                const size_t base = ((((((size_t)gt * 2 + wm) * 2 + mi) * 16 + kk) * 2) * 64 + lane) * 8 + j;
+                                w2s[base] = hi;
+                                w2s[base + 64 * 8] = lo;
+                            }
         if (upload16(e, &e->wx2s, w2s)) return 1;
     }
     if (upload16(e, &e->wh1s, pack_wt32(T[0], T[2], F_IN, 8)) || upload16(e, &e->wh2s, pack_wt32(T[4], T[6], 2 * HID, 8)) ||

@@ -6,12 +6,21 @@
 // The product is computed TRANSPOSED, zx^T = Wx2^T . a1^T, on v_mfma_f32_32x32x16_f16: the A operand is the
 // weight tile (rows = gate rows in the order the recurrent kernel wants them), the B operand the activation
 // tile (columns = (t, candidate) rows of a1).  One 32x32 accumulator block is then exactly one
-// (direction, t, 32-candidate tile, wave, block) piece of lstm32_kernel's accumulator layout
-// (lstm32.hip.h): the epilogue adds the bias and stores it as four contiguous 1 KiB pieces.
+// (direction, 32-candidate tile, t, wave, block) piece of lstm32_kernel's accumulator layout
+// (lstm32.hip.h): the epilogue stores it as four contiguous 1 KiB pieces (the bias seeds the accumulators).
 //
-// Operands arrive pre-split: LSTM1 writes its output as two fp16 planes, the host splits the gate-scaled
-// Wx2 (engine.hip).  Tile: 128 gate rows x 128 activation rows per 256-thread workgroup, 2x2 waves of
-// 64 x 64 (four accumulator blocks), K in steps of 32 through LDS.
+// Weight-stationary, persistent.  K is only 256, so the whole K extent of a wave's 64 gate rows (both fp16
+// planes: 64 KiB) fits the 256 accumulation VGPRs of a one-wave-per-SIMD kernel -- the same trick as the
+// recurrent kernels.  A workgroup (2x2 waves of 64 gate rows x 64 activation rows) therefore loads its 128-row
+// weight tile ONCE and then walks over activation tiles; per 32-wide k-slab only the activation tile (two
+// planes, 16 KiB) goes through LDS, double-buffered, one barrier per slab, register-prefetched two slabs ahead
+// across tile boundaries.  Compared with the tile-per-workgroup version this halves the LDS traffic and the
+// staging instructions per MFMA, removes the weight re-reads (270 MB of L2 traffic per launch) and the
+// per-workgroup launch / first-tile latency (profiles/r01_microbench.txt, gemm_split_probe).
+//
+// Workgroup -> work.  id & 7 = XCD (hardware round-robin); on an XCD, local id l = id >> 3: gate tile l & 7, group
+// l >> 3.  The eight workgroups of a group walk the SAME activation tiles (x_tile = xcd + 8 * (group + groups * j)),
+// so an activation slab is fetched from HBM once per XCD and served to the other seven from that XCD's L2.
 #pragma once
 #include "common.hip.h"
 #include "lstm32.hip.h"
@@ -22,134 +31,171 @@ typedef unsigned short f16bits_t;   // raw fp16 storage
 
 struct GemmSplitArgs {
     const f16bits_t *X3;    // [2][33*n_pad][256]  fp16 planes of a1 (rows in (t, n) order)
-    const f16bits_t *W3;    // [8 ksteps][2 planes][1024 gate rows][32 k]  fp16 planes of gate-scaled Wx2^T;
-                            // gate row R = ((d*4 + w)*4 + b)*32 + 8a + 4h' + c  <->  column d*512 + c*128 + 32w + 8b + 4h' + a
+    const f16bits_t *W3;    // [8 gate tiles][2 wm][2 mi][16 kk][2 planes][64 lanes][8]  A fragments of the gate-scaled Wx2^T:
+                            // gate row R = gtile*128 + wm*64 + mi*32 + lane%32, k = 16*kk + 8*(lane/32) + j;
+                            // R = ((d*4 + w)*4 + b)*32 + 8a + 4h' + c  <->  column d*512 + c*128 + 32w + 8b + 4h' + a
     const float *bias;      // [1024] gate-scaled, in gate-row order
     float *C;               // zx in lstm32_kernel's layout: [2 dir][n_pad/32][33][4 wave][4 b][4 a][64 lane][4 c]
     int n_pad;
     int ntiles;             // n_pad / 32
     int m_rows;             // 33 * n_pad
+    int groups;             // workgroup groups per XCD (grid = 64 * groups)
 };
 
-// LDS tile of one plane: 128 rows x 32 fp16 = 64 B per row, four 16-byte chunks per row.  The fragment read
-// of the 32x32x16 MFMA is ds_read_b128 of row l%32, chunk 2*kk + l/32; the hardware serves it in the lane
-// groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) (MI355X_MICROARCH.md, LDS): XOR-ing the chunk with
+// LDS image of one activation slab plane: 128 rows x 32 fp16 = 64 B per row, four 16-byte chunks per row.  The
+// fragment read of the 32x32x16 MFMA is ds_read_b128 of row l%32, chunk 2*kk + l/32; the hardware serves it in the
+// lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) (MI355X_MICROARCH.md, LDS): XOR-ing the chunk with
 // (row >> 3) & 3 puts the 16 rows of every group on 16 different 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 3)) << 3); }   // in fp16 units
 
-// PROBE != 0 only in tools/ubench/gemm_split_probe.hip: 1 = no zx store, 2 = no MFMAs, 3 = no global loads after the first
-template <int PROBE = 0>
-__global__ __launch_bounds__(256, 3) void gemm_split_kernel(GemmSplitArgs p) {
-    __shared__ __attribute__((aligned(16))) f16bits_t Ws[2][128 * 32];
-    __shared__ __attribute__((aligned(16))) f16bits_t Xs[2][128 * 32];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_split_kernel(GemmSplitArgs p) {
+    __shared__ __attribute__((aligned(16))) f16bits_t Xs[2][2 * 128 * 32];   // [buffer][plane][row][k]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l32 = lane & 31, lh = lane >> 5;
-    // XCD-aware tile order.  Workgroups go round-robin over the 8 XCDs (one L2 each) by linear id, so the
-    // eight gate-row tiles that share one 128-row activation tile are given ids with the same id & 7 and
-    // consecutive id >> 3: they run back to back on ONE XCD and the activation tile crosses the fabric once
-    // instead of up to eight times (PMC FETCH_SIZE 170 MB -> 65 MB per launch, profiles/r01_pmc_hbm_traffic.txt).
-    const int wg = blockIdx.x;
-    const int xcd = wg & 7, seq = wg >> 3;
-    const int x_tile = (seq >> 3) * 8 + xcd;
-    if (x_tile * 128 >= p.m_rows) return;
-    const int xrow0 = x_tile * 128;          // first activation row ((t, n) order)
-    const int grow0 = (seq & 7) * 128;       // first gate row
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int gtile = local & 7, group = local >> 3;
+    const int x_tiles = (p.m_rows + 127) >> 7;
+    const int x_step = 8 * p.groups;
+    const int x_first = xcd + 8 * group;
+    if (x_first >= x_tiles) return;
+    const int n_my = (x_tiles - x_first + x_step - 1) / x_step;   // activation tiles of this workgroup
 
-    // staging map: chunk id f = tid + 256*h (h = 0,1) of a plane tile: row f>>2, 16-byte chunk f&3
-    const f16bits_t *xsrc[2];
-    int lds_dst[2];
+    // resident weights: Wr[mi][kk][plane]
+    f16x8 Wr[2][16][2];
+    {
+        const f16x8 *wp = (const f16x8 *)p.W3 + ((size_t)(gtile * 2 + wm) * (2 * 16 * 2 * 64)) + lane;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int f = tid + 256 * h, r = f >> 2, c = f & 3;
-        int gr = xrow0 + r;
-        gr = gr < p.m_rows ? gr : p.m_rows - 1;
-        xsrc[h] = p.X3 + (size_t)gr * 256 + c * 8;
-        lds_dst[h] = split_lds_off(r, c);
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) Wr[mi][kk][pl] = wp[((mi * 16 + kk) * 2 + pl) * 64];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+a"(Wr[mi][kk][pl]));   // AGPR-resident, never re-loaded (lstm32.hip.h)
     }
-    const size_t x_plane = (size_t)p.m_rows * 256;
-    const f16bits_t *wsrc = p.W3 + ((size_t)grow0 * 32) + (size_t)tid * 8;   // + (kstep*2 + plane)*1024*32 + h*256*8
-
-    f32x16 acc[2][2];   // [gate block mi][activation block ni]
+    f32x4 bq[2][4];   // bias quads of this wave's two gate blocks: rows 8a + 4h' + c
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int a = 0; a < 4; ++a) bq[mi][a] = *(const f32x4 *)(p.bias + gtile * 128 + wm * 64 + mi * 32 + 8 * a + 4 * lh);
 
-    f32x4 rx[2][2], rw[2][2];   // raw 16-byte chunks in flight (f16x8 each)
-    auto gload = [&](int ks) {
+    // staging map of a slab (2 planes x 128 rows x 4 chunks = 1024 chunks of 16 B): chunk f = tid + 256*j -> plane f>>9,
+    // row (f>>2)&127, chunk f&3; slab q = 8*tile_index + ks.  Rows past m_rows of a ragged last tile are read as they
+    // come (the a1 workspace carries 128 rows of slack) -- their accumulator blocks are never stored.
+    const size_t x_plane = (size_t)p.m_rows * 256;
+    int lds_dst[4];
+    const f16bits_t *g_src[4];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                rx[pl][h] = *(const f32x4 *)(xsrc[h] + pl * x_plane + ks * 32);
-                rw[pl][h] = *(const f32x4 *)(wsrc + ((size_t)(ks * 2 + pl) * 1024 * 32) + h * 256 * 8);
-            }
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + 256 * j, pl = f >> 9, r = (f >> 2) & 127, c = f & 3;
+        lds_dst[j] = pl * (128 * 32) + split_lds_off(r, c);
+        g_src[j] = p.X3 + pl * x_plane + (size_t)r * 256 + c * 8;
+    }
+    const int n_slabs = n_my * 8;
+    auto slab_off = [&](int q) -> size_t {   // wave-uniform offset of slab q from the staging pointers
+        const int qq = q < n_slabs ? q : n_slabs - 1;   // the prefetch past the end re-reads the last slab
+        return ((size_t)(x_first + (qq >> 3) * x_step) * 128 * 256) + (qq & 7) * 32;
     };
-    gload(0);
-    constexpr int KSTEPS = 8;   // 256 / 32
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        __syncthreads();   // previous step's fragments are all in registers / consumed
+    auto gload = [&](f32x4 (&r)[4], int q) {
+        const size_t off = slab_off(q);
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int j = 0; j < 4; ++j) r[j] = *(const f32x4 *)(g_src[j] + off);
+    };
+    auto lstore = [&](const f32x4 (&r)[4], int buf) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *(f32x4 *)&Xs[pl][lds_dst[h]] = rx[pl][h];
-                *(f32x4 *)&Ws[pl][lds_dst[h]] = rw[pl][h];
-            }
-        __syncthreads();
-        if (ks + 1 < KSTEPS && PROBE != 3) gload(ks + 1);
+        for (int j = 0; j < 4; ++j) *(f32x4 *)&Xs[buf][lds_dst[j]] = r[j];
+    };
+    // B fragments of a whole slab: [kk][plane][activation block]
+    auto fread = [&](f16x8 (&xf)[2][2][2], int buf) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // fragments of this wave's two gate blocks and two activation blocks, both planes:
-            // lane (l32, lh) = row l32, k-chunk 2*kk + lh
-            f16x8 wf[2][2], xf[2][2];
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    wf[pl][i] = *(const f16x8 *)&Ws[pl][split_lds_off(wm * 64 + i * 32 + l32, 2 * kk + lh)];
-                    xf[pl][i] = *(const f16x8 *)&Xs[pl][split_lds_off(wn * 64 + i * 32 + l32, 2 * kk + lh)];
-                }
-            if (PROBE == 2) {
-                acc[0][0][kk] += (float)wf[0][0][0] + (float)xf[0][1][1] + (float)wf[1][1][2] + (float)xf[1][0][3];
-                continue;
-            }
-            // three product terms, small ones first; the four blocks alternate so that consecutive MFMAs
-            // never wait on each other's accumulator
-#define SPLIT_TERM(PW, PX)                                                                     \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) \
-        acc[mi][ni] = mfma32h(wf[PW][mi], xf[PX][ni], acc[mi][ni]);
-            SPLIT_TERM(1, 0)
-            SPLIT_TERM(0, 1)
-            SPLIT_TERM(0, 0)
-#undef SPLIT_TERM
-        }
-    }
+                for (int ni = 0; ni < 2; ++ni)
+                    xf[kk][pl][ni] = *(const f16x8 *)&Xs[buf][pl * (128 * 32) + split_lds_off(wn * 64 + ni * 32 + l32, 2 * kk + lh)];
+    };
 
-    // epilogue: bias, then each accumulator block is four contiguous 1 KiB pieces of the recurrent kernel's layout
+    // Pipeline state at the top of slab q: LDS[q&1] = slab q and LDS[(q+1)&1] = slab q+1 visible, xa/xb = fragments of slab q
+    // (xa for even q), register set ra/rb = slabs q+2, q+3 in flight (ra holds even slabs).
+    f32x4 ra[4], rb[4];
+    f16x8 xa[2][2][2], xb[2][2][2];
+    gload(ra, 0);
+    gload(rb, 1);
+    lstore(ra, 0);
+    gload(ra, 2);
+    lstore(rb, 1);
+    gload(rb, 3);
+    __syncthreads();
+    fread(xa, 0);
+
+    f32x16 acc[2][2];   // [gate block mi][activation block ni]
+    for (int it = 0; it < n_my; ++it) {
+        const int xt = x_first + it * x_step;
+        // the bias seeds the accumulators (plain VALU moves; two wait states before the first asm MFMA reads them)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int xblk = (xrow0 >> 5) + wn * 2 + ni;      // = t * ntiles + tile
-        if (xblk * 32 >= p.m_rows) continue;
-        const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int gblk = (grow0 >> 5) + wm * 2 + mi;  // = (d*4 + w)*4 + b
-            const int d = gblk >> 4, wb = gblk & 15;
-            float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4;
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const f32x4 bv = *(const f32x4 *)(p.bias + gblk * 32 + 8 * a + 4 * lh);
-                f32x4 v = {acc[mi][ni][4 * a + 0], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]};
-                v += bv;
-                if (PROBE == 1 && v[0] != 12345.678f) continue;
-                *(f32x4 *)(dst + a * 256) = v;
+                for (int a = 0; a < 4; ++a) {
+                    acc[mi][ni][4 * a] = bq[mi][a][0]; acc[mi][ni][4 * a + 1] = bq[mi][a][1];
+                    acc[mi][ni][4 * a + 2] = bq[mi][a][2]; acc[mi][ni][4 * a + 3] = bq[mi][a][3];
+                }
+        asm volatile("s_nop 1" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            // next slab's fragments first: their LDS latency hides behind this slab's 24 MFMAs
+            if (ks & 1) fread(xa, 0); else fread(xb, 1);
+            // 24 MFMAs: three product terms per k-step, small ones first; the four blocks alternate so consecutive MFMAs never
+            // chain.  The staging traffic rides in their shadows, one instruction per MFMA: slab q+2 -> the LDS buffer slab q
+            // has just left (every wave read it before the previous barrier), then slab q+4 -> the freed registers.
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
+                mfma32_av(acc[mi][ni], Wr[mi][ks * 2 + kk][term == 0 ? 1 : 0],
+                          (ks & 1) ? xb[kk][term == 1 ? 1 : 0][ni] : xa[kk][term == 1 ? 1 : 0][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m >= 2 && m < 10 && (m & 1) == 0) {
+                    const int j = (m - 2) >> 1;
+                    if (ks & 1) *(f32x4 *)&Xs[1][lds_dst[j]] = rb[j]; else *(f32x4 *)&Xs[0][lds_dst[j]] = ra[j];
+                }
+                if (m >= 10 && m < 18 && (m & 1) == 0) {
+                    const int j = (m - 10) >> 1;
+                    if (ks & 1) rb[j] = *(const f32x4 *)(g_src[j] + slab_off(it * 8 + ks + 4));
+                    else ra[j] = *(const f32x4 *)(g_src[j] + slab_off(it * 8 + ks + 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        // epilogue: each accumulator block is four contiguous 1 KiB pieces of the recurrent kernel's layout
+        // (12 wait states between the last MFMA and the first read of its result)
+        asm volatile("s_nop 11" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int xblk = xt * 4 + wn * 2 + ni;      // = t * ntiles + tile
+            if (xblk * 32 >= p.m_rows) continue;
+            const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int gblk = gtile * 4 + wm * 2 + mi;  // = (d*4 + w)*4 + b
+                const int d = gblk >> 4, wb = gblk & 15;
+                float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#ifdef GEMM_PROBE_NOSTORE   // tools/ubench/gemm_split_probe.hip only
+                    if (acc[mi][ni][4 * a] == 12345.678f)
+#endif
+                    *(f32x4 *)(dst + a * 256) = (f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]};
             }
         }
     }

@@ -82,6 +82,7 @@ struct Lstm32Args {
     float *aout;                // !FIRST: [33][n_pad][256] fp32
     int n_pad;
     int ntiles;                 // n_pad / 32
+    int dir_only;               // -1: workgroup id = 2*tile + direction; 0 / 1: this direction only, workgroup id = tile
 };
 
 __device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cand = lane & 31, hq = lane >> 5;
-    const int d = blockIdx.x & 1;
-    const int tile = blockIdx.x >> 1;
+    const int d = p.dir_only < 0 ? (blockIdx.x & 1) : p.dir_only;
+    const int tile = p.dir_only < 0 ? (blockIdx.x >> 1) : blockIdx.x;
 
     // resident weights: Aw[b][kk][plane] = 8 fp16 of gate row (b, lane%32), k = 16*kk + 8*(lane/32) + j
     f16x8 Aw[4][8][2];

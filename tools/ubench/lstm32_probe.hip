@@ -18,7 +18,7 @@ template <bool FIRST> void run(int n_pad) {
     (void)hipMemset(zx, 0, (size_t)33 * n_pad * 1024 * 4); (void)hipMemset(bq, 0, 4096); (void)hipMemset(x, 0, (size_t)n_pad * 33 * 32 * 4);
     long long *st; (void)hipMalloc(&st, 33 * 16 * 8); (void)hipMemset(st, 0, 33 * 16 * 8);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(l32_stamps), &st, sizeof(st));
-    Lstm32Args a{x, wxs, bq, zx, whs, a1, a2, n_pad, ntiles};
+    Lstm32Args a{x, wxs, bq, zx, whs, a1, a2, n_pad, ntiles, -1};
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((lstm32_kernel<FIRST>), dim3(ntiles * 2), dim3(256), 0, 0, a);
     (void)hipEventRecord(e0);
