@@ -48,6 +48,10 @@ KERNEL_BYTES = {
     "l4": 33 * 256 * 4 + 16 * 192 * 4,                    # layer output in; split-K partials out
     "tail": 16 * 192 * 4 + 90 * 4,
 }
+# HBM bytes per launch at batch 1024 from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
+# doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/r01_pmc_hbm_traffic.txt.  Not collected live: a
+# counter pass serialises kernels and cannot share a process with the timed run.
+PMC_TRAFFIC_BYTES_B1024 = {"lstm1": 46.0e6, "proj2": 181.6e6, "lstm2": 175.2e6, "l4": 54.6e6, "tail": 16.1e6}
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
 PEAK_F16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: f16/bf16 MFMA dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
@@ -163,10 +167,10 @@ def main():
         kern = {k: {"ms_mean": (ms / cnt if cnt else None), "launches": cnt} for k, (ms, cnt) in times.items()}
         kern_iso = {k: round(ms / cnt, 5) if cnt else None for k, (ms, cnt) in times_iso.items()}
         # dominant = most chip time: duration x share of the 256 CUs its grid can occupy (the recurrent kernels
-        # launch 2 workgroups per 16-candidate tile, i.e. 128 CUs at batch 1024)
+        # launch 2 workgroups per 32-candidate tile, one per CU: 64 CUs at batch 1024)
         cu_share = {k: 1.0 for k in times_iso}
         for k in ("lstm1", "lstm2"):
-            cu_share[k] = min(1.0, (batch + 31) // 32 * 32 / 16 * 2 / 256.0)
+            cu_share[k] = min(1.0, (batch + 31) // 32 * 2 / 256.0)
         dom = max(times_iso, key=lambda k: times_iso[k][0] * cu_share[k])
         dom_ms = times_iso[dom][0] / max(times_iso[dom][1], 1)
         ovl_ms = times[dom][0] / max(times[dom][1], 1)
@@ -183,12 +187,14 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None}
+        roof["traffic"] = round(PMC_TRAFFIC_BYTES_B1024[dom] * batch / 1024) if dom in PMC_TRAFFIC_BYTES_B1024 else None
         roof.update({
+            "traffic_source": "profiles/r01_pmc_hbm_traffic.txt (rocprofv3 PMC passes at batch 1024, scaled by batch/1024)",
             "kernel_ms": round(dom_ms, 4), "algorithmic_flop_per_launch": flop, "algorithmic_bytes_per_launch": byts,
             "algorithmic_tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1),
             "mfma_frac_executed": round(tf * SPLIT_TERMS / PEAK_F16_MFMA_TFLOPS, 4),
             "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-            "note": "matmuls run as 2-way fp16 split: 3 v_mfma_f32_16x16x32_f16 per algorithmic fp32 product block",
+            "note": "matmuls run as 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
             "measured": "HIP events on the kernel's stream, %d launches on one stream right after the timed region "
                         "(no other stream active)" % iso_steps,
             "overlapped_kernel_ms": round(ovl_ms, 4)})

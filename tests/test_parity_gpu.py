@@ -43,6 +43,29 @@ def test_layerwise_taps(engine, synth_weights):
     a2 = engine.debug_read(0, 2, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
     assert np.abs(a1 - inter["a1"]).max() <= ACT_TOL
     assert np.abs(a2 - inter["a2"]).max() <= ACT_TOL
+    # L4: split-K partials (tap 3), reduced on the host in float64, bias + selu as clair/model.py:482-488
+    part = engine.debug_read(0, 3, (16, n_pad, 192)).astype(np.float64).sum(axis=0)[:n] + synth_weights["l4_bias"].astype(np.float64)
+    l4 = 1.0507009873554804934193349852946 * np.where(part >= 0, part, 1.6732632423543772848170429916717 * np.expm1(part))
+    assert np.abs(l4 - inter["l4"]).max() <= ACT_TOL
+
+
+def test_l3_tap_has_no_split_outliers(synth_weights, monkeypatch):
+    """The fp16 hi/lo planes of L3 must belong to ONE split of each value: a compiler that materialises the hi part twice
+    (fused and unfused rounding) leaves one-fp16-ulp errors on ~1 value in 30 000 (common.hip.h: split2)."""
+    from clair_amd import _capi
+    monkeypatch.setenv("CLAIR_AMD_TAP_L3", "1")
+    eng = _capi.Engine(device=0, max_batch=256, n_slots=1)
+    try:
+        eng.load_weights(synth_weights)
+        n = 256
+        x, _ = synth.synthetic_input(n, "ont", seed=4242)
+        eng.predict(x)
+        _, inter = _oracle(synth_weights, x, keep_intermediates=True)
+        l3 = eng.debug_read(0, 4, (n, 7680))
+        err = np.abs(l3 - inter["l3"])
+        assert err.max() <= ACT_TOL, "l3 max abs err %g, %d values above 2e-5" % (err.max(), int((err > 2e-5).sum()))
+    finally:
+        eng.close()
 
 
 def test_submit_wait_two_slots(engine, synth_weights):
