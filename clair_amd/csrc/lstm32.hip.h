@@ -206,6 +206,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) ch[half][pl] = *(const f16x8 *)&hbuf[s & 1][pl][row][c16 * 16 + half * 8];
     };
+    f32x4 co[2][2];   // layer 2: converted fp32 row pieces [half][4-unit quad pair]
+    auto copy_cvt = [&](int i) {   // layer 2: micro-step i = 0..7 of the fp16-planes -> fp32 conversion: two units each
+        if (FIRST) return;
+        const int half = i >> 2, q = i & 3;
+#pragma unroll
+        for (int j = 2 * q; j < 2 * q + 2; ++j) co[half][j >> 2][j & 3] = (float)ch[half][0][j] + (float)ch[half][1][j];
+    };
     auto copy_write = [&](int s, int half) {
         const int t = d ? T_POS - 1 - s : s;
         const int row = tid >> 3, c16 = tid & 7;
@@ -215,14 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             *(f16x8 *)(p.aout2 + off) = ch[half][0];
             *(f16x8 *)(p.aout2 + plane + off) = ch[half][1];
         } else {
-            f32x4 o0, o1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o0[j] = (float)ch[half][0][j] + (float)ch[half][1][j];
-                o1[j] = (float)ch[half][0][4 + j] + (float)ch[half][1][4 + j];
-            }
-            *(f32x4 *)(p.aout + off) = o0;
-            *(f32x4 *)(p.aout + off + 4) = o1;
+            *(f32x4 *)(p.aout + off) = co[half][0];
+            *(f32x4 *)(p.aout + off + 4) = co[half][1];
         }
     };
 
@@ -317,8 +318,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if ((M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */    \
     if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
-        if ((M) == 8) copy_write(s_prev, 0);                                                                      \
-        if ((M) == 10) copy_write(s_prev, 1);                                                                     \
+        if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
+        if ((M) == 12) copy_write(s_prev, 0);                                                                     \
+        if ((M) == 14) copy_write(s_prev, 1);                                                                     \
     }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
@@ -408,6 +410,8 @@ _Pragma("unroll")                                                               
 #undef L32_OP_LO
 #undef L32_PIN
     copy_read(T_POS - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) copy_cvt(i);
     copy_write(T_POS - 1, 0);
     copy_write(T_POS - 1, 1);
 }
