@@ -74,20 +74,29 @@ def parse_args():
 
 
 def cpu_baseline(w, x, seconds):
-    """Time the C port on all host cores on a bounded sample of the same workload."""
+    """Time the C port of the same forward pass on the host cores, on a bounded sample of the same workload:
+    all cores for about `seconds`, plus the reference's default of 4 threads (README.md:178) on a smaller sample."""
     from oracle import c_oracle
     cores = c_oracle.max_threads()
-    probe = min(256, x.shape[0])
-    t0 = time.perf_counter()
-    c_oracle.forward(w, x[:probe])
-    rate = probe / (time.perf_counter() - t0)
-    n = int(max(probe, min(x.shape[0], rate * seconds)))
-    t0 = time.perf_counter()
-    c_oracle.forward(w, x[:n])
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 1), "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "%d candidates of the same synthetic batch, oracle/clair_oracle.c with OpenMP over %d threads, %.1f s"
-                      % (n, cores, dt)}
+
+    def timed(threads, budget):
+        c_oracle.forward(w, x[:min(64, x.shape[0])], threads=threads)          # warm-up (library load, thread pool)
+        n = min(x.shape[0], 1024)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            c_oracle.forward(w, x[:n], threads=threads)
+            done += n
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return done / dt, done, dt
+
+    rate_all, n_all, dt_all = timed(0, seconds)
+    rate_4, n_4, dt_4 = timed(4, min(seconds, 6.0))
+    return {"value": round(rate_all, 1), "unit": "candidates/s", "cores": cores, "kind": "port",
+            "sample": "%d candidates of the same synthetic batches, oracle/clair_oracle.c with OpenMP over %d threads, %.1f s"
+                      % (n_all, cores, dt_all),
+            "value_4_threads": round(rate_4, 1),
+            "sample_4_threads": "%d candidates, 4 OpenMP threads (the reference's default --threads), %.1f s" % (n_4, dt_4)}
 
 
 def main():
