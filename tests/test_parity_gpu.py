@@ -49,6 +49,31 @@ def test_layerwise_taps(engine, synth_weights):
     assert np.abs(l4 - inter["l4"]).max() <= ACT_TOL
 
 
+@pytest.mark.parametrize("n,platform", [(4096, "pacbio_ccs"), (8192, "illumina")])
+def test_full_size_batches_by_properties(synth_weights, n, platform):
+    """BASELINE.json configs[2] / [4] batch sizes in ONE predict call, checked by size-independent properties: candidates are
+    independent, so a permuted batch must give the permuted outputs BIT-exactly (every candidate sees the same arithmetic
+    whatever tile, lane or workgroup it lands in); rows are distributions; a 256-candidate subsample matches the oracle."""
+    from clair_amd import _capi
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
+    try:
+        eng.load_weights(synth_weights)
+        x, _ = synth.synthetic_input(n, platform, seed=31 + n)
+        got = eng.predict(x)
+        perm = np.random.default_rng(n).permutation(n)
+        got_p = eng.predict(x[perm])
+        for g, gp in zip(got, got_p):
+            assert np.isfinite(g).all()
+            assert np.array_equal(g[perm], gp), "outputs depend on the position of a candidate in the batch"
+            assert np.abs(g.sum(axis=1) - 1).max() < 1e-5
+        pick = perm[:256]
+        want = _oracle(synth_weights, x[pick])
+        for g, w_ in zip(got, want):
+            assert np.abs(g[pick] - w_).max() <= PROB_TOL
+    finally:
+        eng.close()
+
+
 def test_l3_tap_has_no_split_outliers(synth_weights, monkeypatch):
     """The fp16 hi/lo planes of L3 must belong to ONE split of each value: a compiler that materialises the hi part twice
     (fused and unfused rounding) leaves one-fp16-ulp errors on ~1 value in 30 000 (common.hip.h: split2)."""
