@@ -81,7 +81,7 @@ def cpu_baseline(w, x, seconds):
 
     def timed(threads, budget):
         c_oracle.forward(w, x[:min(64, x.shape[0])], threads=threads)          # warm-up (library load, thread pool)
-        n = min(x.shape[0], 1024)
+        n = x.shape[0] if threads == 0 else min(x.shape[0], 1024)   # all cores: the whole resident set per call (32 candidates per thread)
         done, t0 = 0, time.perf_counter()
         while True:
             c_oracle.forward(w, x[:n], threads=threads)
