@@ -1,0 +1,47 @@
+"""ctypes binding of include/clair_host.h (libclair_host.so, built by clair_amd/build.py with g++: no GPU involved)."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclair_host.so")
+SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_parse_tensors")
+N_VALUES = 1056
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError("%s not found: run `python -m clair_amd.build`" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        lib.clair_host_abi_version.restype = i32
+        lib.clair_host_last_error.restype = ctypes.c_char_p
+        lib.clair_host_parse_tensors.argtypes = [vp, i64, i32, i32, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                                 ctypes.POINTER(i64)]
+        if lib.clair_host_abi_version() != 1:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 1" % lib.clair_host_abi_version())
+        _lib = lib
+    return _lib
+
+
+def parse_tensors(chunk, final, max_rows, x_out, row0):
+    """Parse up to max_rows lines of `chunk` (bytes) into x_out[row0:] (float32 [*,1056], C-contiguous).
+    -> (rows_taken, infos of the kept rows as [[ctg, pos, seq], ...], bytes_consumed)"""
+    lib = load()
+    tok = np.empty((max(max_rows, 1), 6), dtype=np.int32)
+    taken, kept, used = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+    buf = ctypes.c_char_p(chunk)           # bytes: passed by pointer, no copy
+    rc = lib.clair_host_parse_tensors(buf, len(chunk), 1 if final else 0, max_rows,
+                                      x_out[row0:].ctypes.data, tok.ctypes.data,
+                                      ctypes.byref(taken), ctypes.byref(kept), ctypes.byref(used))
+    if rc != 0:
+        raise ValueError("malformed tensor record: " + lib.clair_host_last_error().decode())
+    infos = []
+    for k in range(kept.value):
+        o = tok[k]
+        infos.append([chunk[o[0]:o[0] + o[1]].decode(), chunk[o[2]:o[2] + o[3]].decode(), chunk[o[4]:o[4] + o[5]].decode()])
+    return taken.value, infos, used.value

@@ -22,7 +22,22 @@ def needs_build():
     return newest > os.path.getmtime(OUT)
 
 
+HOST_SRC = os.path.join(HERE, "hostsrc", "host_io.cpp")
+HOST_OUT = os.path.join(HERE, "libclair_host.so")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force=False):
+    """Host-side helpers (include/clair_host.h): plain C++, no HIP."""
+    hdr = os.path.join(HERE, "..", "include", "clair_host.h")
+    if (force or not os.path.isfile(HOST_OUT)
+            or max(os.path.getmtime(HOST_SRC), os.path.getmtime(hdr)) > os.path.getmtime(HOST_OUT)):
+        subprocess.check_call([CXX, "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", HOST_SRC, "-o", HOST_OUT])
+    return HOST_OUT
+
+
 def build(force=False, verbose=False):
+    build_host(force)
     if not force and not needs_build():
         return OUT
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]

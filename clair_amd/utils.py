@@ -35,16 +35,55 @@ def setup_environment():
     return None
 
 
-def _open_source(tensor_file_path):
+def _open_source(tensor_file_path, binary=False):
     if tensor_file_path == "PIPE":
-        return None, sys.stdin
+        return None, (sys.stdin.buffer if binary else sys.stdin)
     proc = Popen(shlex.split("gzip -fdc %s" % tensor_file_path), stdout=PIPE,
-                 bufsize=8388608, universal_newlines=True)
+                 bufsize=8388608, universal_newlines=not binary)
     return proc, proc.stdout
 
 
 def tensor_generator_from(tensor_file_path, batch_size):
-    """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size."""
+    """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size.
+
+    The text is parsed by the native helper (include/clair_host.h: clair_host_parse_tensors, ~20x the NumPy path below);
+    `tensor_generator_from_py` is the line-by-line restatement of the reference it is tested against."""
+    from clair_amd import _hostapi
+    proc, stream = _open_source(tensor_file_path, binary=True)
+    processed = 0
+    pending = b""
+    eof = exhausted = False
+    while not exhausted:
+        flat = np.empty((batch_size, N_VALUES), dtype=np.float32)
+        infos = []
+        taken = 0
+        while taken < batch_size:
+            need = batch_size - taken
+            while not eof and pending.count(b"\n") < need:
+                more = stream.read(1 << 23)
+                if more:
+                    pending += more
+                else:
+                    eof = True
+            if not pending:                      # the reference's readline() returned '' (utils.py:75-77)
+                exhausted = True
+                break
+            t, inf, used = _hostapi.parse_tensors(pending, eof, need, flat, len(infos))
+            taken += t
+            infos.extend(inf)
+            pending = pending[used:]
+        n = len(infos)
+        processed += n
+        print("Processed %d tensors" % processed, file=sys.stderr)
+        if n > 0:
+            yield flat.reshape(batch_size, N_POS, N_ROW, N_CH)[:n], infos
+    if proc is not None:
+        stream.close()
+        proc.wait()
+
+
+def tensor_generator_from_py(tensor_file_path, batch_size):
+    """The reference's line-by-line NumPy ingest (clair/utils.py:72-109), kept as the checker of the native parser."""
     proc, lines = _open_source(tensor_file_path)
     processed = 0
     exhausted = False

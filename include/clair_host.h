@@ -1,0 +1,40 @@
+/* clair_host.h -- C ABI of the host-side helpers around the MI355X forward pass (libclair_host.so, plain C++, no HIP).
+ *
+ * These are the SURVEY.md section 8(f) "next" rows: the callers either side of the hot path that cap end-to-end
+ * throughput once the network runs at millions of candidates per second.  Every function restates a piece of the
+ * reference's Python (file:line below) and is pinned, byte for byte, against the build's Python counterpart in
+ * clair_amd/ (which is itself pinned against fixtures minted from the real reference, tests/golden/).
+ *
+ * Convention: functions return 0 on success, non-zero on failure with a message in clair_host_last_error()
+ * (thread-local).  Plain pointers and sizes only. */
+#ifndef CLAIR_HOST_H
+#define CLAIR_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLAIR_HOST_ABI_VERSION 1
+#define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
+
+int clair_host_abi_version(void);
+const char *clair_host_last_error(void);
+
+/* -- ingest: the parsing work of clair/utils.py:72-109 (tensor_generator_from) for one chunk of text ---------------
+ * Record format (dataPrepScripts/CreateTensor.py:60-65): "ctg pos refseq33 v0 ... v1055", whitespace separated.
+ * buf[0..len) is consumed line by line ('\n'; a last line without '\n' counts only when `final` is non-zero) until
+ * max_rows lines have been TAKEN (utils.py:79 counts dropped rows too) or the complete lines run out.  Per line:
+ *   - the last 1056 columns -> float32 (utils.py:81-83); exactly three columns must precede them (utils.py:86);
+ *   - rows whose centre base refseq[16] is not an IUPAC code are dropped (utils.py:90-91, shared/utils.py:24-27);
+ *   - kept row k: x[k*1056 ..] = values with channels 1..3 -= channel 0 (utils.py:96-98);
+ *     tok[k*6 ..] = (offset, length) pairs of ctg, pos, refseq inside buf.
+ * Outputs: *rows_taken, *rows_kept, *bytes_consumed (start of the first line not taken).
+ * Errors (malformed line: too few columns, not three leading columns, refseq shorter than 17, unparsable value) name
+ * the 0-based line index inside this chunk; the reference raises a Python exception at the same places. */
+int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_rows,
+                             float *x, int32_t *tok, int *rows_taken, int *rows_kept, int64_t *bytes_consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
