@@ -6,7 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
-SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_parse_tensors")
+SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_parse_tensors", "clair_host_decode_rows")
 N_VALUES = 1056
 _lib = None
 
@@ -22,6 +22,8 @@ def load():
         lib.clair_host_last_error.restype = ctypes.c_char_p
         lib.clair_host_parse_tensors.argtypes = [vp, i64, i32, i32, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(i32),
                                                  ctypes.POINTER(i64)]
+        lib.clair_host_decode_rows.argtypes = [vp, vp, vp, vp, vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64,
+                                               ctypes.POINTER(i64), ctypes.POINTER(i32)]
         if lib.clair_host_abi_version() != 1:
             raise RuntimeError("libclair_host.so has ABI version %d, expected 1" % lib.clair_host_abi_version())
         _lib = lib
@@ -45,3 +47,32 @@ def parse_tensors(chunk, final, max_rows, x_out, row0):
         o = tok[k]
         infos.append([chunk[o[0]:o[0] + o[1]].decode(), chunk[o[2]:o[2] + o[3]].decode(), chunk[o[4]:o[4] + o[5]].decode()])
     return taken.value, infos, used.value
+
+
+def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2):
+    """clair_host_decode_rows over one batch -> list of VCF row strings (input order, skipped candidates left out)."""
+    lib = load()
+    n = len(infos)
+    if n == 0:
+        return []
+    x = np.ascontiguousarray(X, dtype=np.float32).reshape(n, N_VALUES)
+    gt21, genotype, len1, len2 = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
+    parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
+    lens = np.fromiter(map(len, parts), dtype=np.int32, count=3 * n)
+    tok = np.empty((n, 6), dtype=np.int32)
+    tok[:, 1::2] = lens.reshape(n, 3)
+    starts = np.cumsum(lens, dtype=np.int64) - lens
+    tok[:, 0::2] = starts.reshape(n, 3)
+    meta = "".join(parts).encode("ascii")
+    cap = 4096 + 256 * n + 2 * len(meta)
+    out = ctypes.create_string_buffer(cap)
+    out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)
+    rc = lib.clair_host_decode_rows(x.ctypes.data, gt21.ctypes.data, genotype.ctypes.data, len1.ctypes.data, len2.ctypes.data,
+                                    meta, tok.ctypes.data, n, int(bool(show_reference)), int(bool(haploid_precision)),
+                                    int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
+                                    int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows))
+    if rc != 0:
+        raise ValueError("native decode: " + lib.clair_host_last_error().decode())
+    if out_len.value == 0:
+        return []
+    return out.raw[:out_len.value - 1].decode("ascii").split("\n")

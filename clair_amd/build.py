@@ -22,7 +22,7 @@ def needs_build():
     return newest > os.path.getmtime(OUT)
 
 
-HOST_SRC = os.path.join(HERE, "hostsrc", "host_io.cpp")
+HOST_SRCS = [os.path.join(HERE, "hostsrc", f) for f in ("host_io.cpp", "host_decode.cpp")]
 HOST_OUT = os.path.join(HERE, "libclair_host.so")
 CXX = os.environ.get("CXX", "g++")
 
@@ -31,8 +31,9 @@ def build_host(force=False):
     """Host-side helpers (include/clair_host.h): plain C++, no HIP."""
     hdr = os.path.join(HERE, "..", "include", "clair_host.h")
     if (force or not os.path.isfile(HOST_OUT)
-            or max(os.path.getmtime(HOST_SRC), os.path.getmtime(hdr)) > os.path.getmtime(HOST_OUT)):
-        subprocess.check_call([CXX, "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", HOST_SRC, "-o", HOST_OUT])
+            or max([os.path.getmtime(f) for f in HOST_SRCS] + [os.path.getmtime(hdr)]) > os.path.getmtime(HOST_OUT)):
+        # -ffp-contract=off: the decode restates float32 product chains bit for bit (no fused multiply-add)
+        subprocess.check_call([CXX, "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wall"] + HOST_SRCS + ["-o", HOST_OUT])
     return HOST_OUT
 
 

@@ -415,15 +415,31 @@ def _debug_line(contig, position, gt21_row, genotype_row, l1_row, l2_row, note):
 class VariantDecoder(object):
     """batch_output / output_with (call_var.py:1002-1236): (X, infos, 4 prob arrays) -> text rows."""
 
-    def __init__(self, config, lookup=None, always_use_bam=False, arith="legacy"):
+    def __init__(self, config, lookup=None, always_use_bam=False, arith="legacy", native=True):
         if arith not in ("legacy", "numpy2"):
             raise ValueError("arith must be 'legacy' or 'numpy2'")
         self.cfg = config
         self.lookup = lookup if lookup is not None else AlignmentLookup()
         self.bases = IndelBases(self.lookup, always_use_bam)
         self.arith = arith
+        self.native = native
 
     def decode_batch(self, X, infos, Y):
+        """Rows of one batch.  The common configuration (no BAM look-ups, no --debug, no --output_for_ensemble) runs in the
+        native decoder (include/clair_host.h: clair_host_decode_rows, byte-identical, ~100x); everything else on the
+        Python restatement below."""
+        cfg = self.cfg
+        if (self.native and not cfg.is_debug and not cfg.is_output_for_ensemble and not self.bases.always_use_bam
+                and self.lookup.sam is None and isinstance(cfg.quality_score_for_pass, (int, type(None)))):
+            if len(Y[0]) != len(infos):
+                sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(Y[0])))
+            from clair_amd import _hostapi
+            return _hostapi.decode_rows(X, infos, Y, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
+                                        cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass,
+                                        self.arith == "numpy2")
+        return self.decode_batch_py(X, infos, Y)
+
+    def decode_batch_py(self, X, infos, Y):
         gt21, genotype, len1, len2 = [np.asarray(a, dtype=np.float32) for a in Y]
         if len(gt21) != len(infos):
             sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(gt21)))

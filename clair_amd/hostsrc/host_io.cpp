@@ -61,6 +61,17 @@ bool parse_value(const char *p, const char *end, float *out) {
 
 }  // namespace
 
+// shared with host_decode.cpp
+int clair_host_fail(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return 1;
+}
+
 extern "C" {
 
 int clair_host_abi_version(void) { return CLAIR_HOST_ABI_VERSION; }

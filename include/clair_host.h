@@ -34,6 +34,20 @@ const char *clair_host_last_error(void);
 int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_rows,
                              float *x, int32_t *tok, int *rows_taken, int *rows_kept, int64_t *bytes_consumed);
 
+/* -- decode: probabilities -> VCF rows, the work of clair/call_var.py:589-1236 (possible_outcome_probabilites_from, output_from,
+ *    output_with, batch_output) for one batch, in the configuration the GPU pipeline runs in: no BAM look-ups available (every
+ *    look-up answers "", the reference's own fall-back to tensor-inferred bases, :520-524, :562-564), no --debug, no
+ *    --output_for_ensemble.  x [n][1056] (channels 1..3 already minus channel 0), the four softmax arrays [n][21|3|33|33];
+ *    meta + meta_tok: per candidate the (offset, length) pairs of ctg, pos, refseq inside meta (the layout
+ *    clair_host_parse_tensors produces).  show_reference / haploid_* = the CLI flags (:1402-1429); qual_threshold < 0 = no
+ *    --qual (FILTER "."); arith_numpy2 selects how QUAL and AF are rounded (clair_amd/call_var.py "Arithmetic mode").
+ *    Rows are appended to out, each terminated by '\n', in input order; candidates that produce no row are skipped exactly as
+ *    the reference skips them.  Byte-identical to clair_amd.call_var.VariantDecoder (tests/test_host.py). */
+int clair_host_decode_rows(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
+                           const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
+                           int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
+                           int64_t *out_len, int *n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,3 +83,58 @@ def test_native_ingest_rejects_what_the_reference_rejects(tmp_path, mutation):
         _collect(utils.tensor_generator_from_py, path, 8)      # ValueError / IndexError in the reference's code path
     with pytest.raises(ValueError):
         _collect(utils.tensor_generator_from, path, 8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# native decode (clair_host_decode_rows) against the Python decoder, which tests/test_decode.py pins to the reference
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_probs(rng, n, k, peak):
+    logits = rng.standard_normal((n, k)).astype(np.float32) * peak
+    tie = rng.random(n) < 0.15                       # exact ties between two classes
+    logits[tie, 1] = logits[tie, 0]
+    e = np.exp(logits - logits.max(axis=1, keepdims=True)).astype(np.float32)
+    p = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    p[rng.random((n, k)) < 0.05] = 0.0               # exact zeros
+    return p
+
+
+@pytest.mark.parametrize("platform,peak", [("ont", 0.5), ("illumina", 2.0), ("pacbio_ccs", 6.0), ("ont", 12.0)])
+@pytest.mark.parametrize("arith", ["legacy", "numpy2"])
+def test_native_decode_equals_python_decode(platform, peak, arith):
+    from clair_amd import call_var as cvar
+    rng = np.random.default_rng(int(peak * 10) + len(platform))
+    n = 1500
+    x, infos = synth.synthetic_input(n, platform, seed=int(peak * 7) + 3)
+    infos = [list(i) for i in infos]
+    for k in range(0, n, 97):
+        infos[k][2] = infos[k][2][:16] + "N" + infos[k][2][17:]      # not callable: no row
+    for k in range(5, n, 131):
+        infos[k][2] = infos[k][2][:16] + "U" + infos[k][2][17:]
+    for k in range(9, n, 211):
+        x[k, 16, :, :] = 0                                           # read depth zero: no row
+    Y = [_random_probs(rng, n, 21, peak), _random_probs(rng, n, 3, peak), _random_probs(rng, n, 33, peak),
+         _random_probs(rng, n, 33, peak)]
+    configs = [cvar.OutputConfig(True, False, False, False, False, None), cvar.OutputConfig(False, False, False, False, False, 30),
+               cvar.OutputConfig(True, False, True, False, False, None), cvar.OutputConfig(False, False, False, True, False, 100)]
+    for cfg in configs:
+        native = cvar.VariantDecoder(cfg, arith=arith)
+        python = cvar.VariantDecoder(cfg, arith=arith, native=False)
+        try:
+            want = python.decode_batch(x, infos, Y)
+        except (ValueError, ZeroDivisionError):
+            with pytest.raises(ValueError):                          # numpy2 quality score at p == 1: both raise
+                native.decode_batch(x, infos, Y)
+            continue
+        assert native.decode_batch(x, infos, Y) == want
+
+
+def test_native_decode_is_bypassed_where_it_does_not_apply():
+    from clair_amd import call_var as cvar
+    x, infos = synth.synthetic_input(8, "ont", seed=1)
+    rng = np.random.default_rng(0)
+    Y = [_random_probs(rng, 8, k, 2.0) for k in (21, 3, 33, 33)]
+    debug = cvar.VariantDecoder(cvar.OutputConfig(True, True, False, False, False, None))
+    assert debug.decode_batch(x, infos, Y) == debug.decode_batch_py(x, infos, Y)          # --debug rows come from Python
+    ens = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, True, None))
+    assert ens.decode_batch(x, infos, Y) == ens.decode_batch_py(x, infos, Y)
+    assert cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None)).decode_batch(x[:0], [], [y[:0] for y in Y]) == []
