@@ -30,22 +30,23 @@ def load():
     return _lib
 
 
-def parse_tensors(chunk, final, max_rows, x_out, row0):
-    """Parse up to max_rows lines of `chunk` (bytes) into x_out[row0:] (float32 [*,1056], C-contiguous).
-    -> (rows_taken, infos of the kept rows as [[ctg, pos, seq], ...], bytes_consumed)"""
+def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):
+    """Parse up to max_rows lines of `chunk` (bytes), starting at byte `offset`, into x_out[row0:] (float32 [*,1056],
+    C-contiguous).  -> (rows_taken, infos of the kept rows as [[ctg, pos, seq], ...], bytes_consumed)"""
     lib = load()
     tok = np.empty((max(max_rows, 1), 6), dtype=np.int32)
     taken, kept, used = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
-    buf = ctypes.c_char_p(chunk)           # bytes: passed by pointer, no copy
-    rc = lib.clair_host_parse_tensors(buf, len(chunk), 1 if final else 0, max_rows,
+    base = ctypes.cast(ctypes.c_char_p(chunk), ctypes.c_void_p).value      # bytes: passed by pointer, no copy
+    rc = lib.clair_host_parse_tensors(base + offset, len(chunk) - offset, 1 if final else 0, max_rows,
                                       x_out[row0:].ctypes.data, tok.ctypes.data,
                                       ctypes.byref(taken), ctypes.byref(kept), ctypes.byref(used))
     if rc != 0:
         raise ValueError("malformed tensor record: " + lib.clair_host_last_error().decode())
     infos = []
-    for k in range(kept.value):
-        o = tok[k]
-        infos.append([chunk[o[0]:o[0] + o[1]].decode(), chunk[o[2]:o[2] + o[3]].decode(), chunk[o[4]:o[4] + o[5]].decode()])
+    if kept.value:
+        t = (tok[:kept.value].astype(np.int64) + np.array([offset, 0, offset, 0, offset, 0], dtype=np.int64)).tolist()
+        for o in t:
+            infos.append([chunk[o[0]:o[0] + o[1]].decode(), chunk[o[2]:o[2] + o[3]].decode(), chunk[o[4]:o[4] + o[5]].decode()])
     return taken.value, infos, used.value
 
 

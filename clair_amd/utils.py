@@ -49,9 +49,21 @@ def tensor_generator_from(tensor_file_path, batch_size):
     The text is parsed by the native helper (include/clair_host.h: clair_host_parse_tensors, ~20x the NumPy path below);
     `tensor_generator_from_py` is the line-by-line restatement of the reference it is tested against."""
     from clair_amd import _hostapi
+    import queue
+    import threading
     proc, stream = _open_source(tensor_file_path, binary=True)
+    chunks = queue.Queue(maxsize=4)
+
+    def reader():                                # decompressed text arrives while the previous chunk is being parsed
+        while True:
+            more = stream.read(1 << 23)
+            chunks.put(more)
+            if not more:
+                return
+
+    threading.Thread(target=reader, daemon=True).start()
     processed = 0
-    pending = b""
+    buf, off, lines_ahead = b"", 0, 0            # unparsed text = buf[off:], holding `lines_ahead` newline characters
     eof = exhausted = False
     while not exhausted:
         flat = np.empty((batch_size, N_VALUES), dtype=np.float32)
@@ -59,19 +71,21 @@ def tensor_generator_from(tensor_file_path, batch_size):
         taken = 0
         while taken < batch_size:
             need = batch_size - taken
-            while not eof and pending.count(b"\n") < need:
-                more = stream.read(1 << 23)
+            while not eof and lines_ahead < need:
+                more = chunks.get()
                 if more:
-                    pending += more
+                    buf, off = buf[off:] + more, 0
+                    lines_ahead += more.count(b"\n")
                 else:
                     eof = True
-            if not pending:                      # the reference's readline() returned '' (utils.py:75-77)
+            if off >= len(buf):                  # the reference's readline() returned '' (utils.py:75-77)
                 exhausted = True
                 break
-            t, inf, used = _hostapi.parse_tensors(pending, eof, need, flat, len(infos))
+            t, inf, used = _hostapi.parse_tensors(buf, eof, need, flat, len(infos), off)
             taken += t
             infos.extend(inf)
-            pending = pending[used:]
+            off += used
+            lines_ahead -= t
         n = len(infos)
         processed += n
         print("Processed %d tensors" % processed, file=sys.stderr)
