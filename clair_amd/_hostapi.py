@@ -6,7 +6,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
-SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_parse_tensors", "clair_host_decode_rows")
+SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_parse_tensors",
+           "clair_host_decode_rows")
 N_VALUES = 1056
 _lib = None
 

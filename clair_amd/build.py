@@ -33,7 +33,7 @@ def build_host(force=False):
     if (force or not os.path.isfile(HOST_OUT)
             or max([os.path.getmtime(f) for f in HOST_SRCS] + [os.path.getmtime(hdr)]) > os.path.getmtime(HOST_OUT)):
         # -ffp-contract=off: the decode restates float32 product chains bit for bit (no fused multiply-add)
-        subprocess.check_call([CXX, "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-Wall"] + HOST_SRCS + ["-o", HOST_OUT])
+        subprocess.check_call([CXX, "-O3", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", "-Wall"] + HOST_SRCS + ["-o", HOST_OUT])
     return HOST_OUT
 
 

@@ -15,8 +15,11 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 int clair_host_fail(const char *fmt, ...);   // host_io.cpp
+extern "C" int clair_host_threads(int work_items);
 
 namespace {
 
@@ -350,25 +353,47 @@ extern "C" int clair_host_decode_rows(const float *x, const float *gt21, const f
     if (!x || !gt21 || !genotype || !len1 || !len2 || !meta || !meta_tok || !out || !out_len || !n_rows || n < 0)
         return clair_host_fail("clair_host_decode_rows: bad arguments");
     Config cfg{show_reference, haploid_precision, haploid_sensitive, qual_threshold >= 0, qual_threshold, arith_numpy2};
-    static thread_local Families fam;
-    std::string buf;
-    buf.reserve((size_t)n * 64);
-    int rows = 0;
-    for (int i = 0; i < n; ++i) {
-        const int32_t *t = meta_tok + (size_t)i * 6;
-        const char *ctg = meta + t[0], *pos = meta + t[2], *seq = meta + t[4];
-        if (t[5] <= CENTER) return clair_host_fail("candidate %d: reference sequence has %d characters, the centre base is index 16", i, t[5]);
-        char *endp = nullptr;
-        std::string ptxt(pos, (size_t)t[3]);
-        const long long position = strtoll(ptxt.c_str(), &endp, 10);
-        if (endp == ptxt.c_str() || *endp) return clair_host_fail("candidate %d: position %s is not an integer", i, ptxt.c_str());
-        const size_t before = buf.size();
-        const int rc = decode_one(x + (size_t)i * CLAIR_HOST_VALUES, gt21 + (size_t)i * 21, genotype + (size_t)i * 3, len1 + (size_t)i * 33,
-                                  len2 + (size_t)i * 33, ctg, t[1], position, seq, t[5], cfg, fam, buf);
-        if (rc < 0) return 1;
-        if (rc == 1) { buf.push_back('\n'); ++rows; }
-        else buf.resize(before);
+    // candidates are independent: contiguous ranges per thread, rows concatenated in input order
+    const int nthreads = clair_host_threads(n);
+    std::vector<std::string> parts((size_t)nthreads), errs((size_t)nthreads);
+    std::vector<int> part_rows((size_t)nthreads, 0), err_at((size_t)nthreads, -1);
+    auto work = [&](int t) {
+        static thread_local Families fam;
+        const int lo = (int)((int64_t)n * t / nthreads), hi = (int)((int64_t)n * (t + 1) / nthreads);
+        std::string &buf = parts[(size_t)t];
+        buf.reserve((size_t)(hi - lo) * 64);
+        for (int i = lo; i < hi; ++i) {
+            const int32_t *tk = meta_tok + (size_t)i * 6;
+            const char *ctg = meta + tk[0], *pos = meta + tk[2], *seq = meta + tk[4];
+            int rc;
+            if (tk[5] <= CENTER) { clair_host_fail("candidate %d: reference sequence has %d characters, the centre base is index 16", i, tk[5]); rc = -1; }
+            else {
+                char *endp = nullptr;
+                const std::string ptxt(pos, (size_t)tk[3]);
+                const long long position = strtoll(ptxt.c_str(), &endp, 10);
+                if (endp == ptxt.c_str() || *endp) { clair_host_fail("candidate %d: position %s is not an integer", i, ptxt.c_str()); rc = -1; }
+                else {
+                    const size_t before = buf.size();
+                    rc = decode_one(x + (size_t)i * CLAIR_HOST_VALUES, gt21 + (size_t)i * 21, genotype + (size_t)i * 3, len1 + (size_t)i * 33,
+                                    len2 + (size_t)i * 33, ctg, tk[1], position, seq, tk[5], cfg, fam, buf);
+                    if (rc == 1) { buf.push_back('\n'); ++part_rows[(size_t)t]; }
+                    else buf.resize(before);
+                }
+            }
+            if (rc < 0) { errs[(size_t)t] = clair_host_last_error(); err_at[(size_t)t] = i; return; }   // thread-local message -> caller
+        }
+    };
+    if (nthreads <= 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
     }
+    for (int t = 0; t < nthreads; ++t)                       // the first failing candidate in input order
+        if (err_at[(size_t)t] >= 0) return clair_host_fail("%s", errs[(size_t)t].c_str());
+    std::string buf;
+    int rows = 0;
+    for (int t = 0; t < nthreads; ++t) { buf += parts[(size_t)t]; rows += part_rows[(size_t)t]; }
     if ((int64_t)buf.size() > out_cap) return clair_host_fail("clair_host_decode_rows: output needs %lld bytes, buffer has %lld", (long long)buf.size(), (long long)out_cap);
     memcpy(out, buf.data(), buf.size());
     *out_len = (int64_t)buf.size();

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -77,26 +79,54 @@ extern "C" {
 int clair_host_abi_version(void) { return CLAIR_HOST_ABI_VERSION; }
 const char *clair_host_last_error(void) { return g_error.c_str(); }
 
+int clair_host_threads(int work_items) {
+    // worker threads for one call: CLAIR_HOST_THREADS, else up to 16 hardware threads; small calls stay single-threaded
+    static const int configured = [] {
+        const char *e = getenv("CLAIR_HOST_THREADS");
+        int n = e ? atoi(e) : 0;
+        if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 16) n = 16; }
+        return n < 1 ? 1 : n;
+    }();
+    const int by_work = work_items / 128;
+    return by_work < 1 ? 1 : (by_work < configured ? by_work : configured);
+}
+
 int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_rows,
                              float *x, int32_t *tok, int *rows_taken, int *rows_kept, int64_t *bytes_consumed) {
     if (!buf || !x || !tok || !rows_taken || !rows_kept || !bytes_consumed || len < 0 || max_rows < 0)
         return fail("clair_host_parse_tensors: bad arguments");
     constexpr int NV = CLAIR_HOST_VALUES;
-    int taken = 0, kept = 0;
+    // pass 1: line boundaries of the lines to take
+    std::vector<int64_t> lstart, lend;
+    lstart.reserve((size_t)max_rows);
+    lend.reserve((size_t)max_rows);
     int64_t pos = 0;
-    // token boundaries of the current line: only the last NV + 3 matter, but a line has to have exactly NV + 3
-    static thread_local int32_t starts[NV + 8], ends[NV + 8];
-    while (taken < max_rows && pos < len) {
+    while ((int)lstart.size() < max_rows && pos < len) {
         const char *nl = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
-        int64_t line_end;
-        if (nl) line_end = nl - buf;
-        else if (final) line_end = len;
-        else break;                                   // incomplete last line: the caller supplies more text
-        float *row = x + (size_t)kept * NV;
-        // fast path: what CreateTensor writes -- three head tokens, then exactly 1056 plain decimal integers, single separators
+        if (!nl && !final) break;                     // incomplete last line: the caller supplies more text
+        const int64_t e = nl ? nl - buf : len;
+        lstart.push_back(pos);
+        lend.push_back(e);
+        pos = nl ? e + 1 : e;
+    }
+    const int taken = (int)lstart.size();
+    // pass 2: every line into the row slot of its line index (independent: threads), pass 3: drop the filtered rows
+    std::vector<signed char> state((size_t)taken, 0);   // 1 kept, 0 dropped, -1 malformed
+    std::vector<std::string> errors((size_t)taken);
+    std::vector<int32_t> ltok((size_t)taken * 6);
+    auto parse_line = [&](int li) {
+        int32_t starts[3], ends[3];
+        float *row = x + (size_t)li * NV;
+        const char *p = buf + lstart[li], *e = buf + lend[li];
+        auto bad = [&](const char *fmt, int a, int b) {
+            char msg[256];
+            snprintf(msg, sizeof msg, fmt, li, a, b);
+            errors[li] = msg;
+            state[li] = -1;
+        };
+        // fast path: what CreateTensor writes -- three head tokens, then exactly 1056 plain decimal integers
         bool fast_ok = false;
         {
-            const char *p = buf + pos, *e = buf + line_end;
             int t = 0;
             for (; t < 3; ++t) {
                 while (p < e && is_space((unsigned char)*p)) ++p;
@@ -124,39 +154,50 @@ int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_ro
                 }
             }
         }
-        if (!fast_ok) {
-        int ntok = 0;
-        bool too_many = false;
-        int64_t i = pos;
-        while (i < line_end) {
-            while (i < line_end && is_space((unsigned char)buf[i])) ++i;
-            if (i >= line_end) break;
-            const int64_t s = i;
-            while (i < line_end && !is_space((unsigned char)buf[i])) ++i;
-            if (ntok < NV + 8) { starts[ntok] = (int32_t)s; ends[ntok] = (int32_t)i; ++ntok; }
-            else too_many = true;
+        if (!fast_ok) {   // general path: tokenise the whole line, as str.split() does
+            std::vector<int32_t> ts, te;
+            int64_t i = lstart[li];
+            const int64_t line_end = lend[li];
+            while (i < line_end) {
+                while (i < line_end && is_space((unsigned char)buf[i])) ++i;
+                if (i >= line_end) break;
+                const int64_t s0 = i;
+                while (i < line_end && !is_space((unsigned char)buf[i])) ++i;
+                ts.push_back((int32_t)s0);
+                te.push_back((int32_t)i);
+                if ((int)ts.size() > NV + 8) break;
+            }
+            const int ntok = (int)ts.size();
+            if (ntok < NV) return bad("line %d: %d columns, fewer than the %d tensor values", ntok, NV);
+            if (ntok != NV + 3) return bad("line %d: %d columns before the %d tensor values, expected exactly 3 (ctg pos refseq)", ntok - NV, NV);
+            for (int t = 0; t < 3; ++t) { starts[t] = ts[t]; ends[t] = te[t]; }
+            for (int v = 0; v < NV; ++v)
+                if (!parse_value(buf + ts[3 + v], buf + te[3 + v], &row[v])) return bad("line %d: value %d is not a number%.0d", v, 0);
         }
-        if (too_many || ntok > NV + 3)
-            return fail("line %d: %s columns before the %d tensor values, expected exactly 3 (ctg pos refseq)", taken,
-                        "more than 3", NV);
-        if (ntok < NV)
-            return fail("line %d: %d columns, fewer than the %d tensor values", taken, ntok, NV);
-        if (ntok != NV + 3)
-            return fail("line %d: %d columns before the %d tensor values, expected exactly 3 (ctg pos refseq)", taken, ntok - NV, NV);
-        for (int v = 0; v < NV; ++v)
-            if (!parse_value(buf + starts[3 + v], buf + ends[3 + v], &row[v]))
-                return fail("line %d: value %d (\"%.*s\") is not a number", taken, v, (int)(ends[3 + v] - starts[3 + v]), buf + starts[3 + v]);
-        }
-        if (ends[2] - starts[2] <= 16)
-            return fail("line %d: reference sequence has %d characters, the centre base is index 16", taken, ends[2] - starts[2]);
-        ++taken;
-        pos = nl ? line_end + 1 : line_end;
-        if (!is_iupac((unsigned char)buf[starts[2] + 16])) continue;   // dropped: the row slot is reused
-        for (int g = 0; g < NV; g += 4) {                               // channels 1..3 -= channel 0
+        if (ends[2] - starts[2] <= 16) return bad("line %d: reference sequence has %d characters, the centre base is index 16%.0d", ends[2] - starts[2], 0);
+        for (int t = 0; t < 3; ++t) { ltok[(size_t)li * 6 + 2 * t] = starts[t]; ltok[(size_t)li * 6 + 2 * t + 1] = ends[t] - starts[t]; }
+        if (!is_iupac((unsigned char)buf[starts[2] + 16])) { state[li] = 0; return; }   // dropped (utils.py:90-91)
+        for (int g = 0; g < NV; g += 4) {                                               // channels 1..3 -= channel 0
             const float c0 = row[g];
             row[g + 1] -= c0; row[g + 2] -= c0; row[g + 3] -= c0;
         }
-        for (int t = 0; t < 3; ++t) { tok[kept * 6 + 2 * t] = starts[t]; tok[kept * 6 + 2 * t + 1] = ends[t] - starts[t]; }
+        state[li] = 1;
+    };
+    const int nthreads = clair_host_threads(taken);
+    if (nthreads <= 1) {
+        for (int li = 0; li < taken; ++li) parse_line(li);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] { for (int li = t; li < taken; li += nthreads) parse_line(li); });
+        for (auto &th : pool) th.join();
+    }
+    int kept = 0;
+    for (int li = 0; li < taken; ++li) {
+        if (state[li] < 0) return fail("%s", errors[li].c_str());       // the first malformed line, as a sequential parse reports it
+        if (state[li] == 0) continue;
+        if (kept != li) memmove(x + (size_t)kept * NV, x + (size_t)li * NV, NV * sizeof(float));
+        memcpy(tok + (size_t)kept * 6, &ltok[(size_t)li * 6], 6 * sizeof(int32_t));
         ++kept;
     }
     *rows_taken = taken;
