@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// ---- 2-way fp16 split of fp32 values (gemm_split.hip.h, lstm.hip.h) ------------------------------------
+// ---- 2-way fp16 split of fp32 values (gemm_split.hip.h, lstm32.hip.h, dense.hip.h) ------------------------------------
 // x ~= x1 + x2 with x1 = fp16(x), x2 = fp16(x - x1): 22 significand bits (relative error <= 2^-22, absolute
 // error <= 3e-8 once x2 falls into the fp16 subnormal range), round-to-nearest-even both times.  Products of
 // two fp16 values are exact in fp32, so  a*b ~= a1*b1 + a1*b2 + a2*b1  on v_mfma_f32_16x16x32_f16 (16x the

@@ -65,7 +65,7 @@ struct clair_engine {
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
     float *bx1 = nullptr, *bx2 = nullptr;   // gate-scaled biases [2][512] of the two layers
-    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr;   // fp16 split register images (lstm_split_kernel)
+    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr;   // fp16 split MFMA fragment images (lstm32.hip.h, dense.hip.h)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
     float *w3f = nullptr, *b3 = nullptr, *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
@@ -109,7 +109,7 @@ inline void split2_host(float x, unsigned short &hi, unsigned short &lo) {
 }
 
 // Factor folded into every LSTM gate column (and bias) so the MFMA result is the exp2 argument of the
-// gate's activation (lstm.hip.h): columns are i | c~ | f | o, 128 each.
+// gate's activation (lstm32.hip.h): columns are i | c~ | f | o, 128 each.
 inline float gate_scale(int col512) {
     const float L2E = 1.44269504088896340736f;
     return ((col512 >> 7) == 1) ? 2.0f * L2E : -L2E;
