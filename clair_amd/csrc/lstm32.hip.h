@@ -244,13 +244,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();   // zeros, Wx1 fragments and bias quads visible
     if (FIRST) load_seed(zq[0], 0, 0);
 
-    // Gate math of one block (4 elements per lane), as a static schedule of 24 "gaps" of 3-5 instructions: gap G
+    // Gate math of one block (4 elements per lane), as a static schedule of 23 "gaps" of 3-5 instructions: gap G
     // is issued right after MFMA G of the next block.  Within a gap all instructions are independent, every
     // operand was produced at least one gap earlier (no dependency stalls for the in-order wave) and at most
     // three are transcendental.
     //   acc holds exp2 arguments (pre-scaled rows): 2^-i, 2^(2 g), 2^-f, 2^-o  ->  registers eg/ei/ef/eo are
     //   reused as 1+e (A), its reciprocal (R) and k = K2 - 2 K2 rg (K); cell state c' = rf c' + ri k (T, C);
-    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HI, HF, D, LO).  Gap 24 packs the lane's four h
+    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HI, D, LO).  The last gap packs the lane's four h
     //   values into one 8-byte LDS store per plane.
     // Placement control.  A sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that
     // opens its gap; pinning its OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking
@@ -267,8 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define L32_OP_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); L32_PIN(ei[e]) }
 #define L32_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); L32_PIN(hh[e]) }
 #define L32_OP_HI(e) { hhi[e] = (_Float16)hh[e]; L32_PIN(hhi[e]) }
-#define L32_OP_HF(e) { tt[e] = (float)hhi[e]; L32_PIN(tt[e]) }
-#define L32_OP_D(e) { tt[e] = hh[e] - tt[e]; L32_PIN(tt[e]) }
+#define L32_OP_D(e) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hhi[e]));   /* h - float(hi) in one instruction: the fp16 operand converts on the fly */
 #define L32_OP_LO(e) { hlo[e] = (_Float16)tt[e]; L32_PIN(hlo[e]) }
 #define L32_GAP(G, PB)                                                                                            \
     {                                                                                                             \
@@ -295,17 +294,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             case 18: L32_OP_A(ei, 2) L32_OP_A(ei, 3) L32_OP_R(ei, 0) L32_OP_R(ei, 1) break;                       \
             case 19: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_H(0) L32_OP_H(1) break;                               \
             case 20: L32_OP_H(2) L32_OP_H(3) L32_OP_HI(0) L32_OP_HI(1) break;                                     \
-            case 21: L32_OP_HI(2) L32_OP_HI(3) L32_OP_HF(0) L32_OP_HF(1) break;                                   \
-            case 22: L32_OP_HF(2) L32_OP_HF(3) L32_OP_D(0) L32_OP_D(1) break;                                     \
-            case 23: L32_OP_D(2) L32_OP_D(3) L32_OP_LO(0) L32_OP_LO(1) break;                                     \
-            default: L32_OP_LO(2) L32_OP_LO(3)                                                                    \
+            case 21: L32_OP_HI(2) L32_OP_HI(3) L32_OP_D(0) L32_OP_D(1) break;                                     \
+            case 22: L32_OP_D(2) L32_OP_D(3) L32_OP_LO(0) L32_OP_LO(1) break;                                     \
+            default: L32_OP_LO(2) L32_OP_LO(3)   /* gap 23 */                                                      \
                      *(f16x4 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hhi[0], hhi[1], hhi[2], hhi[3]}; \
                      *(f16x4 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hlo[0], hlo[1], hlo[2], hlo[3]}; \
                      break;                                                                                       \
         }                                                                                                         \
     }
     // What goes into the gap after MFMA number M (0-based, NM per block) of block B: the previous block's gate
-    // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), its gap 24 behind the last MFMA, and in block 0 the copy-out of h_{s-1}.
+    // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), and in block 0 the copy-out of h_{s-1}.
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if ((B) == 0 && (M) % 3 == 0) { L32_STAMP(8 + (M) / 3) }                                                      \
@@ -314,7 +312,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if (L32_PROBE_ZQ) load_seed(zq[B], s + 1, B);                                                        \
     }                                                                                                             \
     if (L32_PROBE_GATES && (B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                  \
-    if (L32_PROBE_GATES && (B) > 0 && (M) == (NM) - 1) L32_GAP(24, (B) - 1)                                       \
     if ((M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */    \
     if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
@@ -387,7 +384,7 @@ _Pragma("unroll")                                                               
         asm volatile("s_nop 11" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 1; g <= 24; ++g) L32_GAP(g, 3)
+        for (int g = 1; g <= 23; ++g) L32_GAP(g, 3)
         L32_STAMP(5)
         __syncthreads();
         L32_STAMP(6)
@@ -405,7 +402,6 @@ _Pragma("unroll")                                                               
 #undef L32_OP_X
 #undef L32_OP_H
 #undef L32_OP_HI
-#undef L32_OP_HF
 #undef L32_OP_D
 #undef L32_OP_LO
 #undef L32_PIN
