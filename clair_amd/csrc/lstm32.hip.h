@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // three are transcendental.
     //   acc holds exp2 arguments (pre-scaled rows): 2^-i, 2^(2 g), 2^-f, 2^-o  ->  registers eg/ei/ef/eo are
     //   reused as 1+e (A), its reciprocal (R) and k = K2 - 2 K2 rg (K); cell state c' = rf c' + ri k (T, C);
-    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HI, D, LO).  The last gap packs the lane's four h
+    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HP, D, LP).  The last gap packs the lane's four h
     //   values into one 8-byte LDS store per plane.
     // Placement control.  A sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that
     // opens its gap; pinning its OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking
@@ -266,9 +266,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define L32_OP_M(e) { m2[e] = -2.0f * eo[e]; L32_PIN(m2[e]) }
 #define L32_OP_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); L32_PIN(ei[e]) }
 #define L32_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); L32_PIN(hh[e]) }
-#define L32_OP_HI(e) { hhi[e] = (_Float16)hh[e]; L32_PIN(hhi[e]) }
-#define L32_OP_D(e) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hhi[e]));   /* h - float(hi) in one instruction: the fp16 operand converts on the fly */
-#define L32_OP_LO(e) { hlo[e] = (_Float16)tt[e]; L32_PIN(hlo[e]) }
+    // fp16 split of h, two elements per instruction: v_cvt_pk_f16_f32 yields the packed pair the LDS store wants, the residual
+    // h - float(hi) is one v_fma_mix_f32 that converts the selected half on the fly
+#define L32_OP_HP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[q]) : "v"(hh[2 * (q)]), "v"(hh[2 * (q) + 1]));
+#define L32_OP_D(e) { if ((e) & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); \
+                      else asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); }
+#define L32_OP_LP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp[q]) : "v"(tt[2 * (q)]), "v"(tt[2 * (q) + 1]));
 #define L32_GAP(G, PB)                                                                                            \
     {                                                                                                             \
         const f32x16 &Z = acc[(PB) & 1];                                                                          \
@@ -293,12 +296,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             case 17: L32_OP_X(2) L32_OP_X(3) L32_OP_A(ei, 0) L32_OP_A(ei, 1) L32_OP_M(3) break;                   \
             case 18: L32_OP_A(ei, 2) L32_OP_A(ei, 3) L32_OP_R(ei, 0) L32_OP_R(ei, 1) break;                       \
             case 19: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_H(0) L32_OP_H(1) break;                               \
-            case 20: L32_OP_H(2) L32_OP_H(3) L32_OP_HI(0) L32_OP_HI(1) break;                                     \
-            case 21: L32_OP_HI(2) L32_OP_HI(3) L32_OP_D(0) L32_OP_D(1) break;                                     \
-            case 22: L32_OP_D(2) L32_OP_D(3) L32_OP_LO(0) L32_OP_LO(1) break;                                     \
-            default: L32_OP_LO(2) L32_OP_LO(3)   /* gap 23 */                                                      \
-                     *(f16x4 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hhi[0], hhi[1], hhi[2], hhi[3]}; \
-                     *(f16x4 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = (f16x4){hlo[0], hlo[1], hlo[2], hlo[3]}; \
+            case 20: L32_OP_H(2) L32_OP_H(3) L32_OP_HP(0) break;                                                  \
+            case 21: L32_OP_HP(1) L32_OP_D(0) L32_OP_D(1) break;                                                  \
+            case 22: L32_OP_D(2) L32_OP_D(3) L32_OP_LP(0) break;                                                  \
+            default: L32_OP_LP(1)   /* gap 23 */                                                                   \
+                     *(uint2 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(hp[0], hp[1]);      \
+                     *(uint2 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(lp[0], lp[1]);      \
                      break;                                                                                       \
         }                                                                                                         \
     }
@@ -369,7 +372,7 @@ _Pragma("unroll")                                                               
             load_x(xraw, s + 1 < T_POS ? s + 1 : s);
         }
         L32_STAMP(7)
-        _Float16 hhi[4], hlo[4];
+        unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
         float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
         const int s_prev = s > 0 ? s - 1 : 0;
         // x-part first (layer 1: K = 32 = two k-steps, Wx1 fragments from LDS), then the h-part (K = 128 = eight k-steps);
@@ -401,9 +404,9 @@ _Pragma("unroll")                                                               
 #undef L32_OP_M
 #undef L32_OP_X
 #undef L32_OP_H
-#undef L32_OP_HI
+#undef L32_OP_HP
+#undef L32_OP_LP
 #undef L32_OP_D
-#undef L32_OP_LO
 #undef L32_PIN
     copy_read(T_POS - 1);
 #pragma unroll
