@@ -196,34 +196,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
-    // ---- h_s (both planes complete in LDS) -> HBM; thread: row tid>>3, 16-unit chunk tid&7; split into an LDS
-    //      read and two convert+store halves so that the pieces can sit in different MFMA shadows
-    f16x8 ch[2][2];   // [half][plane]
+    // ---- h_s (both planes complete in LDS) -> HBM, as four pieces per thread laid out so that every wave-level store is one
+    //      contiguous run per row (a thread-per-row-chunk map made each store touch 64 quarter-filled 64-byte segments and cost
+    //      ~200 issue cycles; this way a store covers two whole 512-byte fp32 rows / four 256-byte fp16 rows).  Split into an LDS
+    //      read, conversion micro-steps and the stores so that the pieces can sit in different MFMA shadows.
+    //      layer 1: piece j = 16-byte chunk g = 256 j + tid of [plane][32 rows][16 chunks of 8 units]
+    //      layer 2: piece j = 16-byte chunk g = 256 j + tid of [32 rows][32 chunks of 4 units] (fp32 sum of the two planes)
+    f16x8 cp[FIRST ? 4 : 1];
+    f16x4 c4[FIRST ? 1 : 4][2];
+    f32x4 co[FIRST ? 1 : 4];
     auto copy_read = [&](int s) {
-        const int row = tid >> 3, c16 = tid & 7;
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) ch[half][pl] = *(const f16x8 *)&hbuf[s & 1][pl][row][c16 * 16 + half * 8];
+        for (int j = 0; j < 4; ++j) {
+            const int g = j * 256 + tid;
+            if (FIRST) cp[j] = *(const f16x8 *)&hbuf[s & 1][g >> 9][(g >> 4) & 31][(g & 15) * 8];
+            else {
+                c4[j][0] = *(const f16x4 *)&hbuf[s & 1][0][g >> 5][(g & 31) * 4];
+                c4[j][1] = *(const f16x4 *)&hbuf[s & 1][1][g >> 5][(g & 31) * 4];
+            }
+        }
     };
-    f32x4 co[2][2];   // layer 2: converted fp32 row pieces [half][4-unit quad pair]
     auto copy_cvt = [&](int i) {   // layer 2: micro-step i = 0..7 of the fp16-planes -> fp32 conversion: two units each
         if (FIRST) return;
-        const int half = i >> 2, q = i & 3;
-#pragma unroll
-        for (int j = 2 * q; j < 2 * q + 2; ++j) co[half][j >> 2][j & 3] = (float)ch[half][0][j] + (float)ch[half][1][j];
+        const int j = i >> 1, q = (i & 1) * 2;
+        co[j][q] = (float)c4[j][0][q] + (float)c4[j][1][q];
+        co[j][q + 1] = (float)c4[j][0][q + 1] + (float)c4[j][1][q + 1];
     };
-    auto copy_write = [&](int s, int half) {
+    auto copy_write = [&](int s, int j) {
         const int t = d ? T_POS - 1 - s : s;
-        const int row = tid >> 3, c16 = tid & 7;
-        const size_t off = ((size_t)t * p.n_pad + (size_t)tile * L32_TILE + row) * (2 * HID) + d * HID + c16 * 16 + half * 8;
+        const int g = j * 256 + tid;
+        const size_t row0 = ((size_t)t * p.n_pad + (size_t)tile * L32_TILE) * (2 * HID) + d * HID;
         if (FIRST) {
             const size_t plane = (size_t)T_POS * p.n_pad * (2 * HID);
-            *(f16x8 *)(p.aout2 + off) = ch[half][0];
-            *(f16x8 *)(p.aout2 + plane + off) = ch[half][1];
+            *(f16x8 *)(p.aout2 + (g >> 9) * plane + row0 + (size_t)((g >> 4) & 31) * (2 * HID) + (g & 15) * 8) = cp[j];
         } else {
-            *(f32x4 *)(p.aout + off) = co[half][0];
-            *(f32x4 *)(p.aout + off + 4) = co[half][1];
+            *(f32x4 *)(p.aout + row0 + (size_t)(g >> 5) * (2 * HID) + (g & 31) * 4) = co[j];
         }
     };
 
@@ -319,8 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
-        if ((M) == 12) copy_write(s_prev, 0);                                                                     \
-        if ((M) == 14) copy_write(s_prev, 1);                                                                     \
+        if ((M) >= 12 && (M) < 20 && ((M) & 1) == 0) copy_write(s_prev, ((M) - 12) >> 1);                          \
     }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
@@ -411,8 +417,8 @@ _Pragma("unroll")                                                               
     copy_read(T_POS - 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) copy_cvt(i);
-    copy_write(T_POS - 1, 0);
-    copy_write(T_POS - 1, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) copy_write(T_POS - 1, j);
 }
 
 }  // namespace clair
