@@ -67,7 +67,8 @@ __device__ long long *l32_stamps;   // [33 steps][16]
 constexpr int L32_TILE = 32;      // candidates per workgroup
 constexpr int HP_ROW = HID + 8;   // fp16 units per LDS row of one h plane: 272 B, conflict-free ds_read_b128 over 32 rows
 constexpr int L32_HBUF_BYTES = 2 * 2 * L32_TILE * HP_ROW * 2;                 // 34 816
-constexpr int L32_LDS_FIRST = L32_HBUF_BYTES + 4 * 4 * 2 * 2 * 64 * 16 + 4 * 4 * 4 * 2 * 16;   // + Wx1 fragments (64 KiB) + bias quads (2 KiB)
+constexpr int L32_XT_ROW = F_IN + 4;   // floats per row of the staged input tile (144 B pitch)
+constexpr int L32_LDS_FIRST = L32_HBUF_BYTES + 4 * 4 * 2 * 2 * 64 * 16 + 4 * 4 * 4 * 2 * 16 + 2 * L32_TILE * L32_XT_ROW * 4;   // + Wx1 fragments (64 KiB) + bias quads (2 KiB) + two input tiles (9 KiB)
 constexpr int L32_LDS_SECOND = L32_HBUF_BYTES;
 
 struct Lstm32Args {
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     _Float16 (*hbuf)[2][L32_TILE][HP_ROW] = (_Float16 (*)[2][L32_TILE][HP_ROW])lds_raw;   // [step parity][plane][cand][unit]
     _Float16 *wxl = (_Float16 *)(lds_raw + L32_HBUF_BYTES);             // FIRST: [wave][b][kk][plane][lane][8]
     float *bql = (float *)(lds_raw + L32_HBUF_BYTES + (FIRST ? 4 * 4 * 2 * 2 * 64 * 16 : 0));   // FIRST: [wave][b][a][h'][4]
+    float *xt = bql + (FIRST ? 4 * 4 * 4 * 2 * 4 : 0);                  // FIRST: [step parity][32 cand][L32_XT_ROW] input tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,16 +163,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int a = 0; a < 4; ++a) cst[b][a] = 0.0f;
 
-    // ---- layer 1 input: this lane's 16 features (16*kk + 8*h' .. +7, kk = 0,1) of its candidate at step s
-    const float *xrow = FIRST ? p.x + ((size_t)tile * L32_TILE + cand) * (T_POS * F_IN) + hq * 8 : nullptr;
-    auto load_x = [&](f32x4 (&xf)[4], int s) {
-        const int t = d ? T_POS - 1 - s : s;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            xf[kk * 2 + 0] = *(const f32x4 *)(xrow + t * F_IN + kk * 16);
-            xf[kk * 2 + 1] = *(const f32x4 *)(xrow + t * F_IN + kk * 16 + 4);
-        }
+    // ---- layer 1 input: x_t of the 32 candidates (4 KiB) goes through LDS -- ONE coalesced 16-byte load per thread and step
+    //      (row tid>>3, chunk tid&7), two steps ahead; every wave then reads its B fragments (features 16*kk + 8*h' .. +7 of
+    //      candidate lane%32) from the tile.  (Per-lane loads straight from [n][33][32] were four half-used-segment loads per
+    //      wave and step, the same data for all four waves.)
+    const float *xg = FIRST ? p.x + ((size_t)tile * L32_TILE + (tid >> 3)) * (T_POS * F_IN) + (tid & 7) * 4 : nullptr;
+    auto load_x = [&](int s) -> f32x4 {
+        const int sc = s < T_POS ? s : T_POS - 1;
+        return *(const f32x4 *)(xg + (d ? T_POS - 1 - sc : sc) * F_IN);
     };
+    auto stage_x = [&](const f32x4 &v, int s) { *(f32x4 *)&xt[((s & 1) * L32_TILE + (tid >> 3)) * L32_XT_ROW + (tid & 7) * 4] = v; };
     // ---- accumulator seeds (the C operand of a block's first MFMA)
     // layer 2: block b of step s of the x-projection, 4 x 16 bytes per lane; layer 1: the block's bias quads from LDS
     const float *zx0 = FIRST ? nullptr : p.zx + ((((size_t)d * p.ntiles + tile) * T_POS * 4 + w) * 4) * 1024 + lane * 4;
@@ -236,14 +238,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     f32x16 acc[2];        // block b accumulates in acc[b & 1]
     f32x16 zq[FIRST ? 1 : 4];   // seeds: layer 2 [b] = block b of the next step it is needed in; layer 1 [0] = next block's bias
-    f32x4 xraw[4];        // layer 1: next step's raw features
+    f32x4 xreg;           // layer 1: this thread's 16 bytes of x two steps ahead
     f16x8 xh[2], xl[2];   // layer 1: this step's B fragments (k-step kk), hi / lo plane
     f16x8 hf[8][2];       // B fragments of h_{s-1}: [kk][plane]
 
     // h_{-1} = 0: step 0 runs the same code as every other step (its h-part MFMAs add zero)
     for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) ((f32x4 *)&hbuf[1][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (FIRST) {
-        load_x(xraw, 0);
+        stage_x(load_x(0), 0);
+        xreg = load_x(1);
     } else {
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_seed(zq[b], 0, b);
@@ -366,16 +369,20 @@ _Pragma("unroll")                                                               
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
         if (FIRST) {
+            stage_x(xreg, s + 1);        // tile (s+1)&1 was last read at the head of step s-1, a barrier ago
+            xreg = load_x(s + 2);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                const float *xp = &xt[((s & 1) * L32_TILE + cand) * L32_XT_ROW + kk * 16 + hq * 8];
+                const f32x4 x0 = *(const f32x4 *)xp, x1 = *(const f32x4 *)(xp + 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     _Float16 u, v;
-                    split2(xraw[kk * 2 + (j >> 2)][j & 3], u, v);
+                    split2(j < 4 ? x0[j & 3] : x1[j & 3], u, v);
                     xh[kk][j] = u;
                     xl[kk][j] = v;
                 }
-            load_x(xraw, s + 1 < T_POS ? s + 1 : s);
+            }
         }
         L32_STAMP(7)
         unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
