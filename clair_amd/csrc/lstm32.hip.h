@@ -59,7 +59,11 @@ namespace clair {
 #endif
 #ifdef L32_PROBE   // tools/ubench/lstm32_probe.hip only: s_memtime stamps of workgroup 0, wave 0
 __device__ long long *l32_stamps;   // [33 steps][16]
+#ifdef L32_PROBE_NOSTAMP   // launch time only (for the -DL32_PROBE_* ablations)
+#define L32_STAMP(i)
+#else
 #define L32_STAMP(i) if (blockIdx.x == 0 && tid == 0) l32_stamps[s * 16 + (i)] = __builtin_readcyclecounter();
+#endif
 #else
 #define L32_STAMP(i)
 #endif
@@ -67,8 +71,8 @@ __device__ long long *l32_stamps;   // [33 steps][16]
 constexpr int L32_TILE = 32;      // candidates per workgroup
 constexpr int HP_ROW = HID + 8;   // fp16 units per LDS row of one h plane: 272 B, conflict-free ds_read_b128 over 32 rows
 constexpr int L32_HBUF_BYTES = 2 * 2 * L32_TILE * HP_ROW * 2;                 // 34 816
-constexpr int L32_XT_ROW = F_IN + 4;   // floats per row of the staged input tile (144 B pitch)
-constexpr int L32_LDS_FIRST = L32_HBUF_BYTES + 4 * 4 * 2 * 2 * 64 * 16 + 4 * 4 * 4 * 2 * 16 + 2 * L32_TILE * L32_XT_ROW * 4;   // + Wx1 fragments (64 KiB) + bias quads (2 KiB) + two input tiles (9 KiB)
+constexpr int L32_XT_ROW = F_IN + 8;   // fp16 per row of one plane of the staged input tile (80 B pitch)
+constexpr int L32_LDS_FIRST = L32_HBUF_BYTES + 4 * 4 * 2 * 2 * 64 * 16 + 4 * 4 * 4 * 2 * 16 + 2 * 2 * L32_TILE * L32_XT_ROW * 2;   // + Wx1 fragments (64 KiB) + bias quads (2 KiB) + two input tiles of two planes (10 KiB)
 constexpr int L32_LDS_SECOND = L32_HBUF_BYTES;
 
 struct Lstm32Args {
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     _Float16 (*hbuf)[2][L32_TILE][HP_ROW] = (_Float16 (*)[2][L32_TILE][HP_ROW])lds_raw;   // [step parity][plane][cand][unit]
     _Float16 *wxl = (_Float16 *)(lds_raw + L32_HBUF_BYTES);             // FIRST: [wave][b][kk][plane][lane][8]
     float *bql = (float *)(lds_raw + L32_HBUF_BYTES + (FIRST ? 4 * 4 * 2 * 2 * 64 * 16 : 0));   // FIRST: [wave][b][a][h'][4]
-    float *xt = bql + (FIRST ? 4 * 4 * 4 * 2 * 4 : 0);                  // FIRST: [step parity][32 cand][L32_XT_ROW] input tile
+    _Float16 *xt = (_Float16 *)(bql + (FIRST ? 4 * 4 * 4 * 2 * 4 : 0));   // FIRST: [step parity][plane][32 cand][L32_XT_ROW] input tile, already split
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,15 +168,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int a = 0; a < 4; ++a) cst[b][a] = 0.0f;
 
     // ---- layer 1 input: x_t of the 32 candidates (4 KiB) goes through LDS -- ONE coalesced 16-byte load per thread and step
-    //      (row tid>>3, chunk tid&7), two steps ahead; every wave then reads its B fragments (features 16*kk + 8*h' .. +7 of
-    //      candidate lane%32) from the tile.  (Per-lane loads straight from [n][33][32] were four half-used-segment loads per
-    //      wave and step, the same data for all four waves.)
+    //      (row tid>>3, chunk tid&7), a step ahead; the loading thread splits its four values into the two fp16 planes (eight VALU
+    //      instructions in block 0's free gaps) and every wave then reads its B fragments (features 16*kk + 8*h' .. +7 of
+    //      candidate lane%32) from the tile at the step head, next to the h fragments.  (Per-lane loads straight from [n][33][32]
+    //      were four half-used-segment loads per wave and step; splitting after the tile made every wave convert the same 16
+    //      values per lane at the exposed step head: 6 us of the kernel.)
     const float *xg = FIRST ? p.x + ((size_t)tile * L32_TILE + (tid >> 3)) * (T_POS * F_IN) + (tid & 7) * 4 : nullptr;
     auto load_x = [&](int s) -> f32x4 {
         const int sc = s < T_POS ? s : T_POS - 1;
         return *(const f32x4 *)(xg + (d ? T_POS - 1 - sc : sc) * F_IN);
     };
-    auto stage_x = [&](const f32x4 &v, int s) { *(f32x4 *)&xt[((s & 1) * L32_TILE + (tid >> 3)) * L32_XT_ROW + (tid & 7) * 4] = v; };
+    unsigned xp_hi[2], xp_lo[2];
+    float xres[4];
+    auto split_x = [&](const f32x4 &v, int part) {   // same arithmetic as split2: hi = fp16(x), lo = fp16(x - hi)
+        if (part == 0) {
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(xp_hi[0]) : "v"(v[0]), "v"(v[1]));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(xp_hi[1]) : "v"(v[2]), "v"(v[3]));
+        } else if (part == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(xres[e]) : "v"(v[e]), "v"(xp_hi[e >> 1]));
+                else asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(xres[e]) : "v"(v[e]), "v"(xp_hi[e >> 1]));
+            }
+        } else {
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(xp_lo[0]) : "v"(xres[0]), "v"(xres[1]));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(xp_lo[1]) : "v"(xres[2]), "v"(xres[3]));
+        }
+    };
+    auto stage_x = [&](int s) {
+        _Float16 *dst = &xt[(((s & 1) * 2 + 0) * L32_TILE + (tid >> 3)) * L32_XT_ROW + (tid & 7) * 4];
+        *(uint2 *)dst = make_uint2(xp_hi[0], xp_hi[1]);
+        *(uint2 *)(dst + L32_TILE * L32_XT_ROW) = make_uint2(xp_lo[0], xp_lo[1]);
+    };
     // ---- accumulator seeds (the C operand of a block's first MFMA)
     // layer 2: block b of step s of the x-projection, 4 x 16 bytes per lane; layer 1: the block's bias quads from LDS
     const float *zx0 = FIRST ? nullptr : p.zx + ((((size_t)d * p.ntiles + tile) * T_POS * 4 + w) * 4) * 1024 + lane * 4;
@@ -245,7 +272,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // h_{-1} = 0: step 0 runs the same code as every other step (its h-part MFMAs add zero)
     for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) ((f32x4 *)&hbuf[1][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (FIRST) {
-        stage_x(load_x(0), 0);
+        xreg = load_x(0);
+        split_x(xreg, 0);
+        split_x(xreg, 1);
+        split_x(xreg, 2);
+        stage_x(0);
         xreg = load_x(1);
     } else {
 #pragma unroll
@@ -331,6 +362,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
         if ((M) >= 12 && (M) < 20 && ((M) & 1) == 0) copy_write(s_prev, ((M) - 12) >> 1);                          \
     }                                                                                                             \
+    if (FIRST && (B) == 0) {   /* x_{s+1} (loaded a step ago): split, stage into the other tile (last read at the head of step s-1), fetch x_{s+2} */ \
+        if ((M) >= 20 && (M) <= 22) split_x(xreg, (M) - 20);                                                      \
+        if ((M) == 24) stage_x(s + 1);                                                                            \
+        if ((M) == 26) xreg = load_x(s + 2);                                                                      \
+    }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
 #define L32_BLOCK(b)                                                                                              \
@@ -369,19 +405,11 @@ _Pragma("unroll")                                                               
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
         if (FIRST) {
-            stage_x(xreg, s + 1);        // tile (s+1)&1 was last read at the head of step s-1, a barrier ago
-            xreg = load_x(s + 2);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const float *xp = &xt[((s & 1) * L32_TILE + cand) * L32_XT_ROW + kk * 16 + hq * 8];
-                const f32x4 x0 = *(const f32x4 *)xp, x1 = *(const f32x4 *)(xp + 4);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    _Float16 u, v;
-                    split2(j < 4 ? x0[j & 3] : x1[j & 3], u, v);
-                    xh[kk][j] = u;
-                    xl[kk][j] = v;
-                }
+                const _Float16 *xp = &xt[(((s & 1) * 2 + 0) * L32_TILE + cand) * L32_XT_ROW + kk * 16 + hq * 8];
+                xh[kk] = *(const f16x8 *)xp;
+                xl[kk] = *(const f16x8 *)(xp + L32_TILE * L32_XT_ROW);
             }
         }
         L32_STAMP(7)
