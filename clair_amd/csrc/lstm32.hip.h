@@ -268,6 +268,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x4 xreg;           // layer 1: this thread's 16 bytes of x two steps ahead
     f16x8 xh[2], xl[2];   // layer 1: this step's B fragments (k-step kk), hi / lo plane
     f16x8 hf[8][2];       // B fragments of h_{s-1}: [kk][plane]
+    f16x8 wxa[2][2][2];   // layer 1: A fragments of Wx1 for block b in [b & 1][kk][plane], fetched from LDS a block ahead
+    auto load_wx = [&](f16x8 (&dst)[2][2], int b) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dst[kk][pl] = *(const f16x8 *)&wxl[((((size_t)w * 4 + b) * 2 + kk) * 2 + pl) * 512 + lane * 8];
+    };
 
     // h_{-1} = 0: step 0 runs the same code as every other step (its h-part MFMAs add zero)
     for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) ((f32x4 *)&hbuf[1][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -283,7 +290,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int b = 0; b < 4; ++b) load_seed(zq[b], 0, b);
     }
     __syncthreads();   // zeros, Wx1 fragments and bias quads visible
-    if (FIRST) load_seed(zq[0], 0, 0);
+    if (FIRST) {
+        load_seed(zq[0], 0, 0);
+        load_wx(wxa[0], 0);
+    }
 
     // Gate math of one block (4 elements per lane), as a static schedule of 23 "gaps" of 3-5 instructions: gap G
     // is issued right after MFMA G of the next block.  Within a gap all instructions are independent, every
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
         if ((M) >= 12 && (M) < 20 && ((M) & 1) == 0) copy_write(s_prev, ((M) - 12) >> 1);                          \
     }                                                                                                             \
+    if (FIRST && (M) == 8) load_wx(wxa[((B) + 1) & 1], ((B) + 1) & 3);   /* the next block's Wx1 fragments (its first MFMA would wait for them) */ \
     if (FIRST && (B) == 0) {   /* x_{s+1} (loaded a step ago): split, stage into the other tile (last read at the head of step s-1), fetch x_{s+2} */ \
         if ((M) >= 20 && (M) <= 22) split_x(xreg, (M) - 20);                                                      \
         if ((M) == 24) stage_x(s + 1);                                                                            \
@@ -374,17 +385,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             constexpr int NM = FIRST ? 30 : 24;                                                                  \
             const f32x16 zold = zq[FIRST ? 0 : b];                                                               \
             if (FIRST) {                                                                                         \
-                f16x8 wxa[2][2];                                                                                 \
-_Pragma("unroll")                                                                                                \
-                for (int kk = 0; kk < 2; ++kk)                                                                   \
-_Pragma("unroll")                                                                                                \
-                    for (int pl = 0; pl < 2; ++pl)                                                               \
-                        wxa[kk][pl] = *(const f16x8 *)&wxl[((((size_t)w * 4 + b) * 2 + kk) * 2 + pl) * 512 + lane * 8]; \
 _Pragma("unroll")                                                                                                \
                 for (int m = 0; m < 6; ++m) {                                                                    \
                     const int kk = m / 3, term = m % 3;                                                          \
-                    if (m == 0) mfma32_vv_first(acc[b & 1], wxa[kk][1], xh[kk], zold);                           \
-                    else mfma32_vv(acc[b & 1], wxa[kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);         \
+                    if (m == 0) mfma32_vv_first(acc[b & 1], wxa[b & 1][kk][1], xh[kk], zold);                    \
+                    else mfma32_vv(acc[b & 1], wxa[b & 1][kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);  \
                     L32_AFTER_MFMA(m, NM, b)                                                                     \
                 }                                                                                                \
             }                                                                                                    \
