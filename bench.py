@@ -179,11 +179,11 @@ def main():
         value = total / elapsed
         kern = {k: {"ms_mean": (ms / cnt if cnt else None), "launches": cnt} for k, (ms, cnt) in times.items()}
         kern_iso = {k: round(ms / cnt, 5) if cnt else None for k, (ms, cnt) in times_iso.items()}
-        # dominant = most chip time: duration x share of the 256 CUs its grid can occupy (the recurrent kernels
-        # launch 2 workgroups per 32-candidate tile, one per CU: 64 CUs at batch 1024)
-        cu_share = {k: 1.0 for k in times_iso}
-        for k in ("lstm1", "lstm2"):
-            cu_share[k] = min(1.0, (batch + 31) // 32 * 2 / 256.0)
+        # dominant = most chip time: duration x share of the 256 CUs its grid occupies (the recurrent kernels
+        # launch 2 workgroups per 32-candidate tile, one per CU: 64 CUs at batch 1024; with several batches in
+        # flight the projection GEMM is launched on half the chip, see clair_engine_create)
+        wgs = eng.kernel_workgroups(batch)
+        cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in times_iso}
         dom = max(times_iso, key=lambda k: times_iso[k][0] * cu_share[k])
         dom_ms = times_iso[dom][0] / max(times_iso[dom][1], 1)
         ovl_ms = times[dom][0] / max(times[dom][1], 1)
@@ -210,7 +210,11 @@ def main():
             "note": "matmuls run as 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
             "measured": "HIP events on the kernel's stream, %d launches on one stream right after the timed region "
                         "(no other stream active)" % iso_steps,
-            "overlapped_kernel_ms": round(ovl_ms, 4)})
+            "overlapped_kernel_ms": round(ovl_ms, 4),
+            "workgroups": wgs[dom], "cu_share": round(cu_share[dom], 4),
+            "frac_of_cu_share": round(roof["frac"] / cu_share[dom], 4),
+            "cu_share_note": "the kernel is launched on this share of the 256 CUs (one persistent workgroup per CU) so that "
+                             "the other batches in flight run beside it; achieved/peak above are against the WHOLE chip"})
         path_tf = value / world * FLOP_PER_CANDIDATE / 1e12
         out = {
             "metric": "candidate sites/sec (whole node)",

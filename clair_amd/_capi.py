@@ -19,7 +19,7 @@ SYMBOLS = (
     "clair_predict", "clair_submit", "clair_wait",
     "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
     "clair_run_resident", "clair_sync",
-    "clair_timing_enable", "clair_kernel_times", "clair_timing_reset",
+    "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
     "clair_debug_read",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail")
@@ -64,6 +64,7 @@ def load():
     lib.clair_timing_enable.argtypes = [c_vp, c_int]
     lib.clair_kernel_times.argtypes = [c_vp, c_vp, c_vp]
     lib.clair_timing_reset.argtypes = [c_vp]
+    lib.clair_kernel_workgroups.argtypes = [c_vp, c_int, c_vp]
     lib.clair_debug_read.argtypes = [c_vp, c_int, c_int, c_vp, c_i64]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -181,6 +182,12 @@ class Engine(object):
         cnt = np.zeros(len(KERNEL_NAMES), dtype=np.int64)
         self._check(self._lib.clair_kernel_times(self._h, _ptr(ms), _ptr(cnt)), "clair_kernel_times")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    def kernel_workgroups(self, n):
+        """Workgroups each kernel is launched with for a batch of n candidates (its share of the 256 CUs)."""
+        wg = np.zeros(len(KERNEL_NAMES), dtype=np.int32)
+        self._check(self._lib.clair_kernel_workgroups(self._h, int(n), _ptr(wg)), "clair_kernel_workgroups")
+        return {k: int(wg[i]) for i, k in enumerate(KERNEL_NAMES)}
 
     def debug_read(self, slot, which, shape):
         out = np.empty(shape, dtype=np.float32)

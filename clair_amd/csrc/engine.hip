@@ -58,7 +58,7 @@ struct clair_engine {
     int max_pad = 0;
     bool weights_ready = false;
     bool timing = false;
-    int proj2_groups = 4;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 8 gate tiles x 4 = one workgroup per CU
+    int proj2_groups = 4;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 8 gate tiles x groups workgroups (see clair_engine_create)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<Slot> slots;
@@ -285,6 +285,11 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     e->max_batch = max_batch;
     e->max_pad = (max_batch + 31) & ~31;
     { const char *t = getenv("CLAIR_AMD_TAP_L3"); e->tap_l3 = t && t[0] == '1'; }
+    // A handle with one slot runs its kernels alone: the projection GEMM takes every CU (8 XCDs x 8 gate tiles x 4 groups).  With
+    // batches in flight on several slots the 64-workgroup recurrent kernels of the other slots hold whole CUs for ~80 us; a
+    // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Two groups (128
+    // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
+    e->proj2_groups = n_slots > 1 ? 2 : 4;
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
@@ -530,6 +535,20 @@ int clair_timing_reset(clair_engine_t *e) {
     HIP_TRY(e, hipSetDevice(e->device));
     if (drain_timers(e)) return 1;
     for (int k = 0; k < CLAIR_K_COUNT; ++k) { e->ms_sum[k] = 0; e->launches[k] = 0; }
+    return 0;
+}
+
+int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (!workgroups) return fail(e, "workgroups is NULL");
+    if (n < 1 || n > e->max_batch) return fail(e, "n %d out of range [1,%d]", n, e->max_batch);
+    const int n_pad = (n + 31) & ~31, ntiles = n_pad / 32;
+    const int x_tiles = (T_POS * n_pad + 127) / 128;
+    for (int k = 0; k < CLAIR_K_COUNT; ++k) workgroups[k] = 0;
+    workgroups[CLAIR_K_LSTM1] = workgroups[CLAIR_K_LSTM2] = ntiles * 2;
+    workgroups[CLAIR_K_PROJ2] = 64 * std::min(e->proj2_groups, (x_tiles + 7) / 8);
+    workgroups[CLAIR_K_L4] = (n_pad / L34_CAND) * L4_SPLITS;
+    workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
     return 0;
 }
 

@@ -130,6 +130,10 @@ int clair_sync(clair_engine_t *e);
 int clair_timing_enable(clair_engine_t *e, int on);
 int clair_kernel_times(clair_engine_t *e, double *ms_sum /*[CLAIR_K_COUNT]*/, int64_t *launches /*[CLAIR_K_COUNT]*/);
 int clair_timing_reset(clair_engine_t *e);
+/* Launch geometry: the number of 256-thread workgroups each kernel id is launched with for a batch of n candidates on this
+ * handle (0 for ids that launch nothing).  The recurrent kernels and, on handles with several slots, the projection GEMM are
+ * sized to PART of the chip so that the batches in flight on other slots run beside them; a per-kernel roofline needs that share. */
+int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups /*[CLAIR_K_COUNT]*/);
 
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
  *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
