@@ -7,7 +7,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_parse_tensors",
-           "clair_host_decode_rows")
+           "clair_host_decode_rows",
+           "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
+           "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats")
 N_VALUES = 1056
 _lib = None
 
@@ -25,8 +27,19 @@ def load():
                                                  ctypes.POINTER(i64)]
         lib.clair_host_decode_rows.argtypes = [vp, vp, vp, vp, vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                                ctypes.POINTER(i64), ctypes.POINTER(i32)]
-        if lib.clair_host_abi_version() != 1:
-            raise RuntimeError("libclair_host.so has ABI version %d, expected 1" % lib.clair_host_abi_version())
+        lib.clair_host_pileup_create.argtypes = [ctypes.c_char_p, i64, i64, vp, i64, i32, i32, i32, i32, i64, i32, ctypes.POINTER(vp)]
+        lib.clair_host_pileup_destroy.argtypes = [vp]
+        lib.clair_host_pileup_destroy.restype = None
+        lib.clair_host_pileup_feed.argtypes = [vp, vp, i64, i32, ctypes.POINTER(i64)]
+        lib.clair_host_pileup_finish.argtypes = [vp]
+        lib.clair_host_pileup_pending.argtypes = [vp]
+        lib.clair_host_pileup_pending.restype = i64
+        lib.clair_host_pileup_take.argtypes = [vp, i64, vp, vp, vp, ctypes.POINTER(i64)]
+        lib.clair_host_pileup_take_text.argtypes = [vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        lib.clair_host_pileup_stats.argtypes = [vp, vp]
+        if lib.clair_host_abi_version() != 2:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 2: run `python -m clair_amd.build`"
+                               % lib.clair_host_abi_version())
         _lib = lib
     return _lib
 
@@ -78,3 +91,91 @@ def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitiv
     if out_len.value == 0:
         return []
     return out.raw[:out_len.value - 1].decode("ascii").split("\n")
+
+
+class PileupBuilder(object):
+    """clair_host_pileup_*: the native twin of clair_amd.create_tensor.PileupBuilderPy (same constructor, same records)."""
+
+    def __init__(self, ctg_name, reference_sequence, reference_start_0_based, candidates, consider_left_edge=True,
+                 dcov=250, min_coverage=0, min_mq=0, available_slots=5000000, force_general_path=False):
+        self._lib = load()
+        self.ctg = ctg_name
+        ref = reference_sequence.encode("latin-1") if isinstance(reference_sequence, str) else bytes(reference_sequence)
+        cands = np.ascontiguousarray(candidates, dtype=np.int64)
+        h = ctypes.c_void_p()
+        rc = self._lib.clair_host_pileup_create(ref, len(ref), int(reference_start_0_based), cands.ctypes.data, len(cands),
+                                                int(bool(consider_left_edge)), int(dcov), int(min_coverage), int(min_mq),
+                                                int(available_slots), int(bool(force_general_path)), ctypes.byref(h))
+        if rc != 0:
+            raise ValueError("pileup: " + self._lib.clair_host_last_error().decode())
+        self._h = h
+        self._text = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.clair_host_pileup_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def feed(self, sam, final=False):
+        """Consume complete lines of `sam` (bytes or str); returns the unconsumed tail (same type)."""
+        data = sam.encode("latin-1") if isinstance(sam, str) else sam
+        used = ctypes.c_int64(0)
+        base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value
+        rc = self._lib.clair_host_pileup_feed(self._h, base, len(data), 1 if final else 0, ctypes.byref(used))
+        if rc != 0:
+            from .create_tensor import PileupError
+            raise PileupError(self._lib.clair_host_last_error().decode())
+        return sam[used.value:]
+
+    def finish(self):
+        self._lib.clair_host_pileup_finish(self._h)
+
+    def pending(self):
+        return int(self._lib.clair_host_pileup_pending(self._h))
+
+    def take_arrays(self, max_rows=None):
+        """-> (centres int64 [n], refseq list of str, counts int32 [n,33,8,4])"""
+        n = self.pending() if max_rows is None else min(self.pending(), int(max_rows))
+        centres = np.empty(n, dtype=np.int64)
+        seqs = np.zeros((n, 34), dtype=np.uint8)
+        counts = np.empty((n, 33, 8, 4), dtype=np.int32)
+        taken = ctypes.c_int64(0)
+        if n:
+            self._lib.clair_host_pileup_take(self._h, n, centres.ctypes.data, seqs.ctypes.data, counts.ctypes.data, ctypes.byref(taken))
+        raw = seqs.tobytes()
+        return centres, [raw[i * 34:i * 34 + 34].split(b"\0", 1)[0].decode("latin-1") for i in range(n)], counts
+
+    def take(self):
+        centres, seqs, counts = self.take_arrays()
+        return [(int(c), s, counts[i]) for i, (c, s) in enumerate(zip(centres, seqs))]
+
+    def take_text(self, cap=1 << 24):
+        """Finished windows as text records (bytes), as many as fit in `cap` bytes; b"" when none is pending."""
+        if self._text is None or len(self._text) < cap:
+            self._text = ctypes.create_string_buffer(cap)
+        n, taken = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._lib.clair_host_pileup_take_text(self._h, self.ctg.encode(), self._text, cap, ctypes.byref(n), ctypes.byref(taken))
+        return self._text.raw[:n.value]
+
+    def stats(self):
+        st = np.zeros(4, dtype=np.int64)
+        self._lib.clair_host_pileup_stats(self._h, st.ctypes.data)
+        return {"reads": int(st[0]), "open_windows": int(st[1]), "slots_left": int(st[2]), "sorted_path": bool(st[3])}
+
+    def text_from_sam(self, handle, chunk_bytes=1 << 22):
+        """Feed a SAM stream (binary or text file object); yield the finished records as text chunks (str)."""
+        tail = None
+        while True:
+            chunk = handle.read(chunk_bytes)
+            if not chunk:
+                break
+            tail = self.feed(chunk if tail is None else tail + chunk)
+            while self.pending():
+                yield self.take_text().decode("latin-1")
+        if tail:
+            self.feed(tail, final=True)
+        self.finish()
+        while self.pending():
+            yield self.take_text().decode("latin-1")

@@ -22,7 +22,7 @@ def needs_build():
     return newest > os.path.getmtime(OUT)
 
 
-HOST_SRCS = [os.path.join(HERE, "hostsrc", f) for f in ("host_io.cpp", "host_decode.cpp")]
+HOST_SRCS = [os.path.join(HERE, "hostsrc", f) for f in ("host_io.cpp", "host_decode.cpp", "host_pileup.cpp")]
 HOST_OUT = os.path.join(HERE, "libclair_host.so")
 CXX = os.environ.get("CXX", "g++")
 

@@ -1,0 +1,463 @@
+// Host-side helpers of the Clair hot path (include/clair_host.h): native pileup tensor generation.  Plain C++17, no HIP.
+//
+// Restates the main loop of the reference's dataPrepScripts/CreateTensor.py (OutputAlnTensor :251-388 and generate_tensor
+// :29-65) as a streaming builder: SAM text in, finished [33][8][4] count windows out.  See clair_amd/create_tensor.py for
+// the semantics in prose and for PileupBuilderPy, the Python twin this file is pinned against (tests/test_pileup.py); both
+// are pinned against records minted from the real script (tests/golden/pileup_ct_*.json.gz).
+//
+// Differences in mechanism, not in result:
+//   * the reference stores a (position, advance, ref base, read base, strand) tuple per window and read base and sums
+//     them when the window is written; here the four counters are bumped while the read is walked (the sum does not
+//     depend on order) and only the NUMBER of tuples is kept, for the reference's budget of outstanding tuples;
+//   * begin_to_end (reference position -> windows that may open there) is a Python dict holding 34 entries per candidate
+//     forever; for a sorted candidate list -- the normal case -- the same answer is the index range of loaded candidates
+//     within [position-16, position+17], tracked with two cursors per read.  Unsorted lists take a hash-map path that
+//     mirrors the dict.
+#include "../../include/clair_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+int clair_host_fail(const char *fmt, ...);   // host_io.cpp
+
+namespace {
+
+constexpr int FLANK = 16;                 // shared/param.py:9
+constexpr int N_POS = 2 * FLANK + 1;      // 33
+constexpr int N_VAL = N_POS * 8 * 4;      // 1056
+constexpr int64_t LOOKAHEAD = 100000;     // CreateTensor.py:275
+
+inline bool is_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+
+// IUPAC_base_to_num_dict (shared/utils.py:24-27); -1: not a key
+struct BaseTable {
+    signed char num[256];
+    BaseTable() {
+        memset(num, -1, sizeof num);
+        const char *keys = "ACGTURYSWKMBDHVN";
+        const int vals[16] = {0, 1, 2, 3, 3, 0, 1, 1, 0, 2, 0, 1, 0, 0, 0, 0};
+        for (int i = 0; i < 16; ++i) num[(unsigned char)keys[i]] = (signed char)vals[i];
+    }
+};
+const BaseTable BASE;
+
+struct Window {
+    int64_t centre = 0;
+    int64_t used = 0;        // tuples the reference would be holding for this window
+    uint64_t order = 0;      // first-touch sequence number: the reference writes windows in dict insertion order
+    int64_t depth_centre = 0;
+    int32_t counts[N_VAL];
+};
+
+struct Record {
+    int64_t centre;
+    int seq_len;
+    char seq[N_POS + 1];
+    int32_t counts[N_VAL];
+};
+
+struct Active {
+    int64_t centre;
+    Window *win;
+};
+
+}  // namespace
+
+struct clair_pileup {
+    std::string ref;
+    int64_t ref0 = 0;
+    std::vector<int64_t> cands;
+    bool sorted = true;
+    bool left_edge = true;
+    int dcov = 250, min_cov = 0, min_mq = 0;
+    int64_t slots = 5000000;
+    // candidate generator state (CreateTensor.py:68-109, 219, 274-275)
+    size_t next_cand = 0;
+    int64_t cand_pos = 0;
+    // general path only: begin_to_end as the reference builds it
+    std::unordered_map<int64_t, std::vector<int64_t>> begin;   // position -> centres, in load order
+    // live windows by centre (ordered: a flush takes a prefix), pool behind them
+    std::map<int64_t, Window *> live;
+    std::vector<Window *> pool;
+    uint64_t next_order = 0;
+    int64_t prev_pos = 0;
+    int64_t depth_cap = 0;
+    std::deque<Record> out;
+    std::vector<Active> active;            // per read
+    std::vector<Window *> flushed;         // scratch
+    int64_t reads_seen = 0;
+
+    ~clair_pileup() {
+        for (auto &kv : live) delete kv.second;
+        for (Window *w : pool) delete w;
+    }
+
+    Window *new_window(int64_t centre) {
+        Window *w;
+        if (!pool.empty()) { w = pool.back(); pool.pop_back(); }
+        else w = new Window;
+        w->centre = centre;
+        w->used = 0;
+        w->depth_centre = 0;
+        w->order = next_order++;
+        memset(w->counts, 0, sizeof w->counts);
+        return w;
+    }
+
+    void load_candidates(int64_t limit) {
+        while (cand_pos != -1 && cand_pos < limit) {
+            if (next_cand >= cands.size()) { cand_pos = -1; break; }
+            const int64_t p = cands[next_cand++];
+            if (!sorted) {
+                if (left_edge) {
+                    for (int64_t i = p - (FLANK + 1); i < p + (FLANK + 1); ++i) begin[i].push_back(p);
+                } else {
+                    auto &v = begin[p - (FLANK + 1)];
+                    v.assign(1, p);
+                }
+            }
+            cand_pos = p;
+        }
+    }
+
+    // reference_sequence[reference_position - reference_start_0_based] with Python's negative-index wrap
+    bool ref_base(int64_t rp, char *out) {
+        int64_t i = rp - ref0;
+        if (i < 0) i += (int64_t)ref.size();
+        if (i < 0 || i >= (int64_t)ref.size()) {
+            clair_host_fail("reference position %lld is outside the loaded reference sequence", (long long)(rp + 1));
+            return false;
+        }
+        *out = ref[(size_t)i];
+        return true;
+    }
+
+    void open_window(int64_t centre) {
+        for (const Active &a : active)
+            if (a.centre == centre) return;
+        auto it = live.find(centre);
+        Window *w;
+        if (it == live.end()) {
+            w = new_window(centre);
+            live.emplace(centre, w);
+        } else {
+            w = it->second;
+        }
+        // keep `active` in ascending centre order (the sorted path appends in that order anyway)
+        auto pos = active.end();
+        if (!active.empty() && active.back().centre > centre)
+            pos = std::lower_bound(active.begin(), active.end(), centre, [](const Active &a, int64_t c) { return a.centre < c; });
+        active.insert(pos, Active{centre, w});
+    }
+
+    void close_window_ending_at(int64_t rp) {
+        const int64_t centre = rp - (FLANK + 1);
+        for (size_t i = 0; i < active.size(); ++i)
+            if (active[i].centre == centre) { active.erase(active.begin() + (long)i); return; }
+    }
+
+    // one tuple of the reference's alignment lists applied to one window (generate_tensor :34-56)
+    inline void count(Window *w, int64_t rp, int64_t query_adv, char rb, char qb, int so) {
+        w->used += 1;
+        slots -= 1;
+        const int rn = rb == '-' ? -2 : BASE.num[(unsigned char)rb], qn = qb == '-' ? -2 : BASE.num[(unsigned char)qb];
+        if (rn == -1 || qn == -1) return;
+        int64_t idx = rp - w->centre + (FLANK + 1);
+        if (idx < 0 || idx >= N_POS) return;
+        if (qn >= 0 && rn >= 0) {
+            int32_t *r = w->counts + (idx * 8 + rn + so) * 4, *q = w->counts + (idx * 8 + qn + so) * 4;
+            r[0] += 1;
+            q[1] += 1;
+            r[2] += 1;
+            q[3] += 1;
+            if (idx == FLANK) w->depth_centre += 1;
+        } else if (qn >= 0) {
+            idx = std::min<int64_t>(idx + query_adv, N_POS - 1);
+            w->counts[(idx * 8 + qn + so) * 4 + 1] += 1;
+        } else {
+            w->counts[(idx * 8 + rn + so) * 4 + 2] += 1;
+        }
+    }
+
+    void finish_window(Window *w) {
+        const int64_t nrp = w->centre - ref0;
+        if (nrp - (FLANK + 1) < 0 || w->depth_centre < min_cov) return;
+        // reference_sequence[nrp-17 : nrp+16]: a Python slice, clamped to the string
+        const int64_t a = std::min<int64_t>(nrp - (FLANK + 1), (int64_t)ref.size());
+        const int64_t b = std::min<int64_t>(nrp + FLANK, (int64_t)ref.size());
+        out.emplace_back();
+        Record &r = out.back();
+        r.centre = w->centre;
+        r.seq_len = (int)std::max<int64_t>(0, b - a);
+        memcpy(r.seq, ref.data() + a, (size_t)r.seq_len);
+        r.seq[r.seq_len] = 0;
+        memcpy(r.counts, w->counts, sizeof r.counts);
+    }
+
+    int add_read(int flag, int64_t pos1, int64_t mapq, const char *cigar, size_t cigar_len, char *seq, size_t seq_len) {
+        const int64_t pos = pos1 - 1;
+        for (size_t i = 0; i < seq_len; ++i)
+            if (seq[i] >= 'a' && seq[i] <= 'z') seq[i] = (char)(seq[i] - 32);
+        const int so = (flag & 16) ? 4 : 0;
+        if (mapq < min_mq) return 0;
+        load_candidates(pos + (int64_t)seq_len + LOOKAHEAD);
+        if (prev_pos != pos) {
+            prev_pos = pos;
+            depth_cap = 0;
+        } else {
+            depth_cap += 1;
+            if (depth_cap >= dcov) return 0;
+        }
+        active.clear();
+        int64_t rp = pos, qp = 0, adv = 0;
+        // sorted path: candidates [0, next_cand) are loaded; those within [rp-16, rp+17] may open at rp (left-edge mode), or
+        // the one at rp+17 (otherwise).  `seen` = loaded candidates already offered to this read.
+        size_t seen = 0;
+        if (sorted) {
+            const int64_t first = left_edge ? rp - FLANK : rp + (FLANK + 1);
+            seen = (size_t)(std::lower_bound(cands.begin(), cands.begin() + (long)next_cand, first) - cands.begin());
+        }
+        auto open_at = [&](int64_t p) {
+            if (sorted) {
+                const int64_t last = p + (FLANK + 1);
+                if (!left_edge)
+                    while (seen < next_cand && cands[seen] < last) ++seen;   // passed over without being walked at p-17
+                while (seen < next_cand && cands[seen] <= last) open_window(cands[seen++]);
+            } else {
+                auto it = begin.find(p);
+                if (it != begin.end())
+                    for (int64_t centre : it->second) open_window(centre);
+            }
+        };
+        for (size_t ci = 0; ci < cigar_len; ++ci) {
+            if (slots <= 0) break;
+            const char ch = cigar[ci];
+            if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); continue; }
+            if (ch == 'S') qp += adv;
+            if (ch == 'M' || ch == '=' || ch == 'X') {
+                for (int64_t k = 0; k < adv; ++k) {
+                    open_at(rp);
+                    if (!active.empty() && slots > 0) {
+                        if (qp >= (int64_t)seq_len) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%zu bases)", (long long)pos1, seq_len);
+                        char rb;
+                        if (!ref_base(rp, &rb)) return 1;
+                        const char qb = seq[qp];
+                        for (const Active &a : active) {
+                            if (slots <= 0) break;
+                            count(a.win, rp, 0, rb, qb, so);
+                        }
+                    }
+                    if (!active.empty() && active.front().centre <= rp - (FLANK + 1)) close_window_ending_at(rp);
+                    ++rp;
+                    ++qp;
+                }
+            }
+            if (ch == 'I') {
+                for (int64_t k = 0; k < adv; ++k) {
+                    if (!active.empty() && slots > 0) {
+                        if (qp >= (int64_t)seq_len) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%zu bases)", (long long)pos1, seq_len);
+                        const char qb = seq[qp];
+                        for (const Active &a : active) {
+                            if (slots <= 0) break;
+                            count(a.win, rp, k, '-', qb, so);
+                        }
+                    }
+                    ++qp;
+                }
+            }
+            if (ch == 'D') {
+                for (int64_t k = 0; k < adv; ++k) {
+                    if (!active.empty() && slots > 0) {
+                        char rb;
+                        if (!ref_base(rp, &rb)) return 1;
+                        for (const Active &a : active) {
+                            if (slots <= 0) break;
+                            count(a.win, rp, 0, rb, '-', so);
+                        }
+                    }
+                    open_at(rp);
+                    if (!active.empty() && active.front().centre <= rp - (FLANK + 1)) close_window_ending_at(rp);
+                    ++rp;
+                }
+            }
+            adv = 0;
+        }
+        if (depth_cap == 0) {   // a new start position: every window with centre + 17 < POS is complete
+            flushed.clear();
+            auto it = live.begin();
+            while (it != live.end() && it->first + (FLANK + 1) < pos) {
+                flushed.push_back(it->second);
+                it = live.erase(it);
+            }
+            std::sort(flushed.begin(), flushed.end(), [](const Window *a, const Window *b) { return a->order < b->order; });
+            for (Window *w : flushed) {
+                finish_window(w);
+                slots += w->used;
+                pool.push_back(w);
+            }
+        }
+        ++reads_seen;
+        return 0;
+    }
+
+    int add_line(const char *p, const char *end, int64_t line_no) {
+        // str.split(): columns 1, 3, 4, 5, 9 of a whitespace-separated line (CreateTensor.py:252-263)
+        const char *col[10];
+        size_t len[10];
+        int n = 0;
+        while (p < end && n < 10) {
+            while (p < end && is_space((unsigned char)*p)) ++p;
+            if (p >= end) break;
+            const char *q = p;
+            while (q < end && !is_space((unsigned char)*q)) ++q;
+            col[n] = p;
+            len[n] = (size_t)(q - p);
+            ++n;
+            p = q;
+        }
+        if (n == 0) return clair_host_fail("alignment line %lld is empty", (long long)line_no);
+        if (col[0][0] == '@') return 0;
+        if (n < 10) return clair_host_fail("alignment line %lld has %d columns (11 expected)", (long long)line_no, n);
+        int64_t v[3];
+        const int which[3] = {1, 3, 4};
+        for (int i = 0; i < 3; ++i) {
+            const char *s = col[which[i]], *e = s + len[which[i]];
+            bool neg = false;
+            if (s < e && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
+            if (s == e || e - s > 18) return clair_host_fail("alignment line %lld: column %d is not an integer", (long long)line_no, which[i] + 1);
+            int64_t x = 0;
+            for (; s < e; ++s) {
+                if (*s < '0' || *s > '9') return clair_host_fail("alignment line %lld: column %d is not an integer", (long long)line_no, which[i] + 1);
+                x = x * 10 + (*s - '0');
+            }
+            v[i] = neg ? -x : x;
+        }
+        scratch_seq.assign(col[9], len[9]);
+        return add_read((int)v[0], v[1], v[2], col[5], len[5], scratch_seq.data(), scratch_seq.size());
+    }
+    std::string scratch_seq;
+    int64_t lines_seen = 0;
+};
+
+extern "C" {
+
+int clair_host_pileup_create(const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based, const int64_t *candidates,
+                             int64_t n_candidates, int consider_left_edge, int dcov, int min_coverage, int min_mq,
+                             int64_t available_slots, int force_general_path, clair_pileup_t **out) {
+    if (!out) return clair_host_fail("out is NULL");
+    *out = nullptr;
+    if (!ref_seq || ref_len < 0) return clair_host_fail("reference sequence missing");
+    if (n_candidates < 0 || (n_candidates > 0 && !candidates)) return clair_host_fail("candidate list missing");
+    clair_pileup *p = new clair_pileup;
+    p->ref.assign(ref_seq, (size_t)ref_len);
+    p->ref0 = reference_start_0_based;
+    p->cands.assign(candidates, candidates + n_candidates);
+    p->sorted = !force_general_path && std::is_sorted(p->cands.begin(), p->cands.end());
+    p->left_edge = consider_left_edge != 0;
+    p->dcov = dcov;
+    p->min_cov = min_coverage;
+    p->min_mq = min_mq;
+    p->slots = available_slots;
+    *out = p;
+    return 0;
+}
+
+void clair_host_pileup_destroy(clair_pileup_t *p) { delete p; }
+
+int clair_host_pileup_feed(clair_pileup_t *p, const char *sam, int64_t len, int final, int64_t *bytes_consumed) {
+    if (!p || (!sam && len > 0) || !bytes_consumed) return clair_host_fail("bad argument");
+    int64_t at = 0;
+    while (at < len) {
+        const char *nl = (const char *)memchr(sam + at, '\n', (size_t)(len - at));
+        if (!nl && !final) break;
+        const char *end = nl ? nl : sam + len;
+        if (p->add_line(sam + at, end, p->lines_seen)) { *bytes_consumed = at; return 1; }
+        ++p->lines_seen;
+        at = (nl ? nl + 1 : end) - sam;
+    }
+    *bytes_consumed = at;
+    return 0;
+}
+
+int clair_host_pileup_finish(clair_pileup_t *p) {
+    if (!p) return clair_host_fail("bad argument");
+    // the reference's closing loop (CreateTensor.py:375-382): what is left, in first-touch order
+    p->flushed.clear();
+    for (auto &kv : p->live) p->flushed.push_back(kv.second);
+    p->live.clear();
+    std::sort(p->flushed.begin(), p->flushed.end(), [](const Window *a, const Window *b) { return a->order < b->order; });
+    for (Window *w : p->flushed) {
+        p->finish_window(w);
+        p->pool.push_back(w);
+    }
+    return 0;
+}
+
+int64_t clair_host_pileup_pending(const clair_pileup_t *p) { return p ? (int64_t)p->out.size() : 0; }
+
+int clair_host_pileup_take(clair_pileup_t *p, int64_t max_rows, int64_t *centres, char *refseq, int32_t *counts, int64_t *n_taken) {
+    if (!p || !centres || !refseq || !counts || !n_taken || max_rows < 0) return clair_host_fail("bad argument");
+    int64_t n = 0;
+    while (n < max_rows && !p->out.empty()) {
+        const Record &r = p->out.front();
+        centres[n] = r.centre;
+        memset(refseq + n * (N_POS + 1), 0, N_POS + 1);
+        memcpy(refseq + n * (N_POS + 1), r.seq, (size_t)r.seq_len);
+        memcpy(counts + n * N_VAL, r.counts, sizeof r.counts);
+        p->out.pop_front();
+        ++n;
+    }
+    *n_taken = n;
+    return 0;
+}
+
+int clair_host_pileup_take_text(clair_pileup_t *p, const char *ctg_name, char *out, int64_t cap, int64_t *out_len, int64_t *n_taken) {
+    if (!p || !ctg_name || !out || !out_len || !n_taken) return clair_host_fail("bad argument");
+    const size_t ctg_len = strlen(ctg_name);
+    // worst case per record: ctg + ' ' + 20 digits + ' ' + 33 + 1056 * (1 + 11) + '\n'
+    const int64_t worst = (int64_t)ctg_len + 1 + 20 + 1 + N_POS + (int64_t)N_VAL * 12 + 1;
+    int64_t at = 0, n = 0;
+    while (!p->out.empty() && cap - at >= worst) {
+        const Record &r = p->out.front();
+        memcpy(out + at, ctg_name, ctg_len);
+        at += (int64_t)ctg_len;
+        at += snprintf(out + at, 24, " %lld ", (long long)r.centre);
+        memcpy(out + at, r.seq, (size_t)r.seq_len);
+        at += r.seq_len;
+        for (int i = 0; i < N_VAL; ++i) {
+            out[at++] = ' ';
+            int32_t v = r.counts[i];
+            if (v == 0) { out[at++] = '0'; continue; }
+            char tmp[12];
+            int k = 0;
+            uint32_t u = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+            while (u) { tmp[k++] = (char)('0' + u % 10); u /= 10; }
+            if (v < 0) out[at++] = '-';
+            while (k) out[at++] = tmp[--k];
+        }
+        out[at++] = '\n';
+        p->out.pop_front();
+        ++n;
+    }
+    *out_len = at;
+    *n_taken = n;
+    return 0;
+}
+
+int clair_host_pileup_stats(const clair_pileup_t *p, int64_t *stats) {
+    if (!p || !stats) return clair_host_fail("bad argument");
+    stats[0] = p->reads_seen;
+    stats[1] = (int64_t)p->live.size();
+    stats[2] = p->slots;
+    stats[3] = p->sorted ? 1 : 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define CLAIR_HOST_ABI_VERSION 1
+#define CLAIR_HOST_ABI_VERSION 2
 #define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
 
 int clair_host_abi_version(void);
@@ -50,6 +50,40 @@ int clair_host_decode_rows(const float *x, const float *gt21, const float *genot
                            const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
                            int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
                            int64_t *out_len, int *n_rows);
+
+/* -- pileup: alignments -> [33][8][4] count windows, the work of dataPrepScripts/CreateTensor.py:179-394 (OutputAlnTensor) and
+ *    :29-65 (generate_tensor) as a streaming builder.  The caller supplies what the reference obtains from its sub-processes:
+ *    the reference slice `samtools faidx` printed (upper-cased, :137; reference_start_0_based = 0 or region start - 1, :217), the
+ *    candidate positions (column 2 of the candidate rows, 1-based, those outside [ctgStart, ctgEnd] already dropped, :86-92, in
+ *    stream order) and the text `samtools view` prints.  The builder replays the reference's rules: candidates become known
+ *    100 000 bp ahead of the reads (:274-275); mapping-quality filter (:268-269); at most dcov reads per start position
+ *    (:277-284); windows open / close as the CIGAR walk passes centre-17 / centre+17 (:286-371; consider_left_edge: at any
+ *    walked position inside, :95-100); a window is finished when a read with a new start position begins beyond it (:373-386)
+ *    or at clair_host_pileup_finish (:388-394), in first-touch order, and dropped when its centre depth is below min_coverage or
+ *    it would start before the loaded reference (:58-59); available_slots is the reference's budget of outstanding
+ *    (window, base) tuples (5 000 000, :181): bases are dropped once it is used up, exactly where the reference drops them
+ *    (within one reference position the windows are served in ascending centre order; the reference's order there is CPython's
+ *    set iteration order).  force_general_path != 0 selects the hash-map twin of the sorted-candidates fast path (tests).
+ *    Pinned byte for byte against records minted from the real script (tests/golden/pileup_ct_*.json.gz). */
+typedef struct clair_pileup clair_pileup_t;
+int clair_host_pileup_create(const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based, const int64_t *candidates,
+                             int64_t n_candidates, int consider_left_edge, int dcov, int min_coverage, int min_mq,
+                             int64_t available_slots, int force_general_path, clair_pileup_t **out);
+void clair_host_pileup_destroy(clair_pileup_t *p);
+/* Consume SAM text line by line ('\n'; a last line without '\n' only when `final`): header lines ('@') are skipped, columns
+ * FLAG, POS, MAPQ, CIGAR, SEQ are used (:252-263).  *bytes_consumed = start of the first line not consumed.  Errors (too few
+ * columns, non-integer column, CIGAR longer than SEQ, position outside the loaded reference) name the 0-based line index since
+ * creation; the reference raises a Python exception at the same places. */
+int clair_host_pileup_feed(clair_pileup_t *p, const char *sam, int64_t len, int final, int64_t *bytes_consumed);
+int clair_host_pileup_finish(clair_pileup_t *p);
+int64_t clair_host_pileup_pending(const clair_pileup_t *p);   /* finished windows waiting to be taken */
+/* Take up to max_rows finished windows: centres[k] (1-based), refseq[k*34 ..] (NUL-padded; 33 bases unless the loaded reference
+ * ends inside the window, as the reference's slice :63), counts[k*1056 ..] = [33][8][4] int32. */
+int clair_host_pileup_take(clair_pileup_t *p, int64_t max_rows, int64_t *centres, char *refseq, int32_t *counts, int64_t *n_taken);
+/* Take finished windows as the reference's text records "ctg centre refseq v0 ... v1055\n" (:60-65), as many as fit in cap. */
+int clair_host_pileup_take_text(clair_pileup_t *p, const char *ctg_name, char *out, int64_t cap, int64_t *out_len, int64_t *n_taken);
+/* stats[0..3] = reads walked, windows open, slots left, 1 if the sorted-candidates path is in use */
+int clair_host_pileup_stats(const clair_pileup_t *p, int64_t *stats);
 
 #ifdef __cplusplus
 }
