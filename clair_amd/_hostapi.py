@@ -9,7 +9,9 @@ LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_parse_tensors",
            "clair_host_decode_rows",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
-           "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats")
+           "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
+           "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
+           "clair_host_evc_pending", "clair_host_evc_reads", "clair_host_evc_take", "clair_host_evc_take_text")
 N_VALUES = 1056
 _lib = None
 
@@ -37,6 +39,18 @@ def load():
         lib.clair_host_pileup_take.argtypes = [vp, i64, vp, vp, vp, ctypes.POINTER(i64)]
         lib.clair_host_pileup_take_text.argtypes = [vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         lib.clair_host_pileup_stats.argtypes = [vp, vp]
+        lib.clair_host_evc_create.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i64, i64, i64, i64, vp, vp, i64, ctypes.c_double,
+                                              ctypes.c_double, i32, ctypes.POINTER(vp)]
+        lib.clair_host_evc_destroy.argtypes = [vp]
+        lib.clair_host_evc_destroy.restype = None
+        lib.clair_host_evc_feed.argtypes = [vp, vp, i64, i32, ctypes.POINTER(i64)]
+        lib.clair_host_evc_finish.argtypes = [vp]
+        lib.clair_host_evc_pending.argtypes = [vp]
+        lib.clair_host_evc_pending.restype = i64
+        lib.clair_host_evc_reads.argtypes = [vp]
+        lib.clair_host_evc_reads.restype = i64
+        lib.clair_host_evc_take.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
+        lib.clair_host_evc_take_text.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         if lib.clair_host_abi_version() != 2:
             raise RuntimeError("libclair_host.so has ABI version %d, expected 2: run `python -m clair_amd.build`"
                                % lib.clair_host_abi_version())
@@ -166,6 +180,89 @@ class PileupBuilder(object):
 
     def text_from_sam(self, handle, chunk_bytes=1 << 22):
         """Feed a SAM stream (binary or text file object); yield the finished records as text chunks (str)."""
+        tail = None
+        while True:
+            chunk = handle.read(chunk_bytes)
+            if not chunk:
+                break
+            tail = self.feed(chunk if tail is None else tail + chunk)
+            while self.pending():
+                yield self.take_text().decode("latin-1")
+        if tail:
+            self.feed(tail, final=True)
+        self.finish()
+        while self.pending():
+            yield self.take_text().decode("latin-1")
+
+
+class CandidateFinder(object):
+    """clair_host_evc_*: the native twin of clair_amd.extract_variant_candidates.CandidateFinderPy."""
+
+    def __init__(self, ctg_name, reference_sequence, reference_start_0_based, ctg_start=None, ctg_end=None, bed=None,
+                 min_coverage=4, threshold=0.125, min_mq=0):
+        self._lib = load()
+        ref = reference_sequence.encode("latin-1") if isinstance(reference_sequence, str) else bytes(reference_sequence)
+        have_range = ctg_start is not None and ctg_end is not None
+        if bed is None:
+            bs = be = np.zeros(0, dtype=np.int64)
+            n_bed = -1
+        else:
+            bs = np.ascontiguousarray([b[0] for b in bed], dtype=np.int64)
+            be = np.ascontiguousarray([b[1] for b in bed], dtype=np.int64)
+            n_bed = len(bs)
+        h = ctypes.c_void_p()
+        rc = self._lib.clair_host_evc_create(ctg_name.encode(), ref, len(ref), int(reference_start_0_based),
+                                             int(ctg_start) if have_range else -1, int(ctg_end) if have_range else -1,
+                                             bs.ctypes.data, be.ctypes.data, n_bed, float(min_coverage), float(threshold),
+                                             int(min_mq), ctypes.byref(h))
+        if rc != 0:
+            raise ValueError("candidates: " + self._lib.clair_host_last_error().decode())
+        self._h = h
+        self._text = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.clair_host_evc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def reads(self):
+        return int(self._lib.clair_host_evc_reads(self._h))
+
+    def feed(self, sam, final=False):
+        data = sam.encode("latin-1") if isinstance(sam, str) else sam
+        used = ctypes.c_int64(0)
+        base = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value
+        rc = self._lib.clair_host_evc_feed(self._h, base, len(data), 1 if final else 0, ctypes.byref(used))
+        if rc != 0:
+            from .create_tensor import PileupError
+            raise PileupError(self._lib.clair_host_last_error().decode())
+        return sam[used.value:]
+
+    def finish(self):
+        self._lib.clair_host_evc_finish(self._h)
+
+    def pending(self):
+        return int(self._lib.clair_host_evc_pending(self._h))
+
+    def take_positions(self):
+        n = self.pending()
+        pos = np.empty(n, dtype=np.int64)
+        taken = ctypes.c_int64(0)
+        if n:
+            self._lib.clair_host_evc_take(self._h, n, pos.ctypes.data, ctypes.byref(taken))
+        return pos
+
+    def take_text(self, cap=1 << 22):
+        if self._text is None or len(self._text) < cap:
+            self._text = ctypes.create_string_buffer(cap)
+        n, taken = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._lib.clair_host_evc_take_text(self._h, self._text, cap, ctypes.byref(n), ctypes.byref(taken))
+        return self._text.raw[:n.value]
+
+    def text_from_sam(self, handle, chunk_bytes=1 << 22):
         tail = None
         while True:
             chunk = handle.read(chunk_bytes)

@@ -1,0 +1,258 @@
+"""BAM -> VCF for one contig / region: candidate extraction, pileup tensors, network, decode, in ONE process.
+
+Host-side mirror of the reference's clair/callVarBam.py (same flags).  The reference wires three interpreters together with
+text pipes (callVarBam.py:124-199): `pypy ExtractVariantCandidates | pypy CreateTensor | python call_var`, 2.3 KB of decimal
+text per candidate on the second pipe.  Here the same three stages are native code in one process and hand each other
+arrays:
+
+    samtools view  -> clair_host_evc_*     -> candidate positions (int64)
+    samtools view  -> clair_host_pileup_*  -> count windows int32 [n,33,8,4] + (position, refseq)
+                   -> float32, channels 1..3 minus channel 0 (clair/utils.py:96-98), centre-base filter (:90-91)
+                   -> HIP forward pass (libclair_amd.so) -> native decode -> VCF rows
+
+The VCF is the one `extract_variant_candidates | create_tensor | call_var` produce through their text interfaces
+(tests/test_pileup.py pins that), which in turn are pinned against the reference scripts.  Like the reference, alignments
+are read twice (`samtools view` once per stage): the pileup needs the candidates ahead of the reads.
+"""
+import logging
+import os
+import shlex
+import sys
+from argparse import ArgumentParser
+
+import numpy as np
+
+from . import call_var as cv
+from . import create_tensor as ct
+from . import extract_variant_candidates as evc
+from . import param
+
+IUPAC = frozenset("ACGTURYSWKMBDHVN")
+
+
+def candidate_positions(args):
+    """Stage 1.  -> int64 positions (1-based, ascending for sorted alignments)."""
+    from . import _hostapi
+    if args.vcf_fn is not None:
+        return positions_from_vcf(args.vcf_fn, args.ctgName, args.ctgStart, args.ctgEnd)
+    if not os.path.isfile("%s.fai" % args.ref_fn):
+        sys.exit("Fasta index %s.fai doesn't exist." % args.ref_fn)
+    have_range = args.ctgStart is not None and args.ctgEnd is not None
+    region, ref_start = evc.reference_region(args.ctgName, args.ctgStart if have_range else None, args.ctgEnd if have_range else None)
+    seq = evc.load_reference(args.samtools, args.ref_fn, region)
+    if not seq:
+        sys.exit("[ERROR] Failed to load reference seqeunce from file (%s)." % args.ref_fn)
+    tree = evc.bed_regions_from(args.bed_fn)
+    if tree is not None and args.ctgName not in tree:
+        sys.exit("[ERROR] ctg_name(%s) not exists in bed file(%s)." % (args.ctgName, args.bed_fn))
+    finder = _hostapi.CandidateFinder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1,
+                                      ctg_start=args.ctgStart if have_range else None, ctg_end=args.ctgEnd if have_range else None,
+                                      bed=None if tree is None else tree[args.ctgName],
+                                      min_coverage=args.minCoverage, threshold=args.threshold, min_mq=0)
+    view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+                               text=False)
+    chunks, tail = [], None
+    while True:
+        chunk = view.stdout.read(1 << 22)
+        if not chunk:
+            break
+        tail = finder.feed(chunk if tail is None else tail + chunk)
+        if finder.pending():
+            chunks.append(finder.take_positions())
+    if tail:
+        finder.feed(tail, final=True)
+    finder.finish()
+    chunks.append(finder.take_positions())
+    view.stdout.close()
+    view.wait()
+    if view.returncode != 0:
+        sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
+    if finder.reads == 0:
+        print("No read has been process, either the genome region you specified has no read cover, or please check the correctness of your BAM input (%s)."
+              % args.bam_fn, file=sys.stderr)
+    return np.concatenate(chunks) if chunks else np.zeros(0, np.int64)
+
+
+def positions_from_vcf(vcf_fn, ctg_name, ctg_start, ctg_end):
+    """--vcf_fn: call only at the sites of a VCF (the positions dataPrepScripts/GetTruth.py:75-134 would print: every record of
+    the contig inside the range; a '*' alternate adds the base before, :38-45)."""
+    have_range = ctg_start is not None and ctg_end is not None
+    p = ct.subprocess_popen(shlex.split("gzip -fdc %s" % vcf_fn))
+    out = []
+    for row in p.stdout:
+        col = row.strip().split()
+        if not col or col[0][0] == "#" or col[0] != ctg_name:
+            continue
+        pos = int(col[1])
+        if have_range and not ctg_start <= pos <= ctg_end:
+            continue
+        if "*" in col[4]:
+            out.append(pos - 1)
+        if col[4] != "*":
+            out.append(pos)
+    p.stdout.close()
+    p.wait()
+    return np.array(sorted(out), dtype=np.int64)
+
+
+def tensor_batches(args, positions, batch_size):
+    """Stage 2 as a generator of (X float32 [n,33,8,4], [[ctg, pos, refseq], ...]) -- what clair_amd.utils.tensor_generator_from
+    yields for the text records of the same windows."""
+    from . import _hostapi
+    seq, ref_start = ct.reference_sequence_from(args.samtools, args.ref_fn, args.ctgName, args.ctgStart, args.ctgEnd)
+    if not seq:
+        sys.exit("Failed to load reference seqeunce. Please check if the provided reference fasta %s and the ctgName %s are correct."
+                 % (args.ref_fn, args.ctgName))
+    have_range = args.ctgStart is not None and args.ctgEnd is not None
+    if have_range:
+        positions = positions[(positions >= args.ctgStart) & (positions <= args.ctgEnd)]
+    builder = _hostapi.PileupBuilder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1, positions,
+                                     consider_left_edge=not args.stop_consider_left_edge, dcov=args.dcov)
+    region = "%s:%d-%d" % (args.ctgName, args.ctgStart, args.ctgEnd) if have_range else args.ctgName
+    view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+                               text=False)
+    total = 0
+    held_x, held_info, held = [], [], 0
+
+    def drain(final):
+        nonlocal held_x, held_info, held, total
+        while builder.pending():
+            centres, seqs, counts = builder.take_arrays(4 * batch_size)
+            keep = np.fromiter((len(s) > 16 and s[16] in IUPAC for s in seqs), dtype=bool, count=len(seqs))
+            x = counts[keep].astype(np.float32)
+            x[:, :, :, 1:] -= x[:, :, :, 0:1]
+            held_x.append(x)
+            held_info.extend([args.ctgName, str(int(c)), s] for c, s, k in zip(centres, seqs, keep) if k)
+            held += len(x)
+        while held >= batch_size or (final and held > 0):
+            x = np.concatenate(held_x) if len(held_x) > 1 else held_x[0]
+            n = min(batch_size, held)
+            yield_x, rest = x[:n], x[n:]
+            infos, held_info = held_info[:n], held_info[n:]
+            held_x, held = ([rest] if len(rest) else []), len(rest)
+            total += n
+            print("Processed %d tensors" % total, file=sys.stderr)
+            yield np.ascontiguousarray(yield_x), infos
+
+    tail = None
+    while True:
+        chunk = view.stdout.read(1 << 22)
+        if not chunk:
+            break
+        tail = builder.feed(chunk if tail is None else tail + chunk)
+        for batch in drain(False):
+            yield batch
+    if tail:
+        builder.feed(tail, final=True)
+    builder.finish()
+    for batch in drain(True):
+        yield batch
+    view.stdout.close()
+    view.wait()
+    if view.returncode != 0:
+        sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
+
+
+def Run(args):
+    if args.ctgName is None:
+        sys.exit("--ctgName must be specified. You can call variants on multiple chromosomes simultaneously.")
+    for path, suffix in ((args.bam_fn, ""), (args.ref_fn, "")):
+        if not os.path.isfile(path + suffix):
+            sys.exit("[ERROR] file %s not found" % (path + suffix))
+    if args.ctgStart is not None and args.ctgEnd is not None and int(args.ctgStart) > int(args.ctgEnd):
+        args.ctgStart = args.ctgEnd = None          # callVarBam.py:97-101
+    if (args.ctgStart is None) != (args.ctgEnd is None):
+        args.ctgStart = args.ctgEnd = None
+    logging.basicConfig(format="%(message)s", level=logging.INFO)
+    cv.ingest.setup_environment()
+
+    positions = candidate_positions(args)
+    logging.info("%d candidate sites" % len(positions))
+
+    config = cv.OutputConfig(
+        is_show_reference=False, is_debug=args.debug,
+        is_haploid_precision_mode_enabled=args.haploid_precision,
+        is_haploid_sensitive_mode_enabled=args.haploid_sensitive,
+        is_output_for_ensemble=args.output_for_ensemble, quality_score_for_pass=args.qual)
+    lookup = cv.AlignmentLookup(args.bam_fn, args.ref_fn)
+    decoder = cv.VariantDecoder(config, lookup, always_use_bam=args.pysam_for_all_indel_bases, arith=args.arith)
+    writer = cv.VcfWriter(args.call_fn, args.sampleName, args.ref_fn, args.output_for_ensemble)
+    try:
+        if args.activation_only:
+            return
+        from .model import Clair
+        batch = args.batch_size or param.predictBatchSize
+        try:
+            m = Clair(device=args.device, max_batch=batch, n_slots=2)
+            m.init()
+            m.restore_parameters(os.path.abspath(args.chkpnt_fn))
+        except Exception as exc:
+            sys.exit("[ERROR] %s" % exc)
+        try:
+            cv.call_variants(args, m, decoder, writer, batch, generator=tensor_batches(args, positions, batch))
+        finally:
+            m.close()
+    finally:
+        writer.close()
+        lookup.close()
+
+
+def build_parser():
+    """Flags and defaults of clair/callVarBam.py:237-322, plus --batch_size / --device / --arith."""
+    parser = ArgumentParser(description="Call variants using a trained model and a BAM file")
+    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a model")
+    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
+    parser.add_argument('--bed_fn', type=str, default=None,
+                        help="Call variant only in these regions, works in intersection with ctgName, ctgStart and ctgEnd, optional, default: as defined by ctgName, ctgStart and ctgEnd")
+    parser.add_argument('--bam_fn', type=str, default="bam.bam", help="BAM file input, default: %(default)s")
+    parser.add_argument('--call_fn', type=str, default=None, help="Output variant predictions")
+    parser.add_argument('--vcf_fn', type=str, default=None,
+                        help="Candidate sites VCF file input, if provided, variants will only be called at the sites in the VCF file,  default: %(default)s")
+    parser.add_argument('--threshold', type=float, default=0.125,
+                        help="Minimum allele frequence of the 1st non-reference allele for a site to be considered as a condidate site, default: %(default)f")
+    parser.add_argument('--minCoverage', type=float, default=4, help="Minimum coverage required to call a variant, default: %(default)d")
+    parser.add_argument('--qual', type=int, default=None,
+                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
+    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
+    parser.add_argument('--ctgName', type=str, default=None, help="The name of sequence to be processed, default: %(default)s")
+    parser.add_argument('--ctgStart', type=int, default=None, help="The 1-based starting position of the sequence to be processed")
+    parser.add_argument('--ctgEnd', type=int, default=None, help="The 1-based inclusive ending position of the sequence to be processed")
+    parser.add_argument('--stop_consider_left_edge', action='store_true',
+                        help="If not set, would consider left edge only. That is, count the left-most base-pairs of a read for coverage even if the starting position of a read is after the starting position of a tensor")
+    parser.add_argument('--dcov', type=int, default=250, help="Cap depth per position at %(default)s")
+    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
+    parser.add_argument('--pypy', type=str, default="pypy3", help="Ignored: no stage of this pipeline runs under pypy")
+    parser.add_argument('--threads', type=int, default=None, help="Number of threads, optional")
+    parser.add_argument('--delay', type=int, default=10, help="Ignored: there is no TensorFlow start-up thread storm to stagger")
+    parser.add_argument('--debug', action='store_true', help="Debug mode, optional")
+    parser.add_argument('--pysam_for_all_indel_bases', action='store_true', help="Always using pysam for outputting indel bases, optional")
+    parser.add_argument('--haploid_precision', action='store_true', help="call haploid instead of diploid (output homo-variant only)")
+    parser.add_argument('--haploid_sensitive', action='store_true', help="call haploid instead of diploid (output non-multi-variant only)")
+    parser.add_argument('--activation_only', action='store_true', help="Output activation only, no prediction")
+    parser.add_argument('--max_plot', type=int, default=10,
+                        help="The maximum number of plots output, negative number means no limit (plot all), default: %(default)s")
+    parser.add_argument('--log_path', type=str, nargs='?', default=None, help="The path for tensorflow logging, default: %(default)s")
+    parser.add_argument('-p', '--parallel_level', type=int, default=2,
+                        help="The level of parallelism in plotting (currently available: 0, 2), default: %(default)s")
+    parser.add_argument('--fast_plotting', action='store_true', help="Enable fast plotting.")
+    parser.add_argument('-w', '--workers', type=int, default=8, help="The number of workers in plotting, default: %(default)s")
+    parser.add_argument('--output_for_ensemble', action='store_true', help="Output for ensemble")
+    # additions of this implementation
+    parser.add_argument('--batch_size', type=int, default=None, help="Candidates per forward pass, default: %d" % param.predictBatchSize)
+    parser.add_argument('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
+    parser.add_argument('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
+                        help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 0:
+        parser.print_help()
+        sys.exit(1)
+    Run(parser.parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""Print one `callVarBam` command per reference chunk (to be run by `parallel`, a scheduler or a shell loop).
+
+Host-side mirror of the reference's clair/callVarBamParallel.py (:19-116): contigs from `<ref>.fai` (chr1-22/X/Y and
+1-22/X/Y unless --includingAllContigs), cut into --refChunkSize pieces, skipped when a --bed_fn has nothing in the chunk,
+output `<prefix>.<contig>_<start>_<end>.vcf`.  This is also the multi-GPU front door: candidates are independent
+(SURVEY.md 8e), so chunks are dealt round-robin over --devices GPUs (addition; one process per chunk and GPU, no
+collective) and the per-chunk VCFs concatenate in order exactly as the reference's do (README: vcfcat + bcftools sort).
+"""
+import os
+import sys
+from argparse import ArgumentParser
+
+from .extract_variant_candidates import BedRegions, bed_regions_from
+
+major_contigs = {"chr" + str(a) for a in list(range(1, 23)) + ["X", "Y"]}.union({str(a) for a in list(range(1, 23)) + ["X", "Y"]})
+
+
+def _opt(name, value):
+    return None if value is None else '--%s "%s"' % (name, value)
+
+
+def _flag(name, on):
+    return "--%s" % name if on else None
+
+
+def _existing(path, suffix=""):
+    if not isinstance(path, str) or not os.path.isfile(path + suffix):
+        return None
+    return os.path.abspath(path)
+
+
+def _must_exist(path, suffix=""):
+    p = _existing(path, suffix)
+    if p is None:
+        sys.exit("[ERROR] file %s not found" % (str(path) + suffix))
+    return p
+
+
+def chunk_overlaps_bed(regions, start, end):
+    """IntervalTree.overlap(start, end) non-empty (shared/interval_tree.py:52-54)."""
+    import bisect
+    i = bisect.bisect_left(regions.end, start + 1)        # first interval with end > start
+    return i < len(regions.start) and regions.start[i] < end
+
+
+def commands(args):
+    chkpnt_fn = os.path.abspath(args.chkpnt_fn) if args.chkpnt_fn else None
+    if chkpnt_fn is None or not any(os.path.isfile(chkpnt_fn + s) for s in (".meta", ".npz", ".index")):
+        sys.exit("[ERROR] file %s not found" % (str(args.chkpnt_fn) + ".meta"))
+    bam_fn, ref_fn = _must_exist(args.bam_fn), _must_exist(args.ref_fn)
+    fai_fn = _must_exist(args.ref_fn, ".fai") + ".fai"
+    bed_fn, vcf_fn = _existing(args.bed_fn), _existing(args.vcf_fn)
+    tree = bed_regions_from(bed_fn)
+    tree = None if tree is None else {k: BedRegions(v) for k, v in tree.items()}
+    head = " ".join(x for x in [
+        "%s -m clair_amd.callVarBam" % (args.python or sys.executable),
+        _opt("chkpnt_fn", chkpnt_fn), _opt("ref_fn", ref_fn), _opt("bam_fn", bam_fn), _opt("threshold", args.threshold),
+        _opt("minCoverage", args.minCoverage), _opt("pypy", args.pypy), _opt("samtools", args.samtools), _opt("delay", args.delay),
+        _opt("threads", args.tensorflowThreads), _opt("sampleName", args.sampleName), _opt("vcf_fn", vcf_fn), _opt("qual", args.qual),
+        _flag("stop_consider_left_edge", args.stop_consider_left_edge), _flag("debug", args.debug),
+        _flag("pysam_for_all_indel_bases", args.pysam_for_all_indel_bases), _flag("haploid_precision", args.haploid_precision),
+        _flag("haploid_sensitive", args.haploid_sensitive), _flag("output_for_ensemble", args.output_for_ensemble),
+    ] if x is not None)
+    out, k = [], 0
+    with open(fai_fn) as fai:
+        for row in fai:
+            col = row.strip().split("\t")
+            contig, length = col[0], int(col[1])
+            if not args.includingAllContigs and contig not in major_contigs:
+                continue
+            end = 0
+            while end < length:
+                start, end = end, min(end + args.refChunkSize, length)
+                in_bed = tree is not None and contig in tree and chunk_overlaps_bed(tree[contig], start, end)
+                if tree is not None and not in_bed:
+                    continue
+                tail = [_opt("ctgName", contig), _opt("ctgStart", start), _opt("ctgEnd", end),
+                        _opt("call_fn", "%s.%s_%d_%d.vcf" % (args.output_prefix, contig, start, end)),
+                        _opt("bed_fn", bed_fn) if in_bed else None,
+                        _opt("device", k % args.devices) if args.devices > 1 else None]
+                out.append(head + " " + " ".join(x for x in tail if x is not None))
+                k += 1
+    return out
+
+
+def build_parser():
+    """Flags and defaults of clair/callVarBamParallel.py:119-204, plus --devices / --python."""
+    parser = ArgumentParser(description="Create commands for calling variants in parallel using a trained model and a BAM file")
+    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a checkpoint for testing or continue training")
+    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
+    parser.add_argument('--bed_fn', type=str, default=None,
+                        help="Call variant only in these regions, works in intersection with ctgName, ctgStart and ctgEnd, optional, default: as defined by ctgName, ctgStart and ctgEnd")
+    parser.add_argument('--refChunkSize', type=int, default=10000000, help="Divide job with smaller genome chunk size for parallelism, default: %(default)s")
+    parser.add_argument('--bam_fn', type=str, default="bam.bam", help="BAM file input, default: %(default)s")
+    parser.add_argument('--vcf_fn', type=str, default=None,
+                        help="Candidate sites VCF file input, if provided, variants will only be called at the sites in the VCF file,  default: %(default)s")
+    parser.add_argument('--output_prefix', type=str, default=None, help="Output prefix")
+    parser.add_argument('--includingAllContigs', action='store_true', help="Call variants on all contigs, default: chr{1..22,X,Y,M,MT} and {1..22,X,Y,MT}")
+    parser.add_argument('--tensorflowThreads', type=int, default=4, help="Passed on as --threads (host-side threads per process), default: %(default)s")
+    parser.add_argument('--threshold', type=float, default=0.2,
+                        help="Minimum allele frequence of the 1st non-reference allele for a site to be considered as a condidate site, default: %(default)f")
+    parser.add_argument('--minCoverage', type=float, default=4, help="Minimum coverage required to call a variant, default: %(default)f")
+    parser.add_argument('--qual', type=int, default=None,
+                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
+    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
+    parser.add_argument('--stop_consider_left_edge', action='store_true', help="If not set, would consider left edge only.")
+    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
+    parser.add_argument('--pypy', type=str, default="pypy3", help="Passed on; ignored by callVarBam")
+    parser.add_argument('--delay', type=int, default=10, help="Passed on; ignored by callVarBam")
+    parser.add_argument('--debug', action='store_true', help="Debug mode, optional")
+    parser.add_argument('--pysam_for_all_indel_bases', action='store_true', help="Always using pysam for outputting indel bases, optional")
+    parser.add_argument('--haploid_precision', action='store_true', help="call haploid instead of diploid (output homo-variant only)")
+    parser.add_argument('--haploid_sensitive', action='store_true', help="call haploid instead of diploid (output non-multi-variant only)")
+    parser.add_argument('--activation_only', action='store_true', help="Output activation only, no prediction")
+    parser.add_argument('--max_plot', type=int, default=10, help="(plotting is a dead path, kept for flag compatibility)")
+    parser.add_argument('--log_path', type=str, nargs='?', default=None, help="(plotting is a dead path, kept for flag compatibility)")
+    parser.add_argument('-p', '--parallel_level', type=int, default=2, help="(plotting is a dead path, kept for flag compatibility)")
+    parser.add_argument('-w', '--workers', type=int, default=8, help="(plotting is a dead path, kept for flag compatibility)")
+    parser.add_argument('--fast_plotting', action='store_true', help="(plotting is a dead path, kept for flag compatibility)")
+    parser.add_argument('--output_for_ensemble', action='store_true', help="Output for ensemble")
+    # additions of this implementation
+    parser.add_argument('--devices', type=int, default=1, help="Deal the chunks round-robin over this many GPUs (--device k), default: %(default)s")
+    parser.add_argument('--python', type=str, default=None, help="Interpreter to put in the commands, default: the running one")
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 0:
+        parser.print_help()
+        sys.exit(1)
+    args = parser.parse_args(argv)
+    if not args.includingAllContigs:
+        print("echo \"[INFO] --includingAllContigs not enabled, use chr{1..22,X,Y,M,MT} and {1..22,X,Y,MT} by default\"\n")
+    else:
+        print("echo \"[INFO] --includingAllContigs enabled\"\n")
+    for line in commands(args):
+        print(line)
+
+
+if __name__ == "__main__":
+    main()

@@ -584,12 +584,14 @@ class VcfWriter(object):
 # =============================================================================================
 # drivers
 # =============================================================================================
-def call_variants(args, m, decoder, writer, batch_size=None):
+def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     """call_var.py:1312-1367.  Software pipeline per iteration: decode+write batch k-1, forward pass
-    of batch k (asynchronous on the GPU), parse batch k+1; rows appear in input order."""
+    of batch k (asynchronous on the GPU), parse batch k+1; rows appear in input order.  `generator` replaces the
+    --tensor_fn reader with another source of (X, infos) batches (clair_amd.callVarBam hands pileup arrays over)."""
     writer.write_header()
     batch_size = batch_size or param.predictBatchSize
-    generator = ingest.tensor_generator_from(args.tensor_fn, batch_size)
+    if generator is None:
+        generator = ingest.tensor_generator_from(args.tensor_fn, batch_size)
     logging.info("Calling variants ...")
     t0 = time()
     use_async = hasattr(m, "submit") and hasattr(m, "wait")

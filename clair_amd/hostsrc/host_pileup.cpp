@@ -461,3 +461,257 @@ int clair_host_pileup_stats(const clair_pileup_t *p, int64_t *stats) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Candidate extraction: the per-position base / indel tallies of dataPrepScripts/ExtractVariantCandidates.py
+// (make_candidates :160-393) and its depth / allele-frequency filter, streaming.  Inference mode only: the training-set
+// sampling switches (--gen4Training, --var_fn, --outputProb) draw from Python's random module and are not restated.
+namespace {
+
+struct Tally { int32_t n[7]; };   // A C G T I D N, the reference's dict order (:265) -- ties in the sort below keep it
+
+const char TALLY_NAME[7] = {'A', 'C', 'G', 'T', 'I', 'D', 'N'};
+
+// IUPAC_base_to_ACGT_base_dict (shared/utils.py:19-22) through evc_base_from (:27-28): index into TALLY_NAME, -1 = KeyError
+struct AcgtTable {
+    signed char idx[256];
+    AcgtTable() {
+        memset(idx, -1, sizeof idx);
+        const char *keys = "ACGTURYSWKMBDHVN";
+        const char *vals = "ACGTTACCAGACAAAA";
+        for (int i = 0; i < 16; ++i) {
+            const char v = vals[i];
+            idx[(unsigned char)keys[i]] = (signed char)(v == 'A' ? 0 : v == 'C' ? 1 : v == 'G' ? 2 : 3);
+        }
+        idx[(unsigned char)'N'] = 6;   // evc_base_from keeps N
+    }
+};
+const AcgtTable ACGT;
+
+}  // namespace
+
+struct clair_evc {
+    std::string ctg, ref;
+    int64_t ref0 = 0;
+    bool have_range = false, have_bed = false;
+    int64_t ctg_start = 0, ctg_end = 0;
+    std::vector<int64_t> bed_start, bed_end;   // sorted, merged, 0-based half-open
+    double min_depth = 4, min_af = 0.125;
+    int min_mq = 0;
+    std::map<int64_t, Tally> pileup;
+    int64_t reads = 0, lines_seen = 0;
+    struct Cand { int64_t pos1; char ref_base; int64_t depth; signed char order[7]; int32_t n[7]; };
+    std::deque<Cand> out;
+
+    bool in_bed(int64_t p0) const {
+        auto it = std::upper_bound(bed_start.begin(), bed_start.end(), p0);
+        if (it == bed_start.begin()) return false;
+        return p0 < bed_end[(size_t)(it - bed_start.begin()) - 1];
+    }
+
+    void flush(int64_t before, bool all) {
+        auto it = pileup.begin();
+        while (it != pileup.end() && (all || it->first < before)) {
+            emit(it->first, it->second);
+            it = pileup.erase(it);
+        }
+    }
+
+    void emit(int64_t p0, const Tally &t) {
+        if (have_range && !(ctg_start <= p0 + 1 && p0 + 1 <= ctg_end)) return;
+        if (have_bed && !in_bed(p0)) return;
+        int64_t i = p0 - ref0;
+        if (i < 0) i += (int64_t)ref.size();           // Python str indexing
+        if (i < 0 || i >= (int64_t)ref.size()) return;   // IndexError -> except: continue (:349-355)
+        const int rb = ACGT.idx[(unsigned char)ref[(size_t)i]];
+        if (rb < 0) return;                              // KeyError -> continue
+        int64_t depth = 0;
+        for (int k = 0; k < 7; ++k) depth += t.n[k];
+        depth -= t.n[4] + t.n[5];
+        if ((double)depth < min_depth) return;
+        const int64_t denom = depth > 0 ? depth : 1;
+        Cand c;
+        for (int k = 0; k < 7; ++k) { c.order[k] = (signed char)k; c.n[k] = t.n[k]; }
+        std::stable_sort(c.order, c.order + 7, [&](signed char a, signed char b) { return t.n[a] > t.n[b]; });
+        const bool pass = c.order[0] != rb || ((double)t.n[c.order[1]] / (double)denom) >= min_af;
+        if (!pass) return;
+        c.pos1 = p0 + 1;
+        c.ref_base = TALLY_NAME[rb];
+        c.depth = depth;
+        out.push_back(c);
+    }
+
+    int add_line(const char *p, const char *end, int64_t line_no) {
+        const char *col[10];
+        size_t len[10];
+        int n = 0;
+        while (p < end && n < 10) {
+            while (p < end && is_space((unsigned char)*p)) ++p;
+            if (p >= end) break;
+            const char *q = p;
+            while (q < end && !is_space((unsigned char)*q)) ++q;
+            col[n] = p;
+            len[n] = (size_t)(q - p);
+            ++n;
+            p = q;
+        }
+        if (n == 0) return clair_host_fail("alignment line %lld is empty", (long long)line_no);
+        if (col[0][0] == '@') return 0;
+        if (n < 10) return clair_host_fail("alignment line %lld has %d columns (11 expected)", (long long)line_no, n);
+        if (len[2] != ctg.size() || memcmp(col[2], ctg.data(), ctg.size()) != 0) return 0;   // RNAME != ctgName (:279-281)
+        int64_t v[2];
+        const int which[2] = {3, 4};
+        for (int i = 0; i < 2; ++i) {
+            const char *s = col[which[i]], *e = s + len[which[i]];
+            bool neg = false;
+            if (s < e && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
+            if (s == e || e - s > 18) return clair_host_fail("alignment line %lld: column %d is not an integer", (long long)line_no, which[i] + 1);
+            int64_t x = 0;
+            for (; s < e; ++s) {
+                if (*s < '0' || *s > '9') return clair_host_fail("alignment line %lld: column %d is not an integer", (long long)line_no, which[i] + 1);
+                x = x * 10 + (*s - '0');
+            }
+            v[i] = neg ? -x : x;
+        }
+        const int64_t pos = v[0] - 1;
+        if (v[1] < min_mq) return 0;
+        const char *cigar = col[5];
+        const size_t cl = len[5];
+        if (cl == 1 && cigar[0] == '*') return 0;
+        {   // a read less than 55 % aligned is skipped (:143-157)
+            int64_t soft = 0, total = 0, adv = 0;
+            for (size_t i = 0; i < cl; ++i) {
+                const char ch = cigar[i];
+                if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); continue; }
+                if (ch == 'S') soft += adv;
+                total += adv;
+                adv = 0;
+            }
+            if (1.0 - (double)soft / (double)(total + 1) < 0.55) return 0;
+        }
+        ++reads;
+        const char *seq = col[9];
+        const int64_t sl = (int64_t)len[9];
+        int64_t rp = pos, qp = 0, adv = 0;
+        for (size_t i = 0; i < cl; ++i) {
+            const char ch = cigar[i];
+            if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); continue; }
+            if (ch == 'S') {
+                qp += adv;
+            } else if (ch == 'M' || ch == '=' || ch == 'X') {
+                for (int64_t k = 0; k < adv; ++k) {
+                    if (qp >= sl) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%lld bases)", (long long)v[0], (long long)sl);
+                    unsigned char b = (unsigned char)seq[qp];
+                    if (b >= 'a' && b <= 'z') b = (unsigned char)(b - 32);
+                    const int bi = ACGT.idx[b];
+                    if (bi < 0) return clair_host_fail("read at %lld: SEQ holds '%c', not an IUPAC base code", (long long)v[0], (char)b);
+                    pileup[rp].n[bi] += 1;
+                    ++rp;
+                    ++qp;
+                }
+            } else if (ch == 'I') {
+                pileup[rp - 1].n[4] += 1;
+                qp += adv;
+            } else if (ch == 'D') {
+                pileup[rp - 1].n[5] += 1;
+                rp += adv;
+            }
+            adv = 0;
+        }
+        flush(pos, false);   // positions before this read's start are complete (:319)
+        return 0;
+    }
+};
+
+extern "C" {
+
+int clair_host_evc_create(const char *ctg_name, const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based,
+                          int64_t ctg_start, int64_t ctg_end, const int64_t *bed_start, const int64_t *bed_end, int64_t n_bed,
+                          double min_coverage, double threshold, int min_mq, clair_evc_t **out) {
+    if (!out) return clair_host_fail("out is NULL");
+    *out = nullptr;
+    if (!ctg_name || !ref_seq || ref_len < 0) return clair_host_fail("contig name / reference sequence missing");
+    if (n_bed > 0 && (!bed_start || !bed_end)) return clair_host_fail("bed intervals missing");
+    clair_evc *e = new clair_evc;
+    e->ctg = ctg_name;
+    e->ref.assign(ref_seq, (size_t)ref_len);
+    e->ref0 = reference_start_0_based;
+    e->have_range = ctg_start >= 0 && ctg_end >= 0;
+    e->ctg_start = ctg_start;
+    e->ctg_end = ctg_end;
+    e->have_bed = n_bed >= 0;
+    if (n_bed > 0) {
+        // membership only (interval_tree.at(p), shared/interval_tree.py:45-57): sort and merge
+        std::vector<std::pair<int64_t, int64_t>> iv;
+        for (int64_t i = 0; i < n_bed; ++i) iv.emplace_back(bed_start[i], bed_end[i] == bed_start[i] ? bed_end[i] + 1 : bed_end[i]);
+        std::sort(iv.begin(), iv.end());
+        for (auto &x : iv) {
+            if (x.second <= x.first) continue;
+            if (!e->bed_start.empty() && x.first <= e->bed_end.back()) e->bed_end.back() = std::max(e->bed_end.back(), x.second);
+            else { e->bed_start.push_back(x.first); e->bed_end.push_back(x.second); }
+        }
+    }
+    e->min_depth = min_coverage;
+    e->min_af = threshold;
+    e->min_mq = min_mq;
+    *out = e;
+    return 0;
+}
+
+void clair_host_evc_destroy(clair_evc_t *e) { delete e; }
+
+int clair_host_evc_feed(clair_evc_t *e, const char *sam, int64_t len, int final, int64_t *bytes_consumed) {
+    if (!e || (!sam && len > 0) || !bytes_consumed) return clair_host_fail("bad argument");
+    int64_t at = 0;
+    while (at < len) {
+        const char *nl = (const char *)memchr(sam + at, '\n', (size_t)(len - at));
+        if (!nl && !final) break;
+        const char *end = nl ? nl : sam + len;
+        if (e->add_line(sam + at, end, e->lines_seen)) { *bytes_consumed = at; return 1; }
+        ++e->lines_seen;
+        at = (nl ? nl + 1 : end) - sam;
+    }
+    *bytes_consumed = at;
+    return 0;
+}
+
+int clair_host_evc_finish(clair_evc_t *e) {
+    if (!e) return clair_host_fail("bad argument");
+    e->flush(0, true);
+    return 0;
+}
+
+int64_t clair_host_evc_pending(const clair_evc_t *e) { return e ? (int64_t)e->out.size() : 0; }
+int64_t clair_host_evc_reads(const clair_evc_t *e) { return e ? e->reads : 0; }
+
+int clair_host_evc_take(clair_evc_t *e, int64_t max_rows, int64_t *positions, int64_t *n_taken) {
+    if (!e || !positions || !n_taken || max_rows < 0) return clair_host_fail("bad argument");
+    int64_t n = 0;
+    while (n < max_rows && !e->out.empty()) {
+        positions[n++] = e->out.front().pos1;
+        e->out.pop_front();
+    }
+    *n_taken = n;
+    return 0;
+}
+
+int clair_host_evc_take_text(clair_evc_t *e, char *out, int64_t cap, int64_t *out_len, int64_t *n_taken) {
+    if (!e || !out || !out_len || !n_taken) return clair_host_fail("bad argument");
+    const int64_t worst = (int64_t)e->ctg.size() + 64 + 7 * 16;
+    int64_t at = 0, n = 0;
+    while (!e->out.empty() && cap - at >= worst) {
+        const clair_evc::Cand &c = e->out.front();
+        memcpy(out + at, e->ctg.data(), e->ctg.size());
+        at += (int64_t)e->ctg.size();
+        at += snprintf(out + at, 64, " %lld %c %lld", (long long)c.pos1, c.ref_base, (long long)c.depth);
+        for (int k = 0; k < 7; ++k) at += snprintf(out + at, 16, " %c %d", TALLY_NAME[(int)c.order[k]], c.n[(int)c.order[k]]);
+        out[at++] = '\n';
+        e->out.pop_front();
+        ++n;
+    }
+    *out_len = at;
+    *n_taken = n;
+    return 0;
+}
+
+}  // extern "C"

@@ -85,6 +85,28 @@ int clair_host_pileup_take_text(clair_pileup_t *p, const char *ctg_name, char *o
 /* stats[0..3] = reads walked, windows open, slots left, 1 if the sorted-candidates path is in use */
 int clair_host_pileup_stats(const clair_pileup_t *p, int64_t *stats);
 
+/* -- candidates: alignments -> candidate sites, the work of dataPrepScripts/ExtractVariantCandidates.py:160-393 (make_candidates)
+ *    in inference mode, streaming.  Per alignment of contig ctg_name (:279-281): mapping quality >= min_mq (:291), CIGAR not "*"
+ *    and at least 55 % aligned (:143-157, 293); M/=/X bases are tallied per reference position under their IUPAC_base_to_ACGT base
+ *    (N kept), an insertion / deletion counts once at the position before it (:298-316).  Positions before the current read's
+ *    start are complete (:319): a position is a candidate when it lies in [ctg_start, ctg_end] (1-based; -1, -1 = no range) and in
+ *    the bed intervals (0-based half-open, start == end widened by one, shared/interval_tree.py:30-32; n_bed = -1: no bed file),
+ *    its reference base is an IUPAC code, depth = bases - I - D >= min_coverage, and either the most frequent tally is not the
+ *    reference base or the second one reaches `threshold` of the depth (:357-371; ties keep the order A C G T I D N).
+ *    Rows: "ctg pos refbase depth X n X n ... (7 pairs, descending)" (:379-383).  The training-set switches (--gen4Training,
+ *    --var_fn, --outputProb) sample with Python's random module and are not restated. */
+typedef struct clair_evc clair_evc_t;
+int clair_host_evc_create(const char *ctg_name, const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based,
+                          int64_t ctg_start, int64_t ctg_end, const int64_t *bed_start, const int64_t *bed_end, int64_t n_bed,
+                          double min_coverage, double threshold, int min_mq, clair_evc_t **out);
+void clair_host_evc_destroy(clair_evc_t *e);
+int clair_host_evc_feed(clair_evc_t *e, const char *sam, int64_t len, int final, int64_t *bytes_consumed);
+int clair_host_evc_finish(clair_evc_t *e);
+int64_t clair_host_evc_pending(const clair_evc_t *e);
+int64_t clair_host_evc_reads(const clair_evc_t *e);      /* alignments that passed the filters (:295) */
+int clair_host_evc_take(clair_evc_t *e, int64_t max_rows, int64_t *positions, int64_t *n_taken);   /* 1-based positions only */
+int clair_host_evc_take_text(clair_evc_t *e, char *out, int64_t cap, int64_t *out_len, int64_t *n_taken);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,3 +185,174 @@ def test_cli_reports_missing_reference():
         r = subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--ref_fn", fa, "--ctgName", "nope", "--samtools",
                             FAKE_SAMTOOLS, "--bam_fn", fa], input="", capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 1 and "Failed to load reference" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# candidate extraction (dataPrepScripts/ExtractVariantCandidates.py)
+from clair_amd import extract_variant_candidates as evc  # noqa: E402
+
+EVC_GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "pileup_evc_*.json.gz")))
+
+
+def run_evc_cli(doc, extra=()):
+    with tempfile.TemporaryDirectory() as tmp:
+        fa, sam, bedf, can = (os.path.join(tmp, n) for n in ("ref.fa", "reads.sam", "regions.bed", "cands.gz"))
+        open(fa, "w").write(doc["fasta"])
+        open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (doc["ctg"], doc["ref_len"]))
+        open(sam, "w").write(doc["sam"])
+        args = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", doc["ctg"], "--samtools", FAKE_SAMTOOLS] + doc["args"] + list(extra)
+        if doc["bed"] is not None:
+            open(bedf, "w").write(doc["bed"])
+            args += ["--bed_fn", bedf]
+        if doc["via_file"]:
+            args += ["--can_fn", can]
+        r = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates"] + args, capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        return gzip.open(can, "rt").read() if doc["via_file"] else r.stdout
+
+
+def test_evc_golden_files_present():
+    assert len(EVC_GOLDEN) >= 5
+
+
+@pytest.mark.parametrize("path", EVC_GOLDEN, ids=[os.path.basename(p)[11:-8] for p in EVC_GOLDEN])
+def test_evc_cli_matches_reference_stdout(path):
+    doc = load(path)
+    assert run_evc_cli(doc) == doc["expected"]
+
+
+@pytest.mark.parametrize("path", EVC_GOLDEN[:2] + EVC_GOLDEN[-1:], ids=[os.path.basename(p)[11:-8] for p in EVC_GOLDEN[:2] + EVC_GOLDEN[-1:]])
+def test_evc_python_twin_matches_reference_stdout(path):
+    doc = load(path)
+    assert run_evc_cli(doc, ["--python_pileup"]) == doc["expected"]
+
+
+@pytest.mark.parametrize("seed", [201, 202])
+def test_evc_native_matches_python_twin_and_chains_into_pileup(seed):
+    case = pileup_synth.synth_case(seed=seed, n_reads=300, ref_len=2500)
+    ref = parse_fasta(case["fasta"], case["ctg"]).upper()
+    sam = "".join(l + "\n" for l in case["sam"].splitlines() if not l.startswith("@") and not int(l.split("\t")[1]) & 2316)
+    kw = dict(ctg_start=200, ctg_end=2300, bed=[(0, 1000), (900, 1200), (1800, 1800), (2000, 2600)], min_coverage=3, threshold=0.1, min_mq=5)
+    py = evc.CandidateFinderPy(case["ctg"], ref, 0, **kw)
+    want = "".join(evc.rows_from_sam(py, io.StringIO(sam)))
+    nat = _hostapi.CandidateFinder(case["ctg"], ref, 0, **kw)
+    got = "".join(nat.text_from_sam(io.BytesIO(sam.encode()), chunk_bytes=311))
+    assert got == want and want.count("\n") > 30 and nat.reads == py.reads
+    # positions-only hand-off = column 2 of the rows; feeding them to the pileup builder works end to end
+    nat2 = _hostapi.CandidateFinder(case["ctg"], ref, 0, **kw)
+    assert nat2.feed(sam.encode()) == b""
+    nat2.finish()
+    pos = nat2.take_positions()
+    assert pos.tolist() == [int(r.split()[1]) for r in want.splitlines()]
+    b = _hostapi.PileupBuilder(case["ctg"], ref, 0, pos)
+    b.feed(sam.encode())
+    b.finish()
+    centres, seqs, counts = b.take_arrays()
+    assert centres.tolist() == [p for p in pos.tolist() if p - 17 >= 0]
+    # centre column of a window: channel 0 summed over the 8 rows = matched depth = A+C+G+T(+N) tallies of the candidate row
+    rows = {int(r.split()[1]): r.split() for r in want.splitlines()}
+    for c, t in zip(centres.tolist()[:50], counts[:50]):
+        tally = dict(zip(rows[c][4::2], map(int, rows[c][5::2])))
+        # the finder skips mostly-clipped reads, the pileup does not: equal unless such a read covers the site
+        assert t[16, :, 0].sum() >= tally["A"] + tally["C"] + tally["G"] + tally["T"] + tally["N"]
+
+
+def test_evc_rejects_training_switches_and_missing_index():
+    r = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates", "--gen4Training"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "training" in r.stderr
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, "ref.fa")
+        open(fa, "w").write(">chrA\nACGT\n")
+        r = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates", "--ref_fn", fa, "--ctgName", "chrA"],
+                           capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 1 and ".fai doesn't exist" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the in-process BAM -> tensors path of clair_amd.callVarBam vs the text pipeline
+def _bam_case(tmp, seed=301):
+    case = pileup_synth.synth_case(seed=seed, n_reads=500, ref_len=3000)
+    fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\nchrOther\t120\t3100\t120\t121\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"])
+    return case, fa, sam
+
+
+@pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
+def test_in_process_tensor_batches_equal_the_text_pipeline(region):
+    from clair_amd import callVarBam, utils
+    with tempfile.TemporaryDirectory() as tmp:
+        case, fa, sam = _bam_case(tmp)
+        common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS] + region
+        r1 = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates", "--threshold", "0.15", "--minCoverage", "5"] + common,
+                            capture_output=True, text=True, cwd=ROOT)
+        assert r1.returncode == 0, r1.stderr
+        tensors = os.path.join(tmp, "t.gz")
+        r2 = subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--tensor_fn", tensors] + common, input=r1.stdout,
+                            capture_output=True, text=True, cwd=ROOT)
+        assert r2.returncode == 0, r2.stderr
+        want = list(utils.tensor_generator_from(tensors, 64))
+        args = callVarBam.build_parser().parse_args(common + ["--threshold", "0.15", "--minCoverage", "5", "--chkpnt_fn", "x", "--call_fn", "y"])
+        pos = callVarBam.candidate_positions(args)
+        assert pos.tolist() == [int(r.split()[1]) for r in r1.stdout.splitlines()]
+        got = list(callVarBam.tensor_batches(args, pos, 64))
+    assert len(want) > 2 and len(got) == len(want)
+    for (xg, ig), (xw, iw) in zip(got, want):
+        assert xg.dtype == np.float32 and xg.shape == xw.shape and np.array_equal(xg, xw)
+        assert [list(map(str, i)) for i in ig] == [list(map(str, i)) for i in iw]
+
+
+def test_vcf_sites_as_candidates():
+    from clair_amd import callVarBam
+    with tempfile.TemporaryDirectory() as tmp:
+        vcf = os.path.join(tmp, "sites.vcf")
+        open(vcf, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
+                             "chrS\t100\t.\tA\tG\t.\t.\t.\tGT\t0/1\nchrS\t250\t.\tAC\tA,*\t.\t.\t.\tGT\t1/2\nchrT\t5\t.\tA\tG\t.\t.\t.\tGT\t1/1\n"
+                             "chrS\t900\t.\tA\tG\t.\t.\t.\tGT\t1/1\n")
+        assert callVarBam.positions_from_vcf(vcf, "chrS", None, None).tolist() == [100, 249, 250, 900]
+        assert callVarBam.positions_from_vcf(vcf, "chrS", 200, 899).tolist() == [249, 250]
+
+
+@pytest.mark.gpu
+def test_callVarBam_vcf_equals_three_stage_text_pipeline(tmp_path):
+    """BAM -> VCF in one process (arrays between the stages) vs extract_variant_candidates | create_tensor | call_var over
+    their text interfaces, same random-weights model on the MI355X: byte-identical VCF."""
+    from clair_amd import weights
+    case, fa, sam = _bam_case(str(tmp_path), seed=302)
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    ck = weights.save_weights(str(tmp_path / "model"), w)[:-4]
+    common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS]
+    r1 = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates", "--threshold", "0.125", "--minCoverage", "4"] + common,
+                        capture_output=True, text=True, cwd=ROOT, check=True)
+    tensors = str(tmp_path / "t.gz")
+    subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--tensor_fn", tensors] + common, input=r1.stdout, text=True,
+                   cwd=ROOT, check=True, capture_output=True)
+    v1, v2 = str(tmp_path / "text.vcf"), str(tmp_path / "inproc.vcf")
+    subprocess.run([sys.executable, "-m", "clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors, "--call_fn", v1,
+                    "--ref_fn", fa, "--sampleName", "S1", "--batch_size", "128"], cwd=ROOT, check=True, capture_output=True)
+    subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", v2, "--sampleName", "S1",
+                    "--batch_size", "96"] + common, cwd=ROOT, check=True, capture_output=True)
+    a, b = open(v1).read(), open(v2).read()
+    assert a == b and a.count("\n") > 40
+
+
+def test_callVarBamParallel_commands_match_reference():
+    """Chunking, contig selection, bed filtering and option spelling vs the reference's own output
+    (tests/golden/parallel_cmds.json, tools/make_pileup_goldens.py); only the program name differs."""
+    from clair_amd import callVarBamParallel as par
+    doc = json.load(open(os.path.join(HERE, "golden", "parallel_cmds.json")))
+    for name, case in doc["cases"].items():
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn, text in (("ref.fa", ">x\n"), ("ref.fa.fai", doc["fai"]), ("a.bam", ""), ("model.meta", ""), ("r.bed", doc["bed"])):
+                open(os.path.join(tmp, fn), "w").write(text)
+            argv = ["--chkpnt_fn", os.path.join(tmp, "model"), "--ref_fn", os.path.join(tmp, "ref.fa"), "--bam_fn", os.path.join(tmp, "a.bam"),
+                    "--output_prefix", os.path.join(tmp, "out", "var"), "--pypy", "python3", "--samtools", "gzip", "--python", "PY"] + case["extra"]
+            if case["use_bed"]:
+                argv += ["--bed_fn", os.path.join(tmp, "r.bed")]
+            got = par.commands(par.build_parser().parse_args(argv))
+            want = [l.replace("@TMP@", tmp).replace("python /root/reference/clair/../clair.py callVarBam", "PY -m clair_amd.callVarBam")
+                    for l in case["expected"].splitlines()[2:]]
+            assert got == want, name
+            dealt = par.commands(par.build_parser().parse_args(argv + ["--devices", "8"]))
+            assert [l.rsplit(" ", 2)[1:] for l in dealt] == [["--device", '"%d"' % (i % 8)] for i in range(len(dealt))]

@@ -95,6 +95,74 @@ def mint_create_tensor():
         print(name, "records:", out.count("\n"), "bytes:", len(out))
 
 
+EVC_CASES = {
+    # name: (synth kwargs, extra CLI args, bed text or None, candidates to a gzip file?)
+    "evc_default": (dict(seed=21, n_reads=400), [], None, False),
+    "evc_region_mq": (dict(seed=22, n_reads=400), ["--ctgStart", "400", "--ctgEnd", "2400", "--minMQ", "15"], None, True),
+    "evc_bed": (dict(seed=23, n_reads=400), ["--threshold", "0.2"],
+                "chrS\t100\t600\nchrS\t550\t900\nchrS\t1500\t1500\nchrS\t2000\t2900\nchrOther\t0\t50\n", False),
+    "evc_strict": (dict(seed=24, n_reads=500, sub_rate=0.08), ["--threshold", "0.3", "--minCoverage", "12"], None, False),
+    "evc_lowcov": (dict(seed=25, n_reads=60), ["--minCoverage", "1", "--threshold", "0.05"], None, False),
+}
+
+
+def mint_extract_candidates():
+    for name, (kw, extra, bed, via_file) in EVC_CASES.items():
+        case = pileup_synth.synth_case(**kw)
+        with tempfile.TemporaryDirectory() as tmp:
+            fa, sam, bedf, can = (os.path.join(tmp, n) for n in ("ref.fa", "reads.sam", "regions.bed", "cands.gz"))
+            open(fa, "w").write(case["fasta"])
+            open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (case["ctg"], case["ref_len"]))
+            open(sam, "w").write(case["sam"])
+            stub = os.path.join(tmp, "stub", "intervaltree")
+            os.makedirs(stub)
+            open(os.path.join(stub, "__init__.py"), "w").write(INTERVALTREE_STUB)
+            args = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE] + extra
+            if bed is not None:
+                open(bedf, "w").write(bed)
+                args += ["--bed_fn", bedf]
+            if via_file:
+                args += ["--can_fn", can]
+            out = run_reference("dataPrepScripts.ExtractVariantCandidates", args, None, tmp, os.path.dirname(stub))
+            if via_file:
+                out = gzip.open(can, "rt").read()
+        doc = {"tool": "ExtractVariantCandidates", "args": extra, "ctg": case["ctg"], "ref_len": case["ref_len"], "via_file": via_file,
+               "fasta": case["fasta"], "sam": case["sam"], "bed": bed, "expected": out}
+        with gzip.open(os.path.join(GOLD, "pileup_%s.json.gz" % name), "wt", compresslevel=9) as f:
+            json.dump(doc, f)
+        print(name, "rows:", out.count("\n"), "bytes:", len(out))
+
+
+def mint_parallel():
+    """clair/callVarBamParallel.py: the per-chunk command lines (paths below the temporary directory written as @TMP@)."""
+    fai = "chr1\t25000000\t6\t60\t61\nchr2\t9000000\t7\t60\t61\nchrUn_1\t4000\t8\t60\t61\nX\t1200\t9\t60\t61\n"
+    bed = "chr1\t100\t200\nchr1\t10000000\t10000000\nchr2\t8999999\t9000000\nX\t5\t6\n"
+    docs = {}
+    for name, extra, use_bed in (("plain", [], False), ("bed_all", ["--includingAllContigs", "--qual", "748", "--haploid_precision"], True),
+                                 ("small_chunks", ["--refChunkSize", "7000000", "--threshold", "0.25", "--sampleName", "HG1"], False)):
+        with tempfile.TemporaryDirectory() as tmp:
+            for fn, text in (("ref.fa", ">x\n"), ("ref.fa.fai", fai), ("a.bam", ""), ("model.meta", ""), ("r.bed", bed)):
+                open(os.path.join(tmp, fn), "w").write(text)
+            stub = os.path.join(tmp, "stub", "intervaltree")
+            os.makedirs(stub)
+            open(os.path.join(stub, "__init__.py"), "w").write(INTERVALTREE_STUB)
+            args = ["--chkpnt_fn", os.path.join(tmp, "model"), "--ref_fn", os.path.join(tmp, "ref.fa"), "--bam_fn", os.path.join(tmp, "a.bam"),
+                    "--output_prefix", os.path.join(tmp, "out", "var"), "--pypy", "python3", "--samtools", "gzip"] + extra
+            if use_bed:
+                args += ["--bed_fn", os.path.join(tmp, "r.bed")]
+            out = run_reference("clair.callVarBamParallel", args, None, tmp, os.path.dirname(stub))
+            docs[name] = {"extra": extra, "use_bed": use_bed, "expected": out.replace(tmp, "@TMP@")}
+    with open(os.path.join(GOLD, "parallel_cmds.json"), "w") as f:
+        json.dump({"fai": fai, "bed": bed, "cases": docs}, f, indent=1)
+    print("parallel_cmds:", {k: v["expected"].count("\n") for k, v in docs.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    mint_create_tensor()
+    if "--parallel-only" in sys.argv:
+        mint_parallel()
+        sys.exit(0)
+    if "--evc-only" not in sys.argv:
+        mint_create_tensor()
+    mint_extract_candidates()
+    mint_parallel()
