@@ -53,12 +53,7 @@ struct Window {
     int64_t used = 0;        // tuples the reference would be holding for this window
     uint64_t order = 0;      // first-touch sequence number: the reference writes windows in dict insertion order
     int64_t depth_centre = 0;
-    int32_t counts[N_VAL];
-};
-
-struct Record {
-    int64_t centre;
-    int seq_len;
+    int seq_len = 0;         // set when the window is finished: the reference bases under it
     char seq[N_POS + 1];
     int32_t counts[N_VAL];
 };
@@ -89,7 +84,8 @@ struct clair_pileup {
     uint64_t next_order = 0;
     int64_t prev_pos = 0;
     int64_t depth_cap = 0;
-    std::deque<Record> out;
+    std::vector<Window *> out;             // finished windows; [out_head, size) not taken yet (then back to the pool)
+    size_t out_head = 0;
     std::vector<Active> active;            // per read
     std::vector<Window *> flushed;         // scratch
     int64_t reads_seen = 0;
@@ -97,6 +93,7 @@ struct clair_pileup {
     ~clair_pileup() {
         for (auto &kv : live) delete kv.second;
         for (Window *w : pool) delete w;
+        for (size_t i = out_head; i < out.size(); ++i) delete out[i];
     }
 
     Window *new_window(int64_t centre) {
@@ -163,11 +160,12 @@ struct clair_pileup {
             if (active[i].centre == centre) { active.erase(active.begin() + (long)i); return; }
     }
 
-    // one tuple of the reference's alignment lists applied to one window (generate_tensor :34-56)
-    inline void count(Window *w, int64_t rp, int64_t query_adv, char rb, char qb, int so) {
+    // one tuple of the reference's alignment lists applied to one window (generate_tensor :34-56); rn / qn: row of the
+    // reference / read base, -2 for the gap character, -1 for a character outside BASES (tuple kept, never counted)
+    static inline int base_row(char b) { return b == '-' ? -2 : BASE.num[(unsigned char)b]; }
+    inline void count(Window *w, int64_t rp, int64_t query_adv, int rn, int qn, int so) {
         w->used += 1;
         slots -= 1;
-        const int rn = rb == '-' ? -2 : BASE.num[(unsigned char)rb], qn = qb == '-' ? -2 : BASE.num[(unsigned char)qb];
         if (rn == -1 || qn == -1) return;
         int64_t idx = rp - w->centre + (FLANK + 1);
         if (idx < 0 || idx >= N_POS) return;
@@ -186,19 +184,22 @@ struct clair_pileup {
         }
     }
 
-    void finish_window(Window *w) {
+    // -> true: the window went to the output queue (which owns it now); false: dropped, the caller recycles it
+    bool finish_window(Window *w) {
         const int64_t nrp = w->centre - ref0;
-        if (nrp - (FLANK + 1) < 0 || w->depth_centre < min_cov) return;
+        if (nrp - (FLANK + 1) < 0 || w->depth_centre < min_cov) return false;
         // reference_sequence[nrp-17 : nrp+16]: a Python slice, clamped to the string
         const int64_t a = std::min<int64_t>(nrp - (FLANK + 1), (int64_t)ref.size());
         const int64_t b = std::min<int64_t>(nrp + FLANK, (int64_t)ref.size());
-        out.emplace_back();
-        Record &r = out.back();
-        r.centre = w->centre;
-        r.seq_len = (int)std::max<int64_t>(0, b - a);
-        memcpy(r.seq, ref.data() + a, (size_t)r.seq_len);
-        r.seq[r.seq_len] = 0;
-        memcpy(r.counts, w->counts, sizeof r.counts);
+        w->seq_len = (int)std::max<int64_t>(0, b - a);
+        memcpy(w->seq, ref.data() + a, (size_t)w->seq_len);
+        w->seq[w->seq_len] = 0;
+        out.push_back(w);
+        return true;
+    }
+
+    void taken_up_to_head() {
+        if (out_head == out.size()) { out.clear(); out_head = 0; }
     }
 
     int add_read(int flag, int64_t pos1, int64_t mapq, const char *cigar, size_t cigar_len, char *seq, size_t seq_len) {
@@ -248,10 +249,10 @@ struct clair_pileup {
                         if (qp >= (int64_t)seq_len) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%zu bases)", (long long)pos1, seq_len);
                         char rb;
                         if (!ref_base(rp, &rb)) return 1;
-                        const char qb = seq[qp];
+                        const int rn = base_row(rb), qn = base_row(seq[qp]);
                         for (const Active &a : active) {
                             if (slots <= 0) break;
-                            count(a.win, rp, 0, rb, qb, so);
+                            count(a.win, rp, 0, rn, qn, so);
                         }
                     }
                     if (!active.empty() && active.front().centre <= rp - (FLANK + 1)) close_window_ending_at(rp);
@@ -263,10 +264,10 @@ struct clair_pileup {
                 for (int64_t k = 0; k < adv; ++k) {
                     if (!active.empty() && slots > 0) {
                         if (qp >= (int64_t)seq_len) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%zu bases)", (long long)pos1, seq_len);
-                        const char qb = seq[qp];
+                        const int qn = base_row(seq[qp]);
                         for (const Active &a : active) {
                             if (slots <= 0) break;
-                            count(a.win, rp, k, '-', qb, so);
+                            count(a.win, rp, k, -2, qn, so);
                         }
                     }
                     ++qp;
@@ -277,9 +278,10 @@ struct clair_pileup {
                     if (!active.empty() && slots > 0) {
                         char rb;
                         if (!ref_base(rp, &rb)) return 1;
+                        const int rn = base_row(rb);
                         for (const Active &a : active) {
                             if (slots <= 0) break;
-                            count(a.win, rp, 0, rb, '-', so);
+                            count(a.win, rp, 0, rn, -2, so);
                         }
                     }
                     open_at(rp);
@@ -298,9 +300,8 @@ struct clair_pileup {
             }
             std::sort(flushed.begin(), flushed.end(), [](const Window *a, const Window *b) { return a->order < b->order; });
             for (Window *w : flushed) {
-                finish_window(w);
                 slots += w->used;
-                pool.push_back(w);
+                if (!finish_window(w)) pool.push_back(w);
             }
         }
         ++reads_seen;
@@ -393,27 +394,27 @@ int clair_host_pileup_finish(clair_pileup_t *p) {
     for (auto &kv : p->live) p->flushed.push_back(kv.second);
     p->live.clear();
     std::sort(p->flushed.begin(), p->flushed.end(), [](const Window *a, const Window *b) { return a->order < b->order; });
-    for (Window *w : p->flushed) {
-        p->finish_window(w);
-        p->pool.push_back(w);
-    }
+    for (Window *w : p->flushed)
+        if (!p->finish_window(w)) p->pool.push_back(w);
     return 0;
 }
 
-int64_t clair_host_pileup_pending(const clair_pileup_t *p) { return p ? (int64_t)p->out.size() : 0; }
+int64_t clair_host_pileup_pending(const clair_pileup_t *p) { return p ? (int64_t)(p->out.size() - p->out_head) : 0; }
 
 int clair_host_pileup_take(clair_pileup_t *p, int64_t max_rows, int64_t *centres, char *refseq, int32_t *counts, int64_t *n_taken) {
     if (!p || !centres || !refseq || !counts || !n_taken || max_rows < 0) return clair_host_fail("bad argument");
     int64_t n = 0;
-    while (n < max_rows && !p->out.empty()) {
-        const Record &r = p->out.front();
+    while (n < max_rows && p->out_head < p->out.size()) {
+        Window *w = p->out[p->out_head++];
+        const Window &r = *w;
         centres[n] = r.centre;
         memset(refseq + n * (N_POS + 1), 0, N_POS + 1);
         memcpy(refseq + n * (N_POS + 1), r.seq, (size_t)r.seq_len);
         memcpy(counts + n * N_VAL, r.counts, sizeof r.counts);
-        p->out.pop_front();
+        p->pool.push_back(w);
         ++n;
     }
+    p->taken_up_to_head();
     *n_taken = n;
     return 0;
 }
@@ -424,8 +425,9 @@ int clair_host_pileup_take_text(clair_pileup_t *p, const char *ctg_name, char *o
     // worst case per record: ctg + ' ' + 20 digits + ' ' + 33 + 1056 * (1 + 11) + '\n'
     const int64_t worst = (int64_t)ctg_len + 1 + 20 + 1 + N_POS + (int64_t)N_VAL * 12 + 1;
     int64_t at = 0, n = 0;
-    while (!p->out.empty() && cap - at >= worst) {
-        const Record &r = p->out.front();
+    while (p->out_head < p->out.size() && cap - at >= worst) {
+        Window *w = p->out[p->out_head];
+        const Window &r = *w;
         memcpy(out + at, ctg_name, ctg_len);
         at += (int64_t)ctg_len;
         at += snprintf(out + at, 24, " %lld ", (long long)r.centre);
@@ -443,9 +445,11 @@ int clair_host_pileup_take_text(clair_pileup_t *p, const char *ctg_name, char *o
             while (k) out[at++] = tmp[--k];
         }
         out[at++] = '\n';
-        p->out.pop_front();
+        ++p->out_head;
+        p->pool.push_back(w);
         ++n;
     }
+    p->taken_up_to_head();
     *out_len = at;
     *n_taken = n;
     return 0;
@@ -498,8 +502,21 @@ struct clair_evc {
     std::vector<int64_t> bed_start, bed_end;   // sorted, merged, 0-based half-open
     double min_depth = 4, min_af = 0.125;
     int min_mq = 0;
-    std::map<int64_t, Tally> pileup;
+    // pileup[position] of the reference (:265) as a dense window over the positions still open: base .. base + size
+    std::deque<Tally> window;
+    int64_t base = 0;
     int64_t reads = 0, lines_seen = 0;
+
+    inline Tally &at(int64_t p) {
+        if (window.empty()) base = p;
+        if (p < base) {   // unsorted input only
+            window.insert(window.begin(), (size_t)(base - p), Tally{{0, 0, 0, 0, 0, 0, 0}});
+            base = p;
+        }
+        const int64_t i = p - base;
+        if (i >= (int64_t)window.size()) window.resize((size_t)i + 1, Tally{{0, 0, 0, 0, 0, 0, 0}});
+        return window[(size_t)i];
+    }
     struct Cand { int64_t pos1; char ref_base; int64_t depth; signed char order[7]; int32_t n[7]; };
     std::deque<Cand> out;
 
@@ -510,10 +527,11 @@ struct clair_evc {
     }
 
     void flush(int64_t before, bool all) {
-        auto it = pileup.begin();
-        while (it != pileup.end() && (all || it->first < before)) {
-            emit(it->first, it->second);
-            it = pileup.erase(it);
+        while (!window.empty() && (all || base < before)) {
+            const Tally &t = window.front();
+            if (t.n[0] | t.n[1] | t.n[2] | t.n[3] | t.n[4] | t.n[5] | t.n[6]) emit(base, t);   // a key of the reference's dict
+            window.pop_front();
+            ++base;
         }
     }
 
@@ -590,6 +608,9 @@ struct clair_evc {
             if (1.0 - (double)soft / (double)(total + 1) < 0.55) return 0;
         }
         ++reads;
+        // positions before POS - 1 cannot change any more: write them now rather than zero-filling across a coverage gap
+        // (POS - 1 itself can still receive this read's leading insertion / deletion, :307-313)
+        if (!window.empty() && pos - 1 > base + (int64_t)window.size()) flush(pos - 1, false);
         const char *seq = col[9];
         const int64_t sl = (int64_t)len[9];
         int64_t rp = pos, qp = 0, adv = 0;
@@ -605,15 +626,15 @@ struct clair_evc {
                     if (b >= 'a' && b <= 'z') b = (unsigned char)(b - 32);
                     const int bi = ACGT.idx[b];
                     if (bi < 0) return clair_host_fail("read at %lld: SEQ holds '%c', not an IUPAC base code", (long long)v[0], (char)b);
-                    pileup[rp].n[bi] += 1;
+                    at(rp).n[bi] += 1;
                     ++rp;
                     ++qp;
                 }
             } else if (ch == 'I') {
-                pileup[rp - 1].n[4] += 1;
+                at(rp - 1).n[4] += 1;
                 qp += adv;
             } else if (ch == 'D') {
-                pileup[rp - 1].n[5] += 1;
+                at(rp - 1).n[5] += 1;
                 rp += adv;
             }
             adv = 0;
