@@ -322,10 +322,12 @@ def output_aln_tensor(args, native=True):
                            dcov=args.dcov, min_coverage=args.minCoverage, min_mq=args.minMQ)
     have_region = args.ctgStart is not None and args.ctgEnd is not None
     region = "%s:%d-%d" % (args.ctgName, args.ctgStart, args.ctgEnd) if have_region else args.ctgName
+    is_native = not isinstance(builder, PileupBuilderPy)      # the native builder takes the bytes as they come
     if getattr(args, "sam_fn", None):
-        view, sam_handle = None, open(args.sam_fn)
+        view, sam_handle = None, open(args.sam_fn, "rb" if is_native else "r")
     else:
-        view = subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)))
+        view = subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+                                text=not is_native)
         sam_handle = view.stdout
 
     gz = None
