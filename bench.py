@@ -209,8 +209,11 @@ def main():
             "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
             "note": "matmuls run as 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
             "measured": "HIP events on the kernel's stream, %d launches on one stream right after the timed region "
-                        "(no other stream active)" % iso_steps,
+                        "(no other stream active): the 'alone' column of profiles/r01_bench_default_streams3_kernel_stats.txt "
+                        "(rocprofv3 --kernel-trace --stats of this command); overlapped_kernel_ms = the same kernel with the "
+                        "other slots' kernels sharing the chip, the 'timed' / 'instrum.' columns" % iso_steps,
             "overlapped_kernel_ms": round(ovl_ms, 4),
+            "frac_overlapped": round(roof["frac"] * dom_ms / ovl_ms, 4) if ovl_ms else None,
             "workgroups": wgs[dom], "cu_share": round(cu_share[dom], 4),
             "frac_of_cu_share": round(roof["frac"] / cu_share[dom], 4),
             "cu_share_note": "the kernel is launched on this share of the 256 CUs (one persistent workgroup per CU) so that "

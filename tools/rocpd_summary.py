@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite result (--kernel-trace --stats) as a text table.
 
-usage: tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--skip-first N] > profiles/rNN_....txt
+usage: tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--skip-first N] [--phases W,K,I] > profiles/rNN_....txt
 Per kernel: calls, total / mean / min / max duration (us) and share of GPU kernel time;
 VGPR/AGPR/LDS as recorded by the tracer.  --skip-first drops the first N dispatches of each
-kernel (warm-up launches) so the means line up with bench.py's timed region.
+kernel (warm-up launches) so the means line up with bench.py's timed region.  --phases W,K,I splits each kernel's dispatches the way bench.py issues
+them -- W warm-up launches, K timed steps (batches overlapped on the slots), K instrumented steps, I launches alone on one stream
+-- and prints the mean of each phase: the K-step mean is `roofline.overlapped_kernel_ms`, the last-I mean is `roofline.kernel_ms`.
 """
 import sqlite3
 import sys
@@ -35,6 +37,18 @@ def main():
         print("%-58s %6d %12.1f %10.2f %10.2f %10.2f %6.2f  %dx%dx%d/%d %d+%d %d %d"
               % (short, n, tot, mean, mn, mx, 100.0 * tot / total, g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10]))
     print("# total kernel time %.1f us over %d dispatches" % (total, sum(s[2] for s in stats)))
+    if "--phases" in sys.argv:
+        w, k, i = (int(v) for v in sys.argv[sys.argv.index("--phases") + 1].split(","))
+        print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches overlapped | %d instrumented steps | %d "
+              "launches alone on one stream" % (w, k, k, i))
+        print("%-58s %10s %10s %10s %10s" % ("kernel", "warm-up", "timed", "instrum.", "alone"))
+        for name, rs in per.items():
+            d = [(r[2] - r[1]) / 1e3 for r in rs]
+            if len(d) != w + 2 * k + i:
+                continue
+            cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:]]
+            short = name if len(name) <= 58 else name[:55] + "..."
+            print("%-58s %10.2f %10.2f %10.2f %10.2f" % ((short,) + tuple(sum(c) / max(len(c), 1) for c in cut)))
 
 
 if __name__ == "__main__":
