@@ -16,7 +16,7 @@ SYMBOLS = (
     "clair_abi_version", "clair_device_count", "clair_last_error",
     "clair_engine_create", "clair_engine_destroy",
     "clair_set_tensor", "clair_finalize_weights",
-    "clair_predict", "clair_submit", "clair_wait",
+    "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts",
     "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
@@ -55,6 +55,8 @@ def load():
     lib.clair_predict.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.clair_submit.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.clair_wait.argtypes = [c_vp, c_int]
+    lib.clair_slot_input.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
+    lib.clair_submit_counts.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.clair_dataset_alloc.argtypes = [c_vp, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]
     lib.clair_dataset_free.argtypes = [c_vp, c_vp, c_vp]
     lib.clair_dataset_upload.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64]
@@ -140,6 +142,24 @@ class Engine(object):
         outs = self._alloc_out(x.shape[0])
         self._check(self._lib.clair_submit(self._h, slot, _ptr(x), x.shape[0], *[_ptr(o) for o in outs]), "clair_submit")
         self._pending[slot] = (x, outs)  # keep the buffers alive until wait()
+
+    def submit_counts(self, slot, counts):
+        """submit() for raw pileup counts [n,33,8,4] int16 (channel 0 not yet subtracted): half the bytes on the host link,
+        conversion on the device; pair with wait(slot)."""
+        c = np.ascontiguousarray(counts, dtype=np.int16)
+        if c.ndim != 4 or c.shape[1:] != (33, 8, 4):
+            raise ValueError("counts must have shape [n,33,8,4], got %r" % (c.shape,))
+        outs = self._alloc_out(c.shape[0])
+        self._check(self._lib.clair_submit_counts(self._h, slot, _ptr(c), c.shape[0], *[_ptr(o) for o in outs]), "clair_submit_counts")
+        self._pending[slot] = (c, outs)
+
+    def slot_input(self, slot):
+        """The slot's page-locked input buffer as a NumPy array [max_batch,33,8,4] float32: fill rows [0,n) and submit
+        `buf[:n]` for a direct DMA transfer instead of the staged copy pageable arrays get."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.clair_slot_input(self._h, int(slot), ctypes.byref(p)), "clair_slot_input")
+        n = self.max_batch * 1056
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(n,)).reshape(self.max_batch, 33, 8, 4)
 
     def wait(self, slot):
         self._check(self._lib.clair_wait(self._h, slot), "clair_wait")

@@ -112,27 +112,29 @@ def tensor_batches(args, positions, batch_size):
     view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
                                text=False)
     total = 0
-    held_x, held_info, held = [], [], 0
+    held_c, held_info, held = [], [], 0
 
     def drain(final):
-        nonlocal held_x, held_info, held, total
+        nonlocal held_c, held_info, held, total
         while builder.pending():
             centres, seqs, counts = builder.take_arrays(4 * batch_size)
             keep = np.fromiter((len(s) > 16 and s[16] in IUPAC for s in seqs), dtype=bool, count=len(seqs))
-            x = counts[keep].astype(np.float32)
-            x[:, :, :, 1:] -= x[:, :, :, 0:1]
-            held_x.append(x)
+            held_c.append(counts[keep])
             held_info.extend([args.ctgName, str(int(c)), s] for c, s, k in zip(centres, seqs, keep) if k)
-            held += len(x)
+            held += int(keep.sum())
         while held >= batch_size or (final and held > 0):
-            x = np.concatenate(held_x) if len(held_x) > 1 else held_x[0]
+            c = np.concatenate(held_c) if len(held_c) > 1 else held_c[0]
             n = min(batch_size, held)
-            yield_x, rest = x[:n], x[n:]
+            counts, rest = c[:n], c[n:]
             infos, held_info = held_info[:n], held_info[n:]
-            held_x, held = ([rest] if len(rest) else []), len(rest)
+            held_c, held = ([rest] if len(rest) else []), len(rest)
             total += n
             print("Processed %d tensors" % total, file=sys.stderr)
-            yield np.ascontiguousarray(yield_x), infos
+            x = counts.astype(np.float32)                 # the decode reads depth and allele support from the tensor
+            x[:, :, :, 1:] -= x[:, :, :, 0:1]
+            # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
+            small = counts.astype(np.int16) if counts.size and int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
+            yield x, infos, small
 
     tail = None
     while True:

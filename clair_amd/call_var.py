@@ -587,7 +587,8 @@ class VcfWriter(object):
 def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     """call_var.py:1312-1367.  Software pipeline per iteration: decode+write batch k-1, forward pass
     of batch k (asynchronous on the GPU), parse batch k+1; rows appear in input order.  `generator` replaces the
-    --tensor_fn reader with another source of (X, infos) batches (clair_amd.callVarBam hands pileup arrays over)."""
+    --tensor_fn reader with another source of (X, infos) batches (clair_amd.callVarBam hands pileup arrays over); a third
+    element, the raw int16 counts of the same batch, is sent to the GPU instead of X when the model can take it."""
     writer.write_header()
     batch_size = batch_size or param.predictBatchSize
     if generator is None:
@@ -614,7 +615,9 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
         threads = []
         slot = k % 2
         if current is not None:
-            if use_async:
+            if use_async and len(current) > 2 and current[2] is not None and hasattr(m, "submit_counts"):
+                m.submit_counts(slot, current[2])
+            elif use_async:
                 m.submit(slot, current[0])
             threads.append(Thread(target=load))
         if finished is not None:

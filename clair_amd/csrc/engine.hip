@@ -42,6 +42,8 @@ struct Slot {
     float *l4part = nullptr;  // [16][max_pad][192]
     float *d_out = nullptr;   // [max_pad][90]
     float *h_out = nullptr;   // pinned [max_batch][90]
+    float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
+    short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first clair_submit_counts
     // pending host outputs of a submit
     float *o_gt21 = nullptr, *o_gt = nullptr, *o_l1 = nullptr, *o_l2 = nullptr;
     int pending_n = 0;
@@ -169,6 +171,8 @@ void free_slot(Slot &s) {
     (void)hipFree(s.d_x); (void)hipFree(s.zx); (void)hipFree(s.a1); (void)hipFree(s.a2);
     (void)hipFree(s.l4part); (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.h_x) (void)hipHostFree(s.h_x);
+    if (s.d_counts) (void)hipFree(s.d_counts);
     if (s.stream) (void)hipStreamDestroy(s.stream);
 }
 
@@ -435,6 +439,46 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
     HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
     s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
     s.pending_n = n;
+    return 0;
+}
+
+// raw counts -> network input (clair/utils.py:96-98): one (position, row) quad of four channels per thread
+__global__ __launch_bounds__(256) void counts_to_input_kernel(const short4 *counts, f32x4 *x, int n_quads) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_quads) return;
+    const short4 c = counts[i];
+    const float c0 = (float)c.x;
+    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
+}
+
+int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int n, float *gt21, float *genotype, float *l1, float *l2) {
+    if (check_slot(e, slot)) return 1;
+    if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
+    if (!counts || !gt21 || !genotype || !l1 || !l2) return fail(e, "NULL input/output pointer");
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
+    if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
+    const int n_pad = (n + 31) & ~31;
+    HIP_TRY(e, hipMemcpyAsync(s.d_counts, counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
+    const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
+    hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
+    if (n_pad > n)
+        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
+    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
+    HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
+    s.pending_n = n;
+    return 0;
+}
+
+int clair_slot_input(clair_engine_t *e, int slot, float **x_pinned) {
+    if (check_slot(e, slot)) return 1;
+    if (!x_pinned) return fail(e, "x_pinned is NULL");
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+    *x_pinned = s.h_x;
     return 0;
 }
 

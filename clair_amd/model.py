@@ -84,6 +84,11 @@ class Clair(object):
     def submit(self, slot, batchX):
         self._engine.submit(slot, batchX)
 
+    def submit_counts(self, slot, counts):
+        """submit() for raw pileup counts [n,33,8,4] int16 (before clair/utils.py:96-98): the subtraction and the conversion
+        run on the device, the host link carries half the bytes.  Same outputs as submit() on the float32 tensor."""
+        self._engine.submit_counts(slot, counts)
+
     def wait(self, slot):
         return self._engine.wait(slot)
 

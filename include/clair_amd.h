@@ -110,6 +110,17 @@ int clair_predict(clair_engine_t *e, const float *x, int n, float *gt21, float *
 int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21, float *genotype,
                  float *indel_len1, float *indel_len2);
 int clair_wait(clair_engine_t *e, int slot);
+/* The slot's own page-locked input buffer, [max_batch][33][8][4] float32.  A producer that writes its batch there and passes
+ * this pointer as `x` to clair_submit gets a direct DMA transfer (pageable memory goes through the runtime's staging copies at
+ * about a third of the PCIe rate).  The buffer belongs to the handle; it may be refilled once clair_wait(slot) has returned. */
+int clair_slot_input(clair_engine_t *e, int slot, float **x_pinned);
+/* The pipelined call for a producer that holds the RAW pileup counts (dataPrepScripts/CreateTensor.py:29-65: what the text
+ * records carry before clair/utils.py:96-98 subtracts channel 0 from channels 1..3): counts [n][33][8][4] int16, half the bytes
+ * of the float32 tensor on the host link, which is what bounds the host-buffer boundary.  The subtraction
+ * and the conversion run on the device; the results are bit-identical to clair_submit on the float32 tensor utils.py would
+ * build from the same counts (every count is exactly representable).  Counts above 32767 do not fit: the caller checks. */
+int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int n, float *gt21, float *genotype,
+                        float *indel_len1, float *indel_len2);
 
 /* -- device-resident candidate sets (benchmark / multi-GPU shard driver) ------------------------
  * The candidate set lives in HBM: x_dev [N,33,8,4]; outputs out_dev [N,90] rows laid out

@@ -177,3 +177,30 @@ def test_gt_concordance_on_synthetic_set(engine, synth_weights):
     assert len(rows_g) == len(rows_w) > 0
     flips = sum(key(a) != key(b) for a, b in zip(rows_g, rows_w))
     assert flips == 0
+
+
+def test_slot_input_buffer_submits_by_dma(engine):
+    """clair_slot_input: a batch written into the slot's page-locked buffer gives the same outputs as the pageable path."""
+    x, _ = synth.synthetic_input(200, "ont", seed=77)
+    want = engine.predict(x)
+    buf = engine.slot_input(1)
+    assert buf.shape[1:] == (33, 8, 4) and buf.dtype == np.float32 and buf.shape[0] >= 200
+    buf[:200] = x
+    engine.submit(1, buf[:200])
+    got = engine.wait(1)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert engine.slot_input(1).ctypes.data == buf.ctypes.data
+
+
+def test_submit_counts_equals_submit_on_the_float_tensor(engine):
+    """clair_submit_counts: raw int16 counts in, channel subtraction on the device == clair_submit on utils.py's float tensor."""
+    rng = np.random.default_rng(5)
+    counts = rng.integers(0, 120, size=(300, 33, 8, 4)).astype(np.int16)
+    counts[7] = 0
+    counts[8, :, :, 0] = 32767
+    x = counts.astype(np.float32)
+    x[..., 1:] -= x[..., 0:1]
+    want = engine.predict(x)
+    engine.submit_counts(0, counts)
+    got = engine.wait(0)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))

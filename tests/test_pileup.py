@@ -298,8 +298,9 @@ def test_in_process_tensor_batches_equal_the_text_pipeline(region):
         assert pos.tolist() == [int(r.split()[1]) for r in r1.stdout.splitlines()]
         got = list(callVarBam.tensor_batches(args, pos, 64))
     assert len(want) > 2 and len(got) == len(want)
-    for (xg, ig), (xw, iw) in zip(got, want):
+    for (xg, ig, cg), (xw, iw) in zip(got, want):
         assert xg.dtype == np.float32 and xg.shape == xw.shape and np.array_equal(xg, xw)
+        assert cg.dtype == np.int16 and np.array_equal(cg[..., 0], xw[..., 0]) and np.array_equal(cg[..., 1:] - cg[..., 0:1], xw[..., 1:])
         assert [list(map(str, i)) for i in ig] == [list(map(str, i)) for i in iw]
 
 
