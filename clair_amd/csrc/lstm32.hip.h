@@ -59,8 +59,9 @@ namespace clair {
 #endif
 #ifdef L32_PROBE   // tools/ubench/lstm32_probe.hip only: s_memtime stamps of workgroup 0, wave 0
 __device__ long long *l32_stamps;   // [33 steps][16]
-#ifdef L32_PROBE_NOSTAMP   // launch time only (for the -DL32_PROBE_* ablations)
-#define L32_STAMP(i)
+#ifdef L32_PROBE_NOSTAMP   // launch time and the first / last stamp only (for the -DL32_PROBE_* ablations)
+#define L32_STAMP(i) if ((i) == 0 && s == 0 && blockIdx.x == 0 && tid == 0) l32_stamps[0] = __builtin_readcyclecounter(); \
+                     if ((i) == 6 && s == T_POS - 1 && blockIdx.x == 0 && tid == 0) l32_stamps[1] = __builtin_readcyclecounter();
 #else
 #define L32_STAMP(i) if (blockIdx.x == 0 && tid == 0) l32_stamps[s * 16 + (i)] = __builtin_readcyclecounter();
 #endif
@@ -263,10 +264,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
 
-    f32x16 acc[2];        // block b accumulates in acc[b & 1]
-    f32x16 zq[FIRST ? 1 : 4];   // seeds: layer 2 [b] = block b of the next step it is needed in; layer 1 [0] = next block's bias
-    f32x4 xreg;           // layer 1: this thread's 16 bytes of x two steps ahead
-    f16x8 xh[2], xl[2];   // layer 1: this step's B fragments (k-step kk), hi / lo plane
+    f32x16 acc[2];        // layer 2: block b accumulates in acc[b & 1]
+    f32x16 xacc[4];       // layer 1: block b accumulates in xacc[b], which already holds bias + x-part when the step begins
+    f32x16 zq[4];         // layer 2 seeds: [b] = block b of the next step it is needed in
+    f32x4 xreg;           // layer 1: this thread's 16 bytes of x three steps ahead
+    f16x8 xh[2], xl[2];   // layer 1: the NEXT step's B fragments (k-step kk), hi / lo plane
+#define L32_ACC(b) (*(FIRST ? &xacc[(b)] : &acc[(b) & 1]))
     f16x8 hf[8][2];       // B fragments of h_{s-1}: [kk][plane]
     f16x8 wxa[2][2][2];   // layer 1: A fragments of Wx1 for block b in [b & 1][kk][plane], fetched from LDS a block ahead
     auto load_wx = [&](f16x8 (&dst)[2][2], int b) {
@@ -279,21 +282,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // h_{-1} = 0: step 0 runs the same code as every other step (its h-part MFMAs add zero)
     for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) ((f32x4 *)&hbuf[1][0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (FIRST) {
-        xreg = load_x(0);
-        split_x(xreg, 0);
-        split_x(xreg, 1);
-        split_x(xreg, 2);
-        stage_x(0);
-        xreg = load_x(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xreg = load_x(t);
+            split_x(xreg, 0);
+            split_x(xreg, 1);
+            split_x(xreg, 2);
+            stage_x(t);
+        }
+        xreg = load_x(2);
     } else {
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_seed(zq[b], 0, b);
     }
-    __syncthreads();   // zeros, Wx1 fragments and bias quads visible
-    if (FIRST) {
-        load_seed(zq[0], 0, 0);
-        load_wx(wxa[0], 0);
-    }
+    __syncthreads();   // zeros, Wx1 fragments, bias quads and the first two input tiles visible
 
     // Gate math of one block (4 elements per lane), as a static schedule of 23 "gaps" of 3-5 instructions: gap G
     // is issued right after MFMA G of the next block.  Within a gap all instructions are independent, every
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define L32_OP_LP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp[q]) : "v"(tt[2 * (q)]), "v"(tt[2 * (q) + 1]));
 #define L32_GAP(G, PB)                                                                                            \
     {                                                                                                             \
-        const f32x16 &Z = acc[(PB) & 1];                                                                          \
+        const f32x16 &Z = L32_ACC(PB);                                                                            \
         float (&C_)[4] = cst[PB];                                                                                 \
         switch (G) {                                                                                              \
             case 1: L32_OP_E(eg, 1, 0) L32_OP_E(eg, 1, 1) L32_OP_E(eg, 1, 2) break;                               \
@@ -361,46 +363,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if ((B) == 0 && (M) % 3 == 0) { L32_STAMP(8 + (M) / 3) }                                                      \
-    if ((M) == 3) {   /* after the keep-alive below: the refill can land in the very registers it replaces */     \
-        if (FIRST) load_seed(zq[0], 0, ((B) + 1) & 3);                                                            \
-        else if (L32_PROBE_ZQ) load_seed(zq[B], s + 1, B);                                                        \
-    }                                                                                                             \
-    if (L32_PROBE_GATES && (B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                  \
-    if ((M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */    \
+    if (!FIRST && (M) == 3 && L32_PROBE_ZQ) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
+    if ((L32_PROBE_GATES || (M) == 23) && (B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                  \
+    if (!FIRST && (M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */ \
+    if (FIRST && (B) > 0 && (M) == 8) load_seed(xacc[(B) - 1], 0, (B) - 1);   /* the gates above read their accumulators in gaps 1-7: block B-1's restarts from its bias */ \
     if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
         if ((M) >= 12 && (M) < 20 && ((M) & 1) == 0) copy_write(s_prev, ((M) - 12) >> 1);                          \
     }                                                                                                             \
-    if (FIRST && (M) == 8) load_wx(wxa[((B) + 1) & 1], ((B) + 1) & 3);   /* the next block's Wx1 fragments (its first MFMA would wait for them) */ \
-    if (FIRST && (B) == 0) {   /* x_{s+1} (loaded a step ago): split, stage into the other tile (last read at the head of step s-1), fetch x_{s+2} */ \
+    if (FIRST && (B) == 0) {   /* x_{s+2} (loaded a step ago): split, stage into the tile this step does not read */ \
         if ((M) >= 20 && (M) <= 22) split_x(xreg, (M) - 20);                                                      \
-        if ((M) == 24) stage_x(s + 1);                                                                            \
-        if ((M) == 26) xreg = load_x(s + 2);                                                                      \
+        if ((M) == 23) stage_x(s + 2);                                                                            \
+    }                                                                                                             \
+    if (FIRST && (B) == 1 && (M) == 0) xreg = load_x(s + 3);                                                      \
+    if (FIRST && (B) == 3) {   /* operands of the x-part that follows block 3: x_{s+1} fragments, Wx1 fragments of blocks 0 and 1 */ \
+        if ((M) == 12) read_xfrag(s + 1);                                                                         \
+        if ((M) == 14) load_wx(wxa[0], 0);                                                                        \
+        if ((M) == 16) load_wx(wxa[1], 1);                                                                        \
     }                                                                                                             \
     __builtin_amdgcn_sched_barrier(0);
 
 #define L32_BLOCK(b)                                                                                              \
     {                                                                                                             \
-            constexpr int NM = FIRST ? 30 : 24;                                                                  \
-            const f32x16 zold = zq[FIRST ? 0 : b];                                                               \
-            if (FIRST) {                                                                                         \
-_Pragma("unroll")                                                                                                \
-                for (int m = 0; m < 6; ++m) {                                                                    \
-                    const int kk = m / 3, term = m % 3;                                                          \
-                    if (m == 0) mfma32_vv_first(acc[b & 1], wxa[b & 1][kk][1], xh[kk], zold);                    \
-                    else mfma32_vv(acc[b & 1], wxa[b & 1][kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);  \
-                    L32_AFTER_MFMA(m, NM, b)                                                                     \
-                }                                                                                                \
-            }                                                                                                    \
+            constexpr int NM = 24;                                                                               \
+            const f32x16 zold = zq[b];                                                                           \
 _Pragma("unroll")                                                                                                \
             for (int m = 0; m < 24; ++m) {                                                                       \
                 const int kk = m / 3, term = m % 3;                                                              \
                 if (!FIRST && m == 0) mfma32_av_first(acc[b & 1], Aw[b][kk][1], hf[kk][0], zold);                \
-                else mfma32_av(acc[b & 1], Aw[b][kk][term == 0 ? 1 : 0], hf[kk][term == 1 ? 1 : 0]);             \
-                L32_AFTER_MFMA((FIRST ? 6 : 0) + m, NM, b)                                                       \
+                else mfma32_av(L32_ACC(b), Aw[b][kk][term == 0 ? 1 : 0], hf[kk][term == 1 ? 1 : 0]);             \
+                L32_AFTER_MFMA(m, NM, b)                                                                         \
             }                                                                                                    \
             L32_STAMP(1 + b)                                                                                     \
+    }
+
+    // Layer 1: the x-part of the NEXT step (K = 32 = two k-steps per block, 24 MFMAs; Wx1 fragments from LDS) does not depend on
+    // h, so it runs after block 3 and the last block's gate math hides behind it exactly as the other blocks' gates hide behind
+    // the following block.  Block 3's accumulator is read by gaps 1-7 and restarts from its bias in gap 8; its own x-part is the
+    // last six MFMAs.
+#define L32_XTAIL(GATES)                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 24; ++q) {                                                              \
+        const int xb = q / 6, kk = (q % 6) / 3, term = q % 3;                                                     \
+        mfma32_vv(xacc[xb], wxa[xb & 1][kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if ((GATES) && (L32_PROBE_GATES || q == 23) && q >= 1) L32_GAP(q, 3)                                                   \
+        if ((GATES) && q == 8) load_seed(xacc[3], 0, 3);                                                          \
+        if (q == 5) load_wx(wxa[0], 2);                                                                           \
+        if (q == 11) load_wx(wxa[1], 3);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }
+    auto read_xfrag = [&](int s) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const _Float16 *xp = &xt[(((s & 1) * 2 + 0) * L32_TILE + cand) * L32_XT_ROW + kk * 16 + hq * 8];
+            xh[kk] = *(const f16x8 *)xp;
+            xl[kk] = *(const f16x8 *)(xp + L32_TILE * L32_XT_ROW);
+        }
+    };
+    unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
+    float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
+    if (!L32_PROBE_GATES) {   // ablation builds only (tools/ubench): gap 23 still packs and stores
+        hp[0] = hp[1] = lp[0] = lp[1] = 0;
+        tt[0] = tt[1] = tt[2] = tt[3] = 0.f;
+    }
+    if (FIRST) {   // bias + x-part of step 0
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load_seed(xacc[b], 0, b);
+        load_wx(wxa[0], 0);
+        load_wx(wxa[1], 1);
+        read_xfrag(0);
+        {
+            const int s = 0;   // (named by the gap macro; no gap runs here)
+            (void)s;
+            L32_XTAIL(0)
+        }
+        __syncthreads();   // step 0 re-stages the tile just read
     }
 
     for (int s = 0; s < T_POS; ++s) {
@@ -409,17 +447,7 @@ _Pragma("unroll")                                                               
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
-        if (FIRST) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const _Float16 *xp = &xt[(((s & 1) * 2 + 0) * L32_TILE + cand) * L32_XT_ROW + kk * 16 + hq * 8];
-                xh[kk] = *(const f16x8 *)xp;
-                xl[kk] = *(const f16x8 *)(xp + L32_TILE * L32_XT_ROW);
-            }
-        }
         L32_STAMP(7)
-        unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
-        float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
         const int s_prev = s > 0 ? s - 1 : 0;
         // x-part first (layer 1: K = 32 = two k-steps, Wx1 fragments from LDS), then the h-part (K = 128 = eight k-steps);
         // terms per k-step: w_lo.h_hi, w_hi.h_lo, w_hi.h_hi.  The C operand of a block's first MFMA (D != C there) is kept alive
@@ -429,16 +457,22 @@ _Pragma("unroll")                                                               
         L32_BLOCK(1)
         L32_BLOCK(2)
         L32_BLOCK(3)
-        // the last block's gates have no MFMAs left to hide behind (12 wait states after its last MFMA)
-        asm volatile("s_nop 11" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if (FIRST) {
+            L32_XTAIL(1)
+        } else {
+            // layer 2: the last block's gates have no MFMAs left to hide behind (12 wait states after its last MFMA)
+            asm volatile("s_nop 11" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 1; g <= 23; ++g) L32_GAP(g, 3)
+            for (int g = L32_PROBE_GATES ? 1 : 23; g <= 23; ++g) L32_GAP(g, 3)
+        }
         L32_STAMP(5)
         __syncthreads();
         L32_STAMP(6)
     }
 #undef L32_BLOCK
+#undef L32_XTAIL
+#undef L32_ACC
 #undef L32_AFTER_MFMA
 #undef L32_GAP
 #undef L32_OP_E

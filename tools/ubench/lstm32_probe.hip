@@ -27,7 +27,14 @@ template <bool FIRST> void run(int n_pad) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> hs(33 * 16);
     (void)hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-    printf("lstm32<%s> n_pad %d: %.1f us per launch\n", FIRST ? "first" : "second", n_pad, ms * 1000 / 20);
+    printf("lstm32<%s> n_pad %d: %.1f us per launch", FIRST ? "first" : "second", n_pad, ms * 1000 / 20);
+#ifdef L32_PROBE_NOSTAMP
+    printf("   step loop %lld cycles = %.0f per step", hs[1] - hs[0], (double)(hs[1] - hs[0]) / 33);
+#endif
+    printf("\n");
+#ifdef L32_PROBE_NOSTAMP
+    return;
+#endif
     for (int s : {1, 5, 16, 17, 31}) {
         const long long *t = &hs[s * 16];
         printf("  step %2d: head %5lld | block0 %5lld | block1 %5lld | block2 %5lld | block3 %5lld | gate tail %5lld | barrier %5lld | total %5lld (next step starts +%lld)\n", s,
