@@ -310,14 +310,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // below the MFMA that closes it.  (Pinning inputs as well costs an s_nop per op: hipcc pads every asm output
     // that the next VALU touches.)
 #define L32_PIN(x) asm volatile("" : "+v"(x));
-#define L32_OP_E(R, C, e) { R[e] = __builtin_amdgcn_exp2f(Z[4 * (e) + (C)]); L32_PIN(R[e]) }
+#ifdef L32_PROBE_NOTRANS   // tools/ubench ablation: full-rate stand-ins for v_exp_f32 / v_rcp_f32 (results are garbage)
+#define L32_EXP2(x) ((x) * 1.0001f + 0.5f)
+#define L32_RCP(x) ((x) * 0.999f + 0.25f)
+#else
+#define L32_EXP2(x) __builtin_amdgcn_exp2f(x)
+#define L32_RCP(x) fast_rcp(x)
+#endif
+#define L32_OP_E(R, C, e) { R[e] = L32_EXP2(Z[4 * (e) + (C)]); L32_PIN(R[e]) }
 #define L32_OP_A(R, e) { R[e] += 1.0f; L32_PIN(R[e]) }
-#define L32_OP_R(R, e) { R[e] = fast_rcp(R[e]); L32_PIN(R[e]) }
+#define L32_OP_R(R, e) { R[e] = L32_RCP(R[e]); L32_PIN(R[e]) }
 #define L32_OP_K(e) { eg[e] = fmaf(eg[e], -2.0f * GATE_K2, GATE_K2); L32_PIN(eg[e]) }
 #define L32_OP_T(e) { tt[e] = ei[e] * eg[e]; L32_PIN(tt[e]) }
 #define L32_OP_C(e) { C_[e] = fmaf(ef[e], C_[e], tt[e]); L32_PIN(C_[e]) }
 #define L32_OP_M(e) { m2[e] = -2.0f * eo[e]; L32_PIN(m2[e]) }
-#define L32_OP_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); L32_PIN(ei[e]) }
+#define L32_OP_X(e) { ei[e] = L32_EXP2(C_[e]); L32_PIN(ei[e]) }
 #define L32_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); L32_PIN(hh[e]) }
     // fp16 split of h, two elements per instruction: v_cvt_pk_f16_f32 yields the packed pair the LDS store wants, the residual
     // h - float(hi) is one v_fma_mix_f32 that converts the selected half on the fly
