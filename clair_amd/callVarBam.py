@@ -114,27 +114,38 @@ def tensor_batches(args, positions, batch_size):
     total = 0
     held_c, held_info, held = [], [], 0
 
+    def emit(counts, infos):
+        nonlocal total
+        total += len(infos)
+        print("Processed %d tensors" % total, file=sys.stderr)
+        x = counts.astype(np.float32)                     # the decode reads depth and allele support from the tensor
+        x[:, :, :, 1:] -= x[:, :, :, 0:1]
+        # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
+        small = counts.astype(np.int16) if int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
+        return x, infos, small
+
     def drain(final):
-        nonlocal held_c, held_info, held, total
+        nonlocal held_c, held_info, held
         while builder.pending():
-            centres, seqs, counts = builder.take_arrays(4 * batch_size)
+            centres, seqs, counts = builder.take_arrays(batch_size)     # at most one batch per take: every copy below is O(batch)
             keep = np.fromiter((len(s) > 16 and s[16] in IUPAC for s in seqs), dtype=bool, count=len(seqs))
-            held_c.append(counts[keep])
-            held_info.extend([args.ctgName, str(int(c)), s] for c, s, k in zip(centres, seqs, keep) if k)
-            held += int(keep.sum())
-        while held >= batch_size or (final and held > 0):
+            if not keep.all():
+                counts = counts[keep]
+                held_info.extend([args.ctgName, str(int(c)), s] for c, s, k in zip(centres, seqs, keep) if k)
+            else:
+                held_info.extend([args.ctgName, str(c), s] for c, s in zip(centres.tolist(), seqs))
+            held_c.append(counts)
+            held += len(counts)
+            if held >= batch_size:
+                c = np.concatenate(held_c) if len(held_c) > 1 else held_c[0]
+                rest = c[batch_size:]
+                infos, held_info = held_info[:batch_size], held_info[batch_size:]
+                held_c, held = ([rest] if len(rest) else []), len(rest)
+                yield emit(c[:batch_size], infos)
+        if final and held > 0:
             c = np.concatenate(held_c) if len(held_c) > 1 else held_c[0]
-            n = min(batch_size, held)
-            counts, rest = c[:n], c[n:]
-            infos, held_info = held_info[:n], held_info[n:]
-            held_c, held = ([rest] if len(rest) else []), len(rest)
-            total += n
-            print("Processed %d tensors" % total, file=sys.stderr)
-            x = counts.astype(np.float32)                 # the decode reads depth and allele support from the tensor
-            x[:, :, :, 1:] -= x[:, :, :, 0:1]
-            # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
-            small = counts.astype(np.int16) if counts.size and int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
-            yield x, infos, small
+            infos, held_info, held_c, held = held_info, [], [], 0
+            yield emit(c, infos)
 
     tail = None
     while True:
