@@ -281,12 +281,12 @@ def records_from_sam(builder, sam_handle, chunk_bytes=1 << 22):
                 for rec in builder.take():
                     yield rec
     else:
-        tail = ""
+        tail = None
         while True:
             chunk = sam_handle.read(chunk_bytes)
             if not chunk:
                 break
-            tail = builder.feed(tail + chunk)
+            tail = builder.feed(chunk if tail is None else tail + chunk)
             for rec in builder.take():
                 yield rec
         if tail:
@@ -333,12 +333,25 @@ def output_aln_tensor(args, native=True):
     gz = None
     if args.tensor_fn != "PIPE":
         raw = open(args.tensor_fn, "wb")
-        gz = subprocess_popen(shlex.split("gzip -c"), stdin=subprocess.PIPE, stdout=raw)
+        gz = subprocess_popen(shlex.split("gzip -c"), stdin=subprocess.PIPE, stdout=raw, text=not getattr(args, "binary", False))
         sink = gz.stdin
     else:
         sink = sys.stdout
     try:
-        if isinstance(builder, PileupBuilderPy):
+        if getattr(args, "binary", False):
+            from . import tensor_binary
+            out = sink.buffer if hasattr(sink, "buffer") else sink
+            out.write(tensor_binary.MAGIC)
+            group = []
+            for rec in records_from_sam(builder, sam_handle):
+                group.append(rec)
+                if len(group) >= 512:
+                    out.write(tensor_binary.pack_records(args.ctgName, [r[0] for r in group], [r[1] for r in group], np.stack([r[2] for r in group])))
+                    group = []
+            if group:
+                out.write(tensor_binary.pack_records(args.ctgName, [r[0] for r in group], [r[1] for r in group], np.stack([r[2] for r in group])))
+            out.flush()
+        elif isinstance(builder, PileupBuilderPy):
             for centre, refseq, counts in records_from_sam(builder, sam_handle):
                 sink.write(format_record(args.ctgName, centre, refseq, counts))
                 sink.write("\n")
@@ -378,6 +391,8 @@ def build_parser():
     parser.add_argument('--sam_fn', type=str, default=None,
                         help="Read alignments as SAM text from this file instead of spawning `samtools view` (addition)")
     parser.add_argument('--python_pileup', action='store_true', help="Use the pure-Python pileup instead of libclair_host.so (addition; slow)")
+    parser.add_argument('--binary', action='store_true',
+                        help="Write fixed-size binary records (clair_amd/tensor_binary.py) instead of text; call_var recognises them (addition)")
     return parser
 
 

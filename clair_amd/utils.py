@@ -48,11 +48,21 @@ def tensor_generator_from(tensor_file_path, batch_size):
 
     The text is parsed by the native helper (include/clair_host.h: clair_host_parse_tensors, ~20x the NumPy path below);
     `tensor_generator_from_py` is the line-by-line restatement of the reference it is tested against."""
-    from clair_amd import _hostapi
+    from clair_amd import _hostapi, tensor_binary
     import queue
     import threading
     proc, stream = _open_source(tensor_file_path, binary=True)
+    head = stream.read(len(tensor_binary.MAGIC))
+    if head == tensor_binary.MAGIC:              # fixed-size binary records (clair_amd/tensor_binary.py) instead of text
+        for batch in tensor_binary.read_batches(stream, batch_size):
+            yield batch
+        if proc is not None:
+            stream.close()
+            proc.wait()
+        return
     chunks = queue.Queue(maxsize=4)
+    if head:
+        chunks.put(head)
 
     def reader():                                # decompressed text arrives while the previous chunk is being parsed
         while True:

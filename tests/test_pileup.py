@@ -336,6 +336,13 @@ def test_callVarBam_vcf_equals_three_stage_text_pipeline(tmp_path):
                     "--batch_size", "96"] + common, cwd=ROOT, check=True, capture_output=True)
     a, b = open(v1).read(), open(v2).read()
     assert a == b and a.count("\n") > 40
+    # binary tensor records through the file interface: same VCF again
+    tensors_bin, v3 = str(tmp_path / "t.bin.gz"), str(tmp_path / "bin.vcf")
+    subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--tensor_fn", tensors_bin, "--binary"] + common, input=r1.stdout,
+                   text=True, cwd=ROOT, check=True, capture_output=True)
+    subprocess.run([sys.executable, "-m", "clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors_bin, "--call_fn", v3,
+                    "--ref_fn", fa, "--sampleName", "S1", "--batch_size", "200"], cwd=ROOT, check=True, capture_output=True)
+    assert open(v3).read() == a
 
 
 def test_callVarBamParallel_commands_match_reference():
@@ -357,3 +364,35 @@ def test_callVarBamParallel_commands_match_reference():
             assert got == want, name
             dealt = par.commands(par.build_parser().parse_args(argv + ["--devices", "8"]))
             assert [l.rsplit(" ", 2)[1:] for l in dealt] == [["--device", '"%d"' % (i % 8)] for i in range(len(dealt))]
+
+
+def test_binary_tensor_records_equal_the_text_records(tmp_path):
+    """create_tensor --binary -> utils.tensor_generator_from: the same batches as the text records of the same windows, plus the
+    raw int16 counts for the GPU boundary (clair_amd/tensor_binary.py)."""
+    from clair_amd import tensor_binary, utils
+    case, fa, sam = _bam_case(str(tmp_path), seed=303)
+    common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS]
+    text, binary = str(tmp_path / "t.txt.gz"), str(tmp_path / "t.bin.gz")
+    for extra in (["--tensor_fn", text], ["--tensor_fn", binary, "--binary"]):
+        r = subprocess.run([sys.executable, "-m", "clair_amd.create_tensor"] + common + extra, input=case["candidates"], capture_output=True,
+                           text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+    assert gzip.open(binary, "rb").read(8) == tensor_binary.MAGIC
+    want = list(utils.tensor_generator_from(text, 50))
+    got = list(utils.tensor_generator_from(binary, 50))
+    assert len(want) > 2 and len(got) == len(want)
+    for (xw, iw), (xg, ig, cg) in zip(want, got):
+        assert np.array_equal(xw, xg) and [list(map(str, i)) for i in iw] == ig
+        assert cg.dtype == np.int16 and np.array_equal(cg[..., 0], xg[..., 0])
+    # stdout sink and the Python twin write the same bytes
+    r1 = subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--binary"] + common, input=case["candidates"].encode(),
+                        capture_output=True, cwd=ROOT)
+    r2 = subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--binary", "--python_pileup"] + common,
+                        input=case["candidates"].encode(), capture_output=True, cwd=ROOT)
+    assert r1.returncode == 0 and r1.stdout == gzip.open(binary, "rb").read() and r2.stdout == r1.stdout
+    with pytest.raises(ValueError):
+        tensor_binary.pack_records("c" * 40, [1], ["A" * 33], np.zeros((1, 33, 8, 4), np.int32))
+    with pytest.raises(ValueError):
+        tensor_binary.pack_records("c", [1], ["A" * 33], np.full((1, 33, 8, 4), 40000, np.int32))
+    with pytest.raises(ValueError):
+        list(tensor_binary.read_batches(io.BytesIO(b"x" * 100), 4))
