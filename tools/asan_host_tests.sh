@@ -1,0 +1,11 @@
+#!/bin/sh
+# Host library under AddressSanitizer + UBSan: rebuilds libclair_host.so instrumented, runs the host-side tests, restores the
+# optimised build.  (Round 1: 74 passed, no report.)
+set -e
+cd "$(dirname "$0")/.."
+cp clair_amd/libclair_host.so /tmp/libclair_host_good.so
+g++ -O1 -g -std=c++17 -ffp-contract=off -pthread -shared -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer \
+    clair_amd/hostsrc/*.cpp -o clair_amd/libclair_host.so
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
+    python -m pytest tests/test_pileup.py tests/test_host.py -q -m "not gpu" -p no:cacheprovider || true
+cp /tmp/libclair_host_good.so clair_amd/libclair_host.so
