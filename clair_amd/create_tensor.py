@@ -25,7 +25,6 @@ CreateTensor.py:181, 303-309) is accounted for tuple by tuple, so the same bases
 documented liberty: when the budget runs out in the MIDDLE of one reference position, the reference serves the windows in
 CPython set-iteration order; here they are served in ascending centre order.
 """
-import gzip
 import shlex
 import subprocess
 import sys

@@ -17,7 +17,6 @@ import sys
 from argparse import ArgumentParser
 from os.path import isfile
 
-import numpy as np
 
 from .create_tensor import EXPAND_REFERENCE_REGION, SAMTOOLS_VIEW_FILTER_FLAG, PileupError, subprocess_popen
 
