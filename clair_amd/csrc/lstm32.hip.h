@@ -57,6 +57,11 @@ namespace clair {
 #ifndef L32_PROBE_COPY
 #define L32_PROBE_COPY 1
 #endif
+#ifdef L32_PROBE_TWOTILE
+#define L32_TWOTILE_PROBE 1
+#else
+#define L32_TWOTILE_PROBE 0
+#endif
 #ifdef L32_PROBE   // tools/ubench/lstm32_probe.hip only: s_memtime stamps of workgroup 0, wave 0
 __device__ long long *l32_stamps;   // [33 steps][16]
 #ifdef L32_PROBE_NOSTAMP   // launch time and the first / last stamp only (for the -DL32_PROBE_* ablations)
@@ -384,6 +389,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((M) == 23) stage_x(s + 2);                                                                            \
     }                                                                                                             \
     if (FIRST && (B) == 1 && (M) == 0) xreg = load_x(s + 3);                                                      \
+    if (L32_TWOTILE_PROBE && (B) == 3 && (M) % 3 == 2) {   /* probe: next fragments into the slot just used for the last time */ \
+        hf[(M) / 3][0] = *(const f16x8 *)&hbuf[s & 1][0][cand][((M) / 3) * 16 + hq * 8];                           \
+        hf[(M) / 3][1] = *(const f16x8 *)&hbuf[s & 1][1][cand][((M) / 3) * 16 + hq * 8];                           \
+    }                                                                                                             \
     if (FIRST && (B) == 3) {   /* operands of the x-part that follows block 3: x_{s+1} fragments, Wx1 fragments of blocks 0 and 1 */ \
         if ((M) == 12) read_xfrag(s + 1);                                                                         \
         if ((M) == 14) load_wx(wxa[0], 0);                                                                        \
@@ -448,12 +457,22 @@ _Pragma("unroll")                                                               
         __syncthreads();   // step 0 re-stages the tile just read
     }
 
+#ifdef L32_PROBE_TWOTILE   // tools/ubench only: what a step would cost in a two-tile workgroup (timing only, results are wrong):
+                            // h fragments replaced in place inside block 3, the step barrier in mid-stream after block 0, the last
+                            // block's gates left out (they would hide under the other tile's block 0)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[1][pl][cand][kk * 16 + hq * 8];
+#endif
     for (int s = 0; s < T_POS; ++s) {
         L32_STAMP(0)
+#ifndef L32_PROBE_TWOTILE
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
+#endif
         L32_STAMP(7)
         const int s_prev = s > 0 ? s - 1 : 0;
         // x-part first (layer 1: K = 32 = two k-steps, Wx1 fragments from LDS), then the h-part (K = 128 = eight k-steps);
@@ -461,9 +480,18 @@ _Pragma("unroll")                                                               
         // two MFMAs longer by L32_AFTER_MFMA: hipcc knows nothing about the asm MFMA still reading it and would hand the
         // registers to the next VALU result.
         L32_BLOCK(0)
+#ifdef L32_PROBE_TWOTILE
+        __syncthreads();
+#endif
         L32_BLOCK(1)
         L32_BLOCK(2)
         L32_BLOCK(3)
+#ifdef L32_PROBE_TWOTILE
+        {
+#pragma unroll
+            for (int g = 23; g <= 23; ++g) L32_GAP(g, 3)
+        }
+#else
         if (FIRST) {
             L32_XTAIL(1)
         } else {
@@ -473,8 +501,11 @@ _Pragma("unroll")                                                               
 #pragma unroll
             for (int g = L32_PROBE_GATES ? 1 : 23; g <= 23; ++g) L32_GAP(g, 3)
         }
+#endif
         L32_STAMP(5)
+#ifndef L32_PROBE_TWOTILE
         __syncthreads();
+#endif
         L32_STAMP(6)
     }
 #undef L32_BLOCK
