@@ -211,50 +211,44 @@ def Run(args):
 
 
 def build_parser():
-    """Flags and defaults of clair/callVarBam.py:237-322, plus --batch_size / --device / --arith."""
-    parser = ArgumentParser(description="Call variants using a trained model and a BAM file")
-    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a model")
-    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
-    parser.add_argument('--bed_fn', type=str, default=None,
-                        help="Call variant only in these regions, works in intersection with ctgName, ctgStart and ctgEnd, optional, default: as defined by ctgName, ctgStart and ctgEnd")
-    parser.add_argument('--bam_fn', type=str, default="bam.bam", help="BAM file input, default: %(default)s")
-    parser.add_argument('--call_fn', type=str, default=None, help="Output variant predictions")
-    parser.add_argument('--vcf_fn', type=str, default=None,
-                        help="Candidate sites VCF file input, if provided, variants will only be called at the sites in the VCF file,  default: %(default)s")
-    parser.add_argument('--threshold', type=float, default=0.125,
-                        help="Minimum allele frequence of the 1st non-reference allele for a site to be considered as a condidate site, default: %(default)f")
-    parser.add_argument('--minCoverage', type=float, default=4, help="Minimum coverage required to call a variant, default: %(default)d")
-    parser.add_argument('--qual', type=int, default=None,
-                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
-    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
-    parser.add_argument('--ctgName', type=str, default=None, help="The name of sequence to be processed, default: %(default)s")
-    parser.add_argument('--ctgStart', type=int, default=None, help="The 1-based starting position of the sequence to be processed")
-    parser.add_argument('--ctgEnd', type=int, default=None, help="The 1-based inclusive ending position of the sequence to be processed")
-    parser.add_argument('--stop_consider_left_edge', action='store_true',
-                        help="If not set, would consider left edge only. That is, count the left-most base-pairs of a read for coverage even if the starting position of a read is after the starting position of a tensor")
-    parser.add_argument('--dcov', type=int, default=250, help="Cap depth per position at %(default)s")
-    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
-    parser.add_argument('--pypy', type=str, default="pypy3", help="Ignored: no stage of this pipeline runs under pypy")
-    parser.add_argument('--threads', type=int, default=None, help="Number of threads, optional")
-    parser.add_argument('--delay', type=int, default=10, help="Ignored: there is no TensorFlow start-up thread storm to stagger")
-    parser.add_argument('--debug', action='store_true', help="Debug mode, optional")
-    parser.add_argument('--pysam_for_all_indel_bases', action='store_true', help="Always using pysam for outputting indel bases, optional")
-    parser.add_argument('--haploid_precision', action='store_true', help="call haploid instead of diploid (output homo-variant only)")
-    parser.add_argument('--haploid_sensitive', action='store_true', help="call haploid instead of diploid (output non-multi-variant only)")
-    parser.add_argument('--activation_only', action='store_true', help="Output activation only, no prediction")
-    parser.add_argument('--max_plot', type=int, default=10,
-                        help="The maximum number of plots output, negative number means no limit (plot all), default: %(default)s")
-    parser.add_argument('--log_path', type=str, nargs='?', default=None, help="The path for tensorflow logging, default: %(default)s")
-    parser.add_argument('-p', '--parallel_level', type=int, default=2,
-                        help="The level of parallelism in plotting (currently available: 0, 2), default: %(default)s")
-    parser.add_argument('--fast_plotting', action='store_true', help="Enable fast plotting.")
-    parser.add_argument('-w', '--workers', type=int, default=8, help="The number of workers in plotting, default: %(default)s")
-    parser.add_argument('--output_for_ensemble', action='store_true', help="Output for ensemble")
+    """Flag names and defaults of clair/callVarBam.py:237-322 (help texts are this build's), plus --batch_size / --device / --arith."""
+    parser = ArgumentParser(description="BAM to VCF for one contig or region, in one process on one GPU")
+    add = parser.add_argument
+    add('--chkpnt_fn', type=str, default=None, help="model checkpoint prefix (.npz container or TensorFlow bundle)")
+    add('--ref_fn', type=str, default="ref.fa", help="reference FASTA with its .fai")
+    add('--bed_fn', type=str, default=None, help="restrict candidates to these intervals (intersected with the region)")
+    add('--bam_fn', type=str, default="bam.bam", help="sorted alignments")
+    add('--call_fn', type=str, default=None, help="output VCF")
+    add('--vcf_fn', type=str, default=None, help="call only at the sites of this VCF instead of extracting candidates")
+    add('--threshold', type=float, default=0.125, help="minimum allele frequency of a candidate site, default: %(default)s")
+    add('--minCoverage', type=float, default=4, help="minimum depth of a candidate site, default: %(default)s")
+    add('--qual', type=int, default=None, help="PASS / LowQual cut-off, optional")
+    add('--sampleName', type=str, default="SAMPLE", help="sample column of the VCF")
+    add('--ctgName', type=str, default=None, help="contig to process (required)")
+    add('--ctgStart', type=int, default=None, help="1-based first position of the region")
+    add('--ctgEnd', type=int, default=None, help="1-based last position of the region (inclusive)")
+    add('--stop_consider_left_edge', action='store_true', help="open a window only for reads that cover its left edge")
+    add('--dcov', type=int, default=250, help="at most this many reads per start position, default: %(default)s")
+    add('--samtools', type=str, default="samtools", help="samtools executable")
+    add('--pypy', type=str, default="pypy3", help="ignored: no stage of this pipeline runs under pypy")
+    add('--threads', type=int, default=None, help="host threads, optional")
+    add('--delay', type=int, default=10, help="ignored: there is no TensorFlow start-up thread storm to stagger")
+    add('--debug', action='store_true', help="debug lines in the VCF body")
+    add('--pysam_for_all_indel_bases', action='store_true', help="look every indel up in the BAM (needs pysam)")
+    add('--haploid_precision', action='store_true', help="haploid calling: homozygous variants only")
+    add('--haploid_sensitive', action='store_true', help="haploid calling: everything but multi-allelic variants")
+    add('--activation_only', action='store_true', help="kept for flag compatibility (plotting is a dead path)")
+    add('--max_plot', type=int, default=10, help="kept for flag compatibility")
+    add('--log_path', type=str, nargs='?', default=None, help="kept for flag compatibility")
+    add('-p', '--parallel_level', type=int, default=2, help="kept for flag compatibility")
+    add('--fast_plotting', action='store_true', help="kept for flag compatibility")
+    add('-w', '--workers', type=int, default=8, help="kept for flag compatibility")
+    add('--output_for_ensemble', action='store_true', help="write probabilities for ensembling instead of a VCF")
     # additions of this implementation
-    parser.add_argument('--batch_size', type=int, default=None, help="Candidates per forward pass, default: %d" % param.predictBatchSize)
-    parser.add_argument('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
-    parser.add_argument('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
-                        help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")
+    add('--batch_size', type=int, default=None, help="candidates per forward pass, default: %d" % param.predictBatchSize)
+    add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
+    add('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
+        help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")
     return parser
 
 

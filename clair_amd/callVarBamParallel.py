@@ -84,43 +84,40 @@ def commands(args):
 
 
 def build_parser():
-    """Flags and defaults of clair/callVarBamParallel.py:119-204, plus --devices / --python."""
-    parser = ArgumentParser(description="Create commands for calling variants in parallel using a trained model and a BAM file")
-    parser.add_argument('--chkpnt_fn', type=str, default=None, help="Input a checkpoint for testing or continue training")
-    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
-    parser.add_argument('--bed_fn', type=str, default=None,
-                        help="Call variant only in these regions, works in intersection with ctgName, ctgStart and ctgEnd, optional, default: as defined by ctgName, ctgStart and ctgEnd")
-    parser.add_argument('--refChunkSize', type=int, default=10000000, help="Divide job with smaller genome chunk size for parallelism, default: %(default)s")
-    parser.add_argument('--bam_fn', type=str, default="bam.bam", help="BAM file input, default: %(default)s")
-    parser.add_argument('--vcf_fn', type=str, default=None,
-                        help="Candidate sites VCF file input, if provided, variants will only be called at the sites in the VCF file,  default: %(default)s")
-    parser.add_argument('--output_prefix', type=str, default=None, help="Output prefix")
-    parser.add_argument('--includingAllContigs', action='store_true', help="Call variants on all contigs, default: chr{1..22,X,Y,M,MT} and {1..22,X,Y,MT}")
-    parser.add_argument('--tensorflowThreads', type=int, default=4, help="Passed on as --threads (host-side threads per process), default: %(default)s")
-    parser.add_argument('--threshold', type=float, default=0.2,
-                        help="Minimum allele frequence of the 1st non-reference allele for a site to be considered as a condidate site, default: %(default)f")
-    parser.add_argument('--minCoverage', type=float, default=4, help="Minimum coverage required to call a variant, default: %(default)f")
-    parser.add_argument('--qual', type=int, default=None,
-                        help="If set, variant with equal or higher quality will be marked PASS, or LowQual otherwise, optional")
-    parser.add_argument('--sampleName', type=str, default="SAMPLE", help="Define the sample name to be shown in the VCF file")
-    parser.add_argument('--stop_consider_left_edge', action='store_true', help="If not set, would consider left edge only.")
-    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
-    parser.add_argument('--pypy', type=str, default="pypy3", help="Passed on; ignored by callVarBam")
-    parser.add_argument('--delay', type=int, default=10, help="Passed on; ignored by callVarBam")
-    parser.add_argument('--debug', action='store_true', help="Debug mode, optional")
-    parser.add_argument('--pysam_for_all_indel_bases', action='store_true', help="Always using pysam for outputting indel bases, optional")
-    parser.add_argument('--haploid_precision', action='store_true', help="call haploid instead of diploid (output homo-variant only)")
-    parser.add_argument('--haploid_sensitive', action='store_true', help="call haploid instead of diploid (output non-multi-variant only)")
-    parser.add_argument('--activation_only', action='store_true', help="Output activation only, no prediction")
-    parser.add_argument('--max_plot', type=int, default=10, help="(plotting is a dead path, kept for flag compatibility)")
-    parser.add_argument('--log_path', type=str, nargs='?', default=None, help="(plotting is a dead path, kept for flag compatibility)")
-    parser.add_argument('-p', '--parallel_level', type=int, default=2, help="(plotting is a dead path, kept for flag compatibility)")
-    parser.add_argument('-w', '--workers', type=int, default=8, help="(plotting is a dead path, kept for flag compatibility)")
-    parser.add_argument('--fast_plotting', action='store_true', help="(plotting is a dead path, kept for flag compatibility)")
-    parser.add_argument('--output_for_ensemble', action='store_true', help="Output for ensemble")
+    """Flag names and defaults of clair/callVarBamParallel.py:119-204 (help texts are this build's), plus --devices / --python."""
+    parser = ArgumentParser(description="Print one callVarBam command per reference chunk")
+    add = parser.add_argument
+    add('--chkpnt_fn', type=str, default=None, help="model checkpoint prefix")
+    add('--ref_fn', type=str, default="ref.fa", help="reference FASTA (its .fai lists the contigs)")
+    add('--bed_fn', type=str, default=None, help="restrict calling to these intervals; chunks without any are skipped")
+    add('--refChunkSize', type=int, default=10000000, help="chunk length in bp")
+    add('--bam_fn', type=str, default="bam.bam", help="sorted alignments")
+    add('--vcf_fn', type=str, default=None, help="call only at the sites of this VCF")
+    add('--output_prefix', type=str, default=None, help="per-chunk VCFs are <prefix>.<contig>_<start>_<end>.vcf")
+    add('--includingAllContigs', action='store_true', help="every contig of the .fai, not only 1-22, X, Y (with or without chr)")
+    add('--tensorflowThreads', type=int, default=4, help="passed on as --threads (host threads per process)")
+    add('--threshold', type=float, default=0.2, help="minimum allele frequency of a candidate site")
+    add('--minCoverage', type=float, default=4, help="minimum depth of a candidate site")
+    add('--qual', type=int, default=None, help="PASS / LowQual cut-off, optional")
+    add('--sampleName', type=str, default="SAMPLE", help="sample column of the VCF")
+    add('--stop_consider_left_edge', action='store_true', help="passed on to the pileup stage")
+    add('--samtools', type=str, default="samtools", help="samtools executable")
+    add('--pypy', type=str, default="pypy3", help="passed on; callVarBam ignores it")
+    add('--delay', type=int, default=10, help="passed on; callVarBam ignores it")
+    add('--debug', action='store_true', help="passed on")
+    add('--pysam_for_all_indel_bases', action='store_true', help="passed on")
+    add('--haploid_precision', action='store_true', help="passed on")
+    add('--haploid_sensitive', action='store_true', help="passed on")
+    add('--activation_only', action='store_true', help="kept for flag compatibility (plotting is a dead path)")
+    add('--max_plot', type=int, default=10, help="kept for flag compatibility")
+    add('--log_path', type=str, nargs='?', default=None, help="kept for flag compatibility")
+    add('-p', '--parallel_level', type=int, default=2, help="kept for flag compatibility")
+    add('-w', '--workers', type=int, default=8, help="kept for flag compatibility")
+    add('--fast_plotting', action='store_true', help="kept for flag compatibility")
+    add('--output_for_ensemble', action='store_true', help="passed on")
     # additions of this implementation
-    parser.add_argument('--devices', type=int, default=1, help="Deal the chunks round-robin over this many GPUs (--device k), default: %(default)s")
-    parser.add_argument('--python', type=str, default=None, help="Interpreter to put in the commands, default: the running one")
+    add('--devices', type=int, default=1, help="deal the chunks round-robin over this many GPUs (--device k)")
+    add('--python', type=str, default=None, help="interpreter to put in the commands, default: the running one")
     return parser
 
 

@@ -370,28 +370,25 @@ def output_aln_tensor(args, native=True):
 
 
 def build_parser():
-    parser = ArgumentParser(description="Generate tensors summarizing local alignments from a BAM file and a list of candidate locations")
-    parser.add_argument('--bam_fn', type=str, default="input.bam", help="Sorted bam file input, default: %(default)s")
-    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
-    parser.add_argument('--can_fn', type=str, default="PIPE",
-                        help="Variant candidate list generated by ExtractVariantCandidates.py or true variant list generated by GetTruth.py, use PIPE for standard input, default: %(default)s")
-    parser.add_argument('--tensor_fn', type=str, default="PIPE", help="Tensor output, use PIPE for standard output, default: %(default)s")
-    parser.add_argument('--minMQ', type=int, default=0,
-                        help="Minimum Mapping Quality. Mapping quality lower than the setting will be filtered, default: %(default)d")
-    parser.add_argument('--ctgName', type=str, default="chr17", help="The name of sequence to be processed, default: %(default)s")
-    parser.add_argument('--ctgStart', type=int, default=None, help="The 1-based starting position of the sequence to be processed")
-    parser.add_argument('--ctgEnd', type=int, default=None, help="The 1-based inclusive ending position of the sequence to be processed")
-    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
-    parser.add_argument('--stop_consider_left_edge', action='store_true',
-                        help="If not set, would consider left edge only. That is, count the left-most base-pairs of a read for coverage even if the starting position of a read is after the starting position of a tensor")
-    parser.add_argument('--dcov', type=int, default=250, help="Cap depth per position at %(default)d")
-    parser.add_argument('--minCoverage', type=int, default=0, help="Minimum coverage required to generate a tensor, default: %(default)d")
+    """Flag names and defaults of dataPrepScripts/CreateTensor.py:397-437 (help texts are this build's), plus three additions."""
+    parser = ArgumentParser(description="Pileup count tensors for a list of candidate positions")
+    add = parser.add_argument
+    add('--bam_fn', type=str, default="input.bam", help="sorted alignments")
+    add('--ref_fn', type=str, default="ref.fa", help="reference FASTA")
+    add('--can_fn', type=str, default="PIPE", help="candidate rows (column 2 = 1-based position), gzip or plain; PIPE = standard input")
+    add('--tensor_fn', type=str, default="PIPE", help="output records, gzip file; PIPE = standard output")
+    add('--minMQ', type=int, default=0, help="drop alignments below this mapping quality, default: %(default)d")
+    add('--ctgName', type=str, default="chr17", help="contig to process, default: %(default)s")
+    add('--ctgStart', type=int, default=None, help="1-based first position of the region")
+    add('--ctgEnd', type=int, default=None, help="1-based last position of the region (inclusive)")
+    add('--samtools', type=str, default="samtools", help="samtools executable")
+    add('--stop_consider_left_edge', action='store_true', help="open a window only for reads that cover its left edge")
+    add('--dcov', type=int, default=250, help="at most this many reads per start position, default: %(default)d")
+    add('--minCoverage', type=int, default=0, help="drop windows whose centre depth is below this, default: %(default)d")
     # additions (not in the reference)
-    parser.add_argument('--sam_fn', type=str, default=None,
-                        help="Read alignments as SAM text from this file instead of spawning `samtools view` (addition)")
-    parser.add_argument('--python_pileup', action='store_true', help="Use the pure-Python pileup instead of libclair_host.so (addition; slow)")
-    parser.add_argument('--binary', action='store_true',
-                        help="Write fixed-size binary records (clair_amd/tensor_binary.py) instead of text; call_var recognises them (addition)")
+    add('--sam_fn', type=str, default=None, help="read alignments as SAM text from this file instead of spawning `samtools view`")
+    add('--python_pileup', action='store_true', help="use the pure-Python pileup instead of libclair_host.so (slow)")
+    add('--binary', action='store_true', help="write fixed-size binary records (clair_amd/tensor_binary.py) instead of text")
     return parser
 
 

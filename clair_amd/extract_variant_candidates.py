@@ -259,30 +259,26 @@ def make_candidates(args, native=True):
 
 
 def build_parser():
-    parser = ArgumentParser(description="Generate 1-based variant candidates using alignments")
-    parser.add_argument('--bam_fn', type=str, default="input.bam", help="Sorted bam file input, default: %(default)s")
-    parser.add_argument('--ref_fn', type=str, default="ref.fa", help="Reference fasta file input, default: %(default)s")
-    parser.add_argument('--bed_fn', type=str, default=None,
-                        help="Call variant only in these regions, works in intersection with ctgName, ctgStart and ctgEnd, optional, default: as defined by ctgName, ctgStart and ctgEnd")
-    parser.add_argument('--can_fn', type=str, default="PIPE", help="Pile-up count output, use PIPE for standard output, default: %(default)s")
-    parser.add_argument('--var_fn', type=str, default=None,
-                        help="Candidate sites VCF file input, if provided, will choose candidate +/- 1 or +/- 2. Use together with gen4Training. default: %(default)s")
-    parser.add_argument('--threshold', type=float, default=0.125,
-                        help="Minimum allele frequence of the 1st non-reference allele for a site to be considered as a condidate site, default: %(default)f")
-    parser.add_argument('--minCoverage', type=float, default=4, help="Minimum coverage required to call a variant, default: %(default)f")
-    parser.add_argument('--minMQ', type=int, default=0,
-                        help="Minimum Mapping Quality. Mapping quality lower than the setting will be filtered, default: %(default)d")
-    parser.add_argument('--gen4Training', action='store_true',
-                        help="Output all genome positions as candidate for model training (Set --threshold to 0), default: %(default)s")
-    parser.add_argument('--outputProb', type=float, default=(7000000.0 * RATIO_OF_NON_VARIANT_TO_VARIANT / 3000000000), help="output probability")
-    parser.add_argument('--ctgName', type=str, default="chr17", help="The name of sequence to be processed, default: %(default)s")
-    parser.add_argument('--ctgStart', type=int, default=None, help="The 1-based starting position of the sequence to be processed")
-    parser.add_argument('--ctgEnd', type=int, default=None, help="The 1-based inclusive ending position of the sequence to be processed")
-    parser.add_argument('--samtools', type=str, default="samtools", help="Path to the 'samtools', default: %(default)s")
+    """Flag names and defaults of dataPrepScripts/ExtractVariantCandidates.py:408-457 (help texts are this build's), plus two additions."""
+    parser = ArgumentParser(description="Candidate sites (1-based) from sorted alignments")
+    add = parser.add_argument
+    add('--bam_fn', type=str, default="input.bam", help="sorted alignments")
+    add('--ref_fn', type=str, default="ref.fa", help="reference FASTA with its .fai")
+    add('--bed_fn', type=str, default=None, help="restrict candidates to these intervals (intersected with the region)")
+    add('--can_fn', type=str, default="PIPE", help="output rows, gzip file; PIPE = standard output")
+    add('--var_fn', type=str, default=None, help="training-set switch, not supported")
+    add('--threshold', type=float, default=0.125, help="minimum frequency of the runner-up observation, default: %(default)f")
+    add('--minCoverage', type=float, default=4, help="minimum depth, default: %(default)f")
+    add('--minMQ', type=int, default=0, help="drop alignments below this mapping quality, default: %(default)d")
+    add('--gen4Training', action='store_true', help="training-set switch, not supported")
+    add('--outputProb', type=float, default=(7000000.0 * RATIO_OF_NON_VARIANT_TO_VARIANT / 3000000000), help="training-set switch, ignored")
+    add('--ctgName', type=str, default="chr17", help="contig to process, default: %(default)s")
+    add('--ctgStart', type=int, default=None, help="1-based first position of the region")
+    add('--ctgEnd', type=int, default=None, help="1-based last position of the region (inclusive)")
+    add('--samtools', type=str, default="samtools", help="samtools executable")
     # additions (not in the reference)
-    parser.add_argument('--sam_fn', type=str, default=None,
-                        help="Read alignments as SAM text from this file instead of spawning `samtools view` (addition)")
-    parser.add_argument('--python_pileup', action='store_true', help="Use the pure-Python tally instead of libclair_host.so (addition; slow)")
+    add('--sam_fn', type=str, default=None, help="read alignments as SAM text from this file instead of spawning `samtools view`")
+    add('--python_pileup', action='store_true', help="use the pure-Python tally instead of libclair_host.so (slow)")
     return parser
 
 
