@@ -396,3 +396,19 @@ def test_binary_tensor_records_equal_the_text_records(tmp_path):
         tensor_binary.pack_records("c", [1], ["A" * 33], np.full((1, 33, 8, 4), 40000, np.int32))
     with pytest.raises(ValueError):
         list(tensor_binary.read_batches(io.BytesIO(b"x" * 100), 4))
+
+
+def test_cli_mirrors_keep_every_reference_flag_and_default():
+    """Option strings, defaults, types, nargs and action kinds of the four reference command lines
+    (tests/golden/cli_flags.json, tools/make_cli_flag_golden.py); this build may add flags, never drop or change one."""
+    from clair_amd import callVarBam, callVarBamParallel
+    ref = json.load(open(os.path.join(HERE, "golden", "cli_flags.json")))
+    mine = {"CreateTensor": ct.build_parser(), "ExtractVariantCandidates": evc.build_parser(), "callVarBam": callVarBam.build_parser(),
+            "callVarBamParallel": callVarBamParallel.build_parser()}
+    for tool, flags in ref.items():
+        have = {tuple(a.option_strings): a for a in mine[tool]._actions if a.option_strings}
+        for f in flags:
+            a = have.get(tuple(f["flags"]))
+            assert a is not None, (tool, f["flags"])
+            assert a.default == f["default"] and getattr(a.type, "__name__", None) == f["type"] and a.nargs == f["nargs"] \
+                and type(a).__name__ == f["action"], (tool, f["flags"])
