@@ -412,3 +412,15 @@ def test_cli_mirrors_keep_every_reference_flag_and_default():
             assert a is not None, (tool, f["flags"])
             assert a.default == f["default"] and getattr(a.type, "__name__", None) == f["type"] and a.nargs == f["nargs"] \
                 and type(a).__name__ == f["action"], (tool, f["flags"])
+
+
+def test_submodule_dispatcher():
+    """python -m clair_amd <submodule> ... = the reference's `python clair.py <submodule> ...` (clair.py:60-86)."""
+    r = subprocess.run([sys.executable, "-m", "clair_amd"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "callVarBam" in r.stdout and "CreateTensor" in r.stdout
+    r = subprocess.run([sys.executable, "-m", "clair_amd", "CreateTensor"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 1 and "--can_fn" in r.stdout            # the submodule's own help, exit 1 without options
+    r = subprocess.run([sys.executable, "-m", "clair_amd", "train"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "outside this build" in r.stderr
+    r = subprocess.run([sys.executable, "-m", "clair_amd", "nope"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "not found" in r.stderr
