@@ -74,8 +74,11 @@ def candidate_positions(args):
 
 
 def positions_from_vcf(vcf_fn, ctg_name, ctg_start, ctg_end):
-    """--vcf_fn: call only at the sites of a VCF (the positions dataPrepScripts/GetTruth.py:75-134 would print: every record of
-    the contig inside the range; a '*' alternate adds the base before, :38-45)."""
+    """--vcf_fn: call only at the sites of a VCF.  The reference pipes dataPrepScripts/GetTruth.py into CreateTensor, which
+    reads column 2 of its rows; this is that column, in GetTruth's order (GetTruth.py:75-134): every record of the contig inside
+    the range, one row per run of equal positions (:127-133); a '*' alternate adds the base before the record -- first when
+    '*' is one of the first two alternates, after it otherwise (:30-48), so the stream need not be sorted (the pileup handles that
+    as the reference does)."""
     have_range = ctg_start is not None and ctg_end is not None
     p = ct.subprocess_popen(shlex.split("gzip -fdc %s" % vcf_fn))
     out = []
@@ -86,13 +89,19 @@ def positions_from_vcf(vcf_fn, ctg_name, ctg_start, ctg_end):
         pos = int(col[1])
         if have_range and not ctg_start <= pos <= ctg_end:
             continue
+        alts = col[4].split(",") if "*" in col[4] else [col[4]]
         if "*" in col[4]:
-            out.append(pos - 1)
-        if col[4] != "*":
-            out.append(pos)
+            if len(alts) < 2:
+                sys.exit("[ERROR] %s: a lone '*' alternate at %s:%d (the reference's GetTruth cannot read it either)" % (vcf_fn, ctg_name, pos))
+            if alts[1] == "*":
+                alts = ["*", col[4][0]]
+        for alt in alts:
+            site = pos - 1 if alt == "*" else pos
+            if not out or out[-1] != site:
+                out.append(site)
     p.stdout.close()
     p.wait()
-    return np.array(sorted(out), dtype=np.int64)
+    return np.array(out, dtype=np.int64)
 
 
 def tensor_batches(args, positions, batch_size):

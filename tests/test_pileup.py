@@ -305,44 +305,18 @@ def test_in_process_tensor_batches_equal_the_text_pipeline(region):
 
 
 def test_vcf_sites_as_candidates():
+    """--vcf_fn: the candidate stream = column 2 of what the reference's GetTruth prints (tests/golden/get_truth.json, minted by
+    running dataPrepScripts/GetTruth.py here): '*' alternates add the base before, equal positions collapse, order as printed."""
     from clair_amd import callVarBam
+    doc = json.load(open(os.path.join(HERE, "golden", "get_truth.json")))
     with tempfile.TemporaryDirectory() as tmp:
         vcf = os.path.join(tmp, "sites.vcf")
-        open(vcf, "w").write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n"
-                             "chrS\t100\t.\tA\tG\t.\t.\t.\tGT\t0/1\nchrS\t250\t.\tAC\tA,*\t.\t.\t.\tGT\t1/2\nchrT\t5\t.\tA\tG\t.\t.\t.\tGT\t1/1\n"
-                             "chrS\t900\t.\tA\tG\t.\t.\t.\tGT\t1/1\n")
-        assert callVarBam.positions_from_vcf(vcf, "chrS", None, None).tolist() == [100, 249, 250, 900]
-        assert callVarBam.positions_from_vcf(vcf, "chrS", 200, 899).tolist() == [249, 250]
-
-
-@pytest.mark.gpu
-def test_callVarBam_vcf_equals_three_stage_text_pipeline(tmp_path):
-    """BAM -> VCF in one process (arrays between the stages) vs extract_variant_candidates | create_tensor | call_var over
-    their text interfaces, same random-weights model on the MI355X: byte-identical VCF."""
-    from clair_amd import weights
-    case, fa, sam = _bam_case(str(tmp_path), seed=302)
-    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
-    ck = weights.save_weights(str(tmp_path / "model"), w)[:-4]
-    common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS]
-    r1 = subprocess.run([sys.executable, "-m", "clair_amd.extract_variant_candidates", "--threshold", "0.125", "--minCoverage", "4"] + common,
-                        capture_output=True, text=True, cwd=ROOT, check=True)
-    tensors = str(tmp_path / "t.gz")
-    subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--tensor_fn", tensors] + common, input=r1.stdout, text=True,
-                   cwd=ROOT, check=True, capture_output=True)
-    v1, v2 = str(tmp_path / "text.vcf"), str(tmp_path / "inproc.vcf")
-    subprocess.run([sys.executable, "-m", "clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors, "--call_fn", v1,
-                    "--ref_fn", fa, "--sampleName", "S1", "--batch_size", "128"], cwd=ROOT, check=True, capture_output=True)
-    subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", v2, "--sampleName", "S1",
-                    "--batch_size", "96"] + common, cwd=ROOT, check=True, capture_output=True)
-    a, b = open(v1).read(), open(v2).read()
-    assert a == b and a.count("\n") > 40
-    # binary tensor records through the file interface: same VCF again
-    tensors_bin, v3 = str(tmp_path / "t.bin.gz"), str(tmp_path / "bin.vcf")
-    subprocess.run([sys.executable, "-m", "clair_amd.create_tensor", "--tensor_fn", tensors_bin, "--binary"] + common, input=r1.stdout,
-                   text=True, cwd=ROOT, check=True, capture_output=True)
-    subprocess.run([sys.executable, "-m", "clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors_bin, "--call_fn", v3,
-                    "--ref_fn", fa, "--sampleName", "S1", "--batch_size", "200"], cwd=ROOT, check=True, capture_output=True)
-    assert open(v3).read() == a
+        open(vcf, "w").write(doc["vcf"])
+        for name, case in doc["cases"].items():
+            a = callVarBam.build_parser().parse_args(["--ctgName", "chrS"] + case["extra"])
+            want = [int(r.split()[1]) for r in case["stdout"].splitlines()]
+            assert callVarBam.positions_from_vcf(vcf, "chrS", a.ctgStart, a.ctgEnd).tolist() == want, name
+        assert 499 in want or name != "all"
 
 
 def test_callVarBamParallel_commands_match_reference():
