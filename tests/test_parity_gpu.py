@@ -204,3 +204,32 @@ def test_submit_counts_equals_submit_on_the_float_tensor(engine):
     engine.submit_counts(0, counts)
     got = engine.wait(0)
     assert all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """`python bench.py --steps K --warmup W`: exactly one JSON line on stdout carrying the driver's contract fields plus
+    `roofline` and `cpu_baseline` (short run: few steps, 2 s of CPU baseline)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_WARM_STEPS="16")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "24", "--warmup", "4", "--cpu-seconds", "2"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["steps"] == 24 and d["warmup"] == 4 and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e6 and abs(d["value"] - 24 * d["config"]["batch"] / (d["ms_per_step"] * 24e-3)) < 0.01 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert d["gt_concordance"]["gt_identical"] is True and d["parity_max_abs_err"] < 1e-5
