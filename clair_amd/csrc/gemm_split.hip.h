@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef GEMM_PROBE_NOSTORE   // tools/ubench/gemm_split_probe.hip only
                     if (acc[mi][ni][4 * a] == 12345.678f)
 #endif
-                    *(f32x4 *)(dst + a * 256) = (f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]};
+                    __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)(dst + a * 256));
             }
         }
     }

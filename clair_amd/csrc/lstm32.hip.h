@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float *src = zx0 + ((size_t)t * 16 + b) * 1024;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const f32x4 v = *(const f32x4 *)(src + a * 256);
+                const f32x4 v = __builtin_nontemporal_load((const f32x4 *)(src + a * 256));   // read once: keep it out of the caches' way
                 z[4 * a + 0] = v[0]; z[4 * a + 1] = v[1]; z[4 * a + 2] = v[2]; z[4 * a + 3] = v[3];
             }
         }
