@@ -21,6 +21,8 @@ SYMBOLS = (
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
     "clair_debug_read",
+    "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_last_error", "clair_comm_barrier",
+    "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail")
 
@@ -68,9 +70,20 @@ def load():
     lib.clair_timing_reset.argtypes = [c_vp]
     lib.clair_kernel_workgroups.argtypes = [c_vp, c_int, c_vp]
     lib.clair_debug_read.argtypes = [c_vp, c_int, c_int, c_vp, c_i64]
+    lib.clair_comm_unique_id.argtypes = [c_vp]
+    lib.clair_comm_create.argtypes = [c_int, c_int, c_int, c_vp, ctypes.POINTER(c_vp)]
+    lib.clair_comm_destroy.argtypes = [c_vp]
+    lib.clair_comm_destroy.restype = None
+    lib.clair_comm_last_error.argtypes = [c_vp]
+    lib.clair_comm_last_error.restype = ctypes.c_char_p
+    lib.clair_comm_barrier.argtypes = [c_vp]
+    lib.clair_comm_allreduce_f64.argtypes = [c_vp, c_vp, c_int, c_int]
+    lib.clair_comm_broadcast.argtypes = [c_vp, c_vp, c_i64, c_int]
+    lib.clair_comm_allgather.argtypes = [c_vp, c_vp, c_vp, c_i64]
+    lib.clair_comm_allgather_device.argtypes = [c_vp, c_vp, c_vp, c_i64]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("clair_last_error", "clair_engine_destroy"):
+        if name not in ("clair_last_error", "clair_engine_destroy", "clair_comm_last_error", "clair_comm_destroy"):
             fn.restype = c_int
     _lib = lib
     return lib
@@ -191,8 +204,14 @@ class Engine(object):
         self._check(self._lib.clair_sync(self._h), "clair_sync")
 
     # -- measurement ---------------------------------------------------------------------------
-    def timing_enable(self, on=True):
-        self._check(self._lib.clair_timing_enable(self._h, int(bool(on))), "clair_timing_enable")
+    def timing_enable(self, on=True, only=None):
+        """HIP-event timing of every kernel (on=True), of none (False), or of the kernels named in `only` (KERNEL_NAMES)."""
+        mask = int(bool(on))
+        if only:
+            mask = 0
+            for k in only:
+                mask |= 1 << KERNEL_NAMES.index(k)
+        self._check(self._lib.clair_timing_enable(self._h, mask), "clair_timing_enable")
 
     def timing_reset(self):
         self._check(self._lib.clair_timing_reset(self._h), "clair_timing_reset")

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "engine.hip")
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("engine.hip", "comm.hip")]
 OUT = os.path.join(HERE, "libclair_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     build_host(force)
     if not force and not needs_build():
         return OUT
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC"] + SRCS + ["-o", OUT, "-ldl"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -28,12 +28,21 @@ __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fas
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
 
 // clair/selu.py:26-30 : scale * where(x >= 0, x, alpha * elu(x))
+// elu needs expm1, not exp - 1: near 0 the subtraction leaves 6e-8 ABSOLUTE, i.e. 1e-5 relative on an activation of
+// 0.01 -- visible as 1e-5 on the probabilities once a layer with small outputs feeds one with large weights
+// (tools/parity_sweep.py, cell "L4 kernel x0.01").  On (-0.25, 0] the degree-7 Taylor polynomial is exact to 5e-8
+// relative; below, exp - 1 is (<= 2e-7 relative).
 __device__ __forceinline__ float selu_f(float x) {
     constexpr float alpha = 1.6732632423543772848170429916717f;
     constexpr float scale = 1.0507009873554804934193349852946f;
-    // expm1 for x<0: exp(x)-1 loses ~1e-7 absolute near 0, harmless after the scale.
-    float neg = alpha * (fast_exp(x) - 1.0f);
-    return scale * (x >= 0.0f ? x : neg);
+    float p = fmaf(x, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    const float em1 = x > -0.25f ? p * x : fast_exp(x) - 1.0f;
+    return scale * (x >= 0.0f ? x : alpha * em1);
 }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

@@ -211,6 +211,7 @@ struct TailArgs {
     float *out;           // [n][90]
     int n_pad;
     int n;                // valid candidates
+    float l4_scale;       // 2^-w4_shift: the partials are sums over the W4 image scaled by 2^w4_shift (engine.hip)
 };
 
 __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
@@ -225,10 +226,11 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
     // L4: fixed-order reduction of the split-K partials, bias, selu
     for (int f = tid; f < TAIL_TILE * (L4_UNITS / 4); f += 256) {
         const int m = f / (L4_UNITS / 4), j4 = f - m * (L4_UNITS / 4);
-        f32x4 s = *(const f32x4 *)(p.b4 + j4 * 4);
+        f32x4 s = *(const f32x4 *)(p.l4part + ((size_t)n0 + m) * L4_UNITS + j4 * 4);
 #pragma unroll
-        for (int sp = 0; sp < L4_SPLITS; ++sp)
+        for (int sp = 1; sp < L4_SPLITS; ++sp)
             s += *(const f32x4 *)(p.l4part + ((size_t)sp * p.n_pad + n0 + m) * L4_UNITS + j4 * 4);
+        s = s * p.l4_scale + *(const f32x4 *)(p.b4 + j4 * 4);
         f32x4 o = {selu_f(s[0]), selu_f(s[1]), selu_f(s[2]), selu_f(s[3])};
         *(f32x4 *)&l4s[m][j4 * 4] = o;
     }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -59,8 +60,9 @@ struct clair_engine {
     int max_batch = 0;
     int max_pad = 0;
     bool weights_ready = false;
-    bool timing = false;
+    unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
     int proj2_groups = 4;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 8 gate tiles x groups workgroups (see clair_engine_create)
+    int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<Slot> slots;
@@ -126,7 +128,8 @@ inline int gate_col(int w, int b, int rho) {
 
 // fp16 2-way split A fragments of W^T for v_mfma_f32_32x32x16_f16: [dir][wave][b][kk][plane][lane][8]:
 // W[k0 + 16*kk + 8*(lane/32) + j][gate_col(w, b, lane%32)] * gate_scale, kk < nkk
-std::vector<unsigned short> pack_wt32(const std::vector<float> &fw, const std::vector<float> &bw, int k0, int nkk) {
+// `pow2` is an extra power-of-two factor on the image (exact): see L32_X_SHIFT in lstm32.hip.h
+std::vector<unsigned short> pack_wt32(const std::vector<float> &fw, const std::vector<float> &bw, int k0, int nkk, float pow2 = 1.0f) {
     std::vector<unsigned short> out((size_t)2 * 4 * 4 * nkk * 2 * 64 * 8);
     for (int d = 0; d < 2; ++d) {
         const std::vector<float> &src = d ? bw : fw;
@@ -137,7 +140,7 @@ std::vector<unsigned short> pack_wt32(const std::vector<float> &fw, const std::v
                         for (int j = 0; j < 8; ++j) {
                             const int col = gate_col(w, b, lane & 31), k = k0 + 16 * kk + 8 * (lane >> 5) + j;
                             unsigned short hi, lo;
-                            split2_host(src[(size_t)k * 512 + col] * gate_scale(col), hi, lo);
+                            split2_host(src[(size_t)k * 512 + col] * gate_scale(col) * pow2, hi, lo);
                             const size_t base = (((((size_t)(d * 4 + w) * 4 + b) * nkk + kk) * 2) * 64 + lane) * 8 + j;
                             out[base] = hi;
                             out[base + 64 * 8] = lo;
@@ -190,10 +193,10 @@ hipEvent_t get_event(Slot &s) {
 struct KernelTimer {
     clair_engine *e; Slot &s; int id; hipEvent_t start = nullptr, stop = nullptr;
     KernelTimer(clair_engine *e_, Slot &s_, int id_) : e(e_), s(s_), id(id_) {
-        if (e->timing) { start = get_event(s); stop = get_event(s); (void)hipEventRecord(start, s.stream); }
+        if ((e->timing_mask >> id) & 1u) { start = get_event(s); stop = get_event(s); (void)hipEventRecord(start, s.stream); }
     }
     ~KernelTimer() {
-        if (e->timing) { (void)hipEventRecord(stop, s.stream); s.timed.push_back({id, start, stop}); }
+        if (start) { (void)hipEventRecord(stop, s.stream); s.timed.push_back({id, start, stop}); }
     }
 };
 
@@ -244,7 +247,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
-        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n};
+        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift)};
         hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
@@ -367,7 +370,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if (upload16(e, &e->wx2s, w2s)) return 1;
     }
     if (upload16(e, &e->wh1s, pack_wt32(T[0], T[2], F_IN, 8)) || upload16(e, &e->wh2s, pack_wt32(T[4], T[6], 2 * HID, 8)) ||
-        upload16(e, &e->wx1s, pack_wt32(T[0], T[2], 0, 2))) return 1;
+        upload16(e, &e->wx1s, pack_wt32(T[0], T[2], 0, 2, (float)(1 << L32_X_SHIFT)))) return 1;
     {   // L3 B fragments (dense.hip.h: l3l4_kernel): w3f[c][lane][kk*2 + nbk] = W3[c][t = lq*9 + kk][u = nbk*16 + li]
         std::vector<float> w3f((size_t)256 * 64 * 20, 0.0f);
         for (int c = 0; c < 256; ++c)
@@ -381,6 +384,18 @@ int clair_finalize_weights(clair_engine_t *e) {
         if (upload(e, &e->w3f, w3f) || upload(e, &e->b3, T[9])) return 1;
     }
     {   // W4 as fp16 split B fragments of the fused L3/L4 kernel (dense.hip.h): [cg][ks][nb][plane][lane][8]
+        // The image is W4 * 2^w4_shift (exact): a freshly initialised W4 has sigma = 0.011 and a trained one may be smaller still,
+        // i.e. residuals below the fp16 normal range -- the low plane would keep them to 3e-8 ABSOLUTE only (common.hip.h).  The
+        // shift puts the largest |W4| into [2^13, 2^14); the kernel that reduces the split-K partials multiplies by 2^-w4_shift.
+        float w4max = 0.0f;
+        for (float v : T[10]) w4max = std::max(w4max, std::fabs(v));
+        e->w4_shift = 0;
+        if (w4max > 0.0f && std::isfinite(w4max)) {
+            int ex = 0;
+            (void)std::frexp(w4max, &ex);              // w4max = m * 2^ex, m in [0.5, 1)
+            e->w4_shift = std::max(-20, std::min(40, 14 - ex));
+        }
+        const float w4_pow2 = std::ldexp(1.0f, e->w4_shift);
         std::vector<unsigned short> w4s((size_t)16 * 15 * 12 * 2 * 64 * 8);
         for (int cg = 0; cg < 16; ++cg)
             for (int ks = 0; ks < 15; ++ks)
@@ -390,7 +405,7 @@ int clair_finalize_weights(clair_engine_t *e) {
                             const int li = lane & 15, lq = lane >> 4;
                             const int u = 2 * ks + (lq >> 1), ch = 8 * (lq & 1) + j;
                             unsigned short hi, lo;
-                            split2_host(T[10][((size_t)u * 256 + cg * 16 + ch) * L4_UNITS + nb * 16 + li], hi, lo);
+                            split2_host(T[10][((size_t)u * 256 + cg * 16 + ch) * L4_UNITS + nb * 16 + li] * w4_pow2, hi, lo);
                             const size_t base = (((((size_t)cg * 15 + ks) * 12 + nb) * 2) * 64 + lane) * 8 + j;
                             w4s[base] = hi;
                             w4s[base + 64 * 8] = lo;
@@ -559,7 +574,7 @@ int clair_timing_enable(clair_engine_t *e, int on) {
     if (!e) return fail(nullptr, "engine is NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     if (drain_timers(e)) return 1;
-    e->timing = on != 0;
+    e->timing_mask = on == 0 ? 0u : (on == 1 ? ~0u : (unsigned)on);
     return 0;
 }
 
@@ -621,6 +636,10 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
     }
     if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);
     HIP_TRY(e, hipMemcpy(host, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    if (which == 3) {   // the partials are sums over the 2^w4_shift-scaled image
+        const float inv = std::ldexp(1.0f, -e->w4_shift);
+        for (int64_t i = 0; i < count; ++i) host[i] *= inv;
+    }
     return 0;
 }
 

@@ -79,7 +79,8 @@ def _truncated_normal(rng, shape, stddev):
     return (out * stddev).astype(np.float32)
 
 
-def synthetic_weights(seed=20250928, head_gain=1.0, lstm_bias_scale=0.0):
+def synthetic_weights(seed=20250928, head_gain=1.0, lstm_bias_scale=0.0, lstm_gain=1.0, forget_bias=0.0,
+                      input_gain=1.0, l4_gain=1.0, small_fraction=0.0, small_scale=1e-3):
     """Random-init weights of the reference architecture with a fixed seed.
 
     Dense kernels: variance_scaling_initializer(factor=1.0, mode='FAN_IN')
@@ -88,6 +89,14 @@ def synthetic_weights(seed=20250928, head_gain=1.0, lstm_bias_scale=0.0):
     (clair/model.py:300-311), i.e. the variable-scope default Glorot-uniform; biases zero.
     ``head_gain`` scales the four head kernels so that the softmaxes become peaky and
     every branch of the VCF decode is exercised by synthetic data.
+
+    The remaining switches shape the weights like a TRAINED model rather than a fresh one, for the parity sweep
+    (tests/test_parity_gpu.py): ``lstm_gain`` scales the four LSTM kernels (saturating gates), ``forget_bias`` is added
+    to the forget-gate biases (columns 256..383), ``input_gain`` scales the rows of the LSTM1 kernels that multiply the
+    pileup counts (a net trained on counts of 50..250 keeps them small), ``l4_gain`` scales the 7680->192 kernel and
+    divides the L5 kernels by the same factor (same function up to the selu in between, different magnitudes), and
+    ``small_fraction`` of every kernel's entries are multiplied by ``small_scale`` (entries of 1e-4 magnitude: their
+    fp16 low planes are subnormal).
     """
     rng = np.random.default_rng(seed)
     w = OrderedDict()
@@ -105,6 +114,22 @@ def synthetic_weights(seed=20250928, head_gain=1.0, lstm_bias_scale=0.0):
             w[key] = _truncated_normal(rng, shape, np.sqrt(1.3 / fan_in))
             if key.startswith("head_"):
                 w[key] *= np.float32(head_gain)
+    for key in TENSOR_TABLE:
+        if key.startswith("lstm") and key.endswith("_kernel"):
+            w[key] *= np.float32(lstm_gain)
+            if key.startswith("lstm1"):
+                w[key][:F_IN] *= np.float32(input_gain)
+        elif key.startswith("lstm") and forget_bias:
+            w[key][2 * H:3 * H] += np.float32(forget_bias)
+    if l4_gain != 1.0:
+        w["l4_kernel"] *= np.float32(l4_gain)
+        w["l5_kernel"] *= np.float32(1.0 / l4_gain)
+    if small_fraction:
+        srng = np.random.default_rng(seed + 977)
+        for key in TENSOR_TABLE:
+            if key.endswith("_kernel"):
+                mask = srng.random(w[key].shape) < small_fraction
+                w[key][mask] *= np.float32(small_scale)
     return w
 
 

@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define CLAIR_ABI_VERSION 1
+/* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
+ * bump), the clair_comm_* communicator (round 2). */
+#define CLAIR_ABI_VERSION 2
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
 #define CLAIR_POSITIONS 33
@@ -137,7 +139,9 @@ int clair_sync(clair_engine_t *e);
 /* -- measurement ---------------------------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on the slot's own stream.
  * clair_kernel_times returns, per kernel id, the summed duration in milliseconds and the number
- * of launches since the last reset (it synchronises first). */
+ * of launches since the last reset (it synchronises first).
+ * on: 0 = off, 1 = every kernel, any other value = bit mask over enum clair_kernel_id (bit k = kernel k; bit 0 names an
+ * unused id, so 1 is unambiguous): a pass that times ONE kernel adds two marker packets per forward pass instead of ten. */
 int clair_timing_enable(clair_engine_t *e, int on);
 int clair_kernel_times(clair_engine_t *e, double *ms_sum /*[CLAIR_K_COUNT]*/, int64_t *launches /*[CLAIR_K_COUNT]*/);
 int clair_timing_reset(clair_engine_t *e);
@@ -152,6 +156,29 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups /*[CLAIR_K
  *    with CLAIR_AMD_TAP_L3=1 in the environment)
  *    (L3/L4 activations only ever exist in LDS / split-K partials).  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);
+
+/* -- multi-GPU: one process per GPU, candidates shard in contiguous blocks of whole batches -------------------------------
+ * The reference scales out by running one callVarBam per 10 Mbp chunk under GNU parallel and concatenating the chunk VCFs
+ * (clair/callVarBamParallel.py:90-119, README.md:297-303); candidates are classified independently
+ * (docs/POST_PROCESSING.md:17).  Here rank r owns a contiguous block of the candidate stream (clair_amd/shard.py) and the
+ * forward pass needs NO collective.  This communicator is a thin binding of RCCL (xGMI between the GPUs of a node) for
+ * the trivial parts only: the weight blob from rank 0 (9.5 MB, once), the gather of per-rank output rows, counters and timers.
+ * librccl.so is loaded on the first call.  Rendezvous: rank 0 calls clair_comm_unique_id and hands the 128 bytes to the
+ * other ranks out of band (clair_amd/shard.py uses a socket on 127.0.0.1); every rank then calls clair_comm_create
+ * (collective: returns once all `world` ranks have joined).  All calls are blocking; host buffers are staged through HBM. */
+#define CLAIR_COMM_ID_BYTES 128
+enum clair_comm_op { CLAIR_COMM_SUM = 0, CLAIR_COMM_MAX = 1, CLAIR_COMM_MIN = 2 };
+typedef struct clair_comm clair_comm_t;
+int clair_comm_unique_id(uint8_t *id /*[CLAIR_COMM_ID_BYTES]*/);                 /* ncclGetUniqueId */
+int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_comm_t **out);   /* ncclCommInitRank */
+void clair_comm_destroy(clair_comm_t *c);
+const char *clair_comm_last_error(const clair_comm_t *c);                         /* c may be NULL: failure of create / unique_id */
+int clair_comm_barrier(clair_comm_t *c);
+int clair_comm_allreduce_f64(clair_comm_t *c, double *values /*in place*/, int count, int op /*enum clair_comm_op*/);
+int clair_comm_broadcast(clair_comm_t *c, void *host, int64_t bytes, int root);  /* ncclBroadcast of a host buffer (the weight blob) */
+int clair_comm_allgather(clair_comm_t *c, const void *send_host, void *recv_host /*[world][bytes_per_rank]*/, int64_t bytes_per_rank);
+/* the same on HBM-resident buffers (e.g. the out_dev rows of clair_dataset_alloc), no host staging */
+int clair_comm_allgather_device(clair_comm_t *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ def lib():
             build()
         _LIB = ctypes.CDLL(path)
         _LIB.clair_oracle_forward_ex.restype = ctypes.c_int
+        _LIB.clair_oracle_forward_ex_f64.restype = ctypes.c_int
         _LIB.clair_oracle_max_threads.restype = ctypes.c_int
     return _LIB
 
@@ -36,21 +37,26 @@ def max_threads():
     return int(lib().clair_oracle_max_threads())
 
 
-def forward(w, x, threads=0, keep_intermediates=False):
-    """x [n,33,8,4] float32 -> [gt21, genotype, len1, len2] (+ dict of intermediates)."""
+def forward(w, x, threads=0, keep_intermediates=False, dtype=np.float32):
+    """x [n,33,8,4] float32 -> [gt21, genotype, len1, len2] (+ dict of intermediates).
+
+    dtype=np.float64 evaluates the same graph in double precision from the same float32 weights and inputs
+    (outputs and intermediates come back as float64): the yardstick for float32 rounding itself."""
     L = lib()
+    dtype = np.dtype(dtype)
+    fn = L.clair_oracle_forward_ex if dtype == np.float32 else L.clair_oracle_forward_ex_f64
     x = np.ascontiguousarray(x, dtype=np.float32)
     n = x.shape[0]
     keep = [np.ascontiguousarray(w[k], dtype=np.float32) for k in TENSOR_ORDER]
     ptrs = (ctypes.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
-    outs = [np.empty((n, m), dtype=np.float32) for m in (21, 3, 33, 33)]
+    outs = [np.empty((n, m), dtype=dtype) for m in (21, 3, 33, 33)]
     inter = {}
     if keep_intermediates:
-        inter = dict(a1=np.empty((n, 33, 256), np.float32), a2=np.empty((n, 33, 256), np.float32),
-                     l3=np.empty((n, 7680), np.float32), l4=np.empty((n, 192), np.float32))
+        inter = dict(a1=np.empty((n, 33, 256), dtype), a2=np.empty((n, 33, 256), dtype),
+                     l3=np.empty((n, 7680), dtype), l4=np.empty((n, 192), dtype))
     p = lambda a: ctypes.c_void_p(a.ctypes.data)
     opt = lambda k: p(inter[k]) if keep_intermediates else ctypes.c_void_p(0)
-    rc = L.clair_oracle_forward_ex(ptrs, p(x), ctypes.c_int(n), *[p(o) for o in outs],
+    rc = fn(ptrs, p(x), ctypes.c_int(n), *[p(o) for o in outs],
                                    opt("a1"), opt("a2"), opt("l3"), opt("l4"), ctypes.c_int(threads))
     if rc != 0:
         raise RuntimeError("clair_oracle_forward failed (rc=%d)" % rc)

@@ -38,7 +38,7 @@ def test_layerwise_taps(engine, synth_weights):
     x, _ = synth.synthetic_input(n, "ont", seed=77)
     engine.predict(x)
     want, inter = _oracle(synth_weights, x, keep_intermediates=True)
-    n_pad = (n + 31) // 32 * 32      # engine pads to two 16-candidate tiles (include/clair_amd.h)
+    n_pad = (n + 31) // 32 * 32      # the engine pads to whole 32-candidate tiles (include/clair_amd.h: clair_debug_read)
     a1 = engine.debug_read(0, 1, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
     a2 = engine.debug_read(0, 2, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
     assert np.abs(a1 - inter["a1"]).max() <= ACT_TOL
@@ -72,6 +72,68 @@ def test_full_size_batches_by_properties(synth_weights, n, platform):
             assert np.abs(g[pick] - w_).max() <= PROB_TOL
     finally:
         eng.close()
+
+
+def _sweep_cells():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_sweep
+    return parity_sweep
+
+
+def test_weight_sweep_trained_like_shapes_vs_float32_and_float64_oracles():
+    """Parity beyond fresh random init: LSTM kernels x4 / x8 (saturating gates), forget-gate bias +1, count rows of
+    1e-3 magnitude, an L4 kernel of 1e-4 magnitude (fp16 low planes subnormal without the image shifts of engine.hip), half of
+    all kernel entries x1e-3, head gains 1..12; ONT and 300x Illumina inputs.  Criterion per cell, on the probabilities:
+      * |hip - o32| <= 1e-5 wherever the float32 oracle itself is within 2.5e-6 of the float64 evaluation of the same graph;
+      * always |hip - o64| <= max(1e-5, 4 |o32 - o64|): where float32 rounding alone moves the outputs by more than the
+        tolerance (recurrences that amplify 1-ulp differences ~1000x), the HIP path stays in the same class as the oracle."""
+    ps = _sweep_cells()
+    from clair_amd import _capi, weights
+    n = 256
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
+    bad = []
+    try:
+        for label, kw in ps.WEIGHT_CELLS:
+            w = weights.synthetic_weights(**dict(ps.BASE, **kw))
+            eng.load_weights(w)
+            for platform in ("ont", "illumina"):
+                x, _ = synth.synthetic_input(n, platform, seed=4000 + n)
+                r = ps.errors(eng, w, x, taps=False)
+                ok = r["finite"] and r["hip_vs_o64"] <= max(PROB_TOL, 4 * r["o32_vs_o64"])
+                if r["o32_vs_o64"] <= 2.5e-6:
+                    ok = ok and r["hip_vs_o32"] <= PROB_TOL
+                if not ok:
+                    bad.append((label, platform, r))
+    finally:
+        eng.close()
+    assert not bad, bad
+
+
+def test_extreme_counts_through_submit_counts_vs_oracles():
+    """clair_submit_counts against the ORACLE (not against predict) at counts 0, 250 (CreateTensor's depth cap), 2047 (last
+    integer the fp16 high plane holds alone) and 32767 (int16 boundary), on fresh and on trained-like weights."""
+    ps = _sweep_cells()
+    from clair_amd import _capi, weights
+    n = 128
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
+    bad = []
+    try:
+        for kw in (dict(), dict(input_gain=0.01, lstm_gain=4.0, forget_bias=1.0)):
+            w = weights.synthetic_weights(**dict(ps.BASE, **kw))
+            eng.load_weights(w)
+            for level, counts in ps.count_batches(n):
+                x = counts.astype(np.float32)
+                x[..., 1:] -= x[..., 0:1]
+                r = ps.errors(eng, w, x, counts=counts, taps=False)
+                if not (r["finite"] and r["hip_vs_o64"] <= max(PROB_TOL, 4 * r["o32_vs_o64"])):
+                    bad.append((kw, level, r))
+                if level == 0:
+                    assert r["hip_vs_o32"] <= 1e-7
+    finally:
+        eng.close()
+    assert not bad, bad
 
 
 def test_l3_tap_has_no_split_outliers(synth_weights, monkeypatch):
@@ -228,8 +290,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1e6 and abs(d["value"] - 24 * d["config"]["batch"] / (d["ms_per_step"] * 24e-3)) < 0.01 * d["value"]
     roof = d["roofline"]
-    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # algorithmic FLOP of the kernel / its mean duration IN the multi-stream run / dense f16 peak
+    flop = 2 * 33 * 2 * 256 * 512 * d["config"]["batch"]
+    assert roof["algorithmic_flop_per_launch"] == flop
+    assert abs(roof["achieved"] - flop / (roof["kernel_ms"] * 1e-3) / 1e12) < 0.01 * roof["achieved"]
+    assert abs(roof["executed_frac"] - 3 * roof["frac"]) < 2e-3 and roof["alone_kernel_ms"] <= roof["kernel_ms"] * 1.05
     assert roof["traffic"] is None or roof["traffic"] > 0
+    assert d["config"]["device_warm_steps"] == 12 and len(d["per_rank"]) == 1
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert d["gt_concordance"]["gt_identical"] is True and d["parity_max_abs_err"] < 1e-5

@@ -1,8 +1,12 @@
-"""Multi-GPU path on CPU: candidate sharding + the (trivial) collectives, world_size 2 over gloo.
+"""Multi-GPU path on CPU: candidate sharding + the (trivial) collectives, world_size 2.
 
 Each rank runs the forward pass of ITS shard (the oracle stands in for the GPU engine here: no GPU in
 this container), the shards are gathered in rank order and must equal the single-process result
-bit for bit -- candidates are independent, so sharding must not change anything."""
+bit for bit -- candidates are independent, so sharding must not change anything.  Two launchers are
+covered: bench.py's own spawner (clair_amd.shard.spawn_ranks) and torch.distributed.run, the way the
+driver starts `bench.py --gpus N`; in the second the NodeGroup results are cross-checked against
+torch.distributed's gloo backend inside the workers (torch is test-side only: nothing under clair_amd/
+imports it)."""
 import os
 import socket
 import subprocess
@@ -17,7 +21,8 @@ from clair_amd import shard
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("n,batch,world", [(0, 4, 2), (1, 4, 2), (10, 4, 2), (16, 4, 2), (1000, 100, 8), (5, 1024, 8), (200000, 1024, 8)])
+@pytest.mark.parametrize("n,batch,world", [(0, 4, 2), (1, 4, 2), (10, 4, 2), (16, 4, 2), (1000, 100, 8), (5, 1024, 8), (200000, 1024, 8),
+                                           (5000000, 1024, 8), (5000000, 8192, 8)])
 def test_shard_batches_partition(n, batch, world):
     covered = 0
     for r in range(world):
@@ -37,8 +42,9 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %(root)r)
     from clair_amd import shard, synth, weights
     from oracle import c_oracle
-    g = shard.NodeGroup(backend="gloo")
-    w = weights.synthetic_weights(seed=5)
+    g = shard.NodeGroup(transport="tcp")
+    w0 = weights.synthetic_weights(seed=5) if g.rank == 0 else None
+    w = g.broadcast_weights(w0)                       # the other ranks never build the weights themselves
     x, _ = synth.synthetic_input(37, "ont", seed=9)
     first, cnt = shard.shard_batches(len(x), 8, g.rank, g.world)
     outs = c_oracle.forward(w, x[first:first + cnt], threads=1)
@@ -47,27 +53,28 @@ WORKER = textwrap.dedent("""
     full = g.gather_arrays(packed)
     total = g.sum_int(cnt)
     slowest = g.max_float(1.0 + g.rank)
+    per_rank = g.gather_floats(10.0 * (g.rank + 1))
+    if %(gloo)r:
+        import torch, torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([1.0 + g.rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == slowest
+        c = torch.tensor([cnt], dtype=torch.int64); dist.all_reduce(c)
+        assert int(c.item()) == total
+        parts = [torch.zeros(1, dtype=torch.float64) for _ in range(g.world)]
+        dist.all_gather(parts, torch.tensor([10.0 * (g.rank + 1)], dtype=torch.float64))
+        assert [float(p.item()) for p in parts] == per_rank
+        dist.destroy_process_group()
     if g.rank == 0:
         np.save(%(out)r, full)
-        print("RESULT", total, slowest, full.shape[0])
+        print("RESULT", total, slowest, full.shape[0], g.transport, per_rank)
     g.close()
 """)
 
 
-def test_two_rank_gloo_shards_match_single_process(tmp_path):
-    out = str(tmp_path / "gathered.npy")
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "out": out})
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT")][0].split()
-    assert int(line[1]) == 37 and float(line[2]) == 2.0 and int(line[3]) == 37
+def _check(out, stdout):
+    line = [ln for ln in stdout.splitlines() if ln.startswith("RESULT")][0].split()
+    assert int(line[1]) == 37 and float(line[2]) == 2.0 and int(line[3]) == 37 and line[4] == "tcp"
     from clair_amd import synth, weights
     from oracle import c_oracle
     w = weights.synthetic_weights(seed=5)
@@ -75,3 +82,67 @@ def test_two_rank_gloo_shards_match_single_process(tmp_path):
     want = np.concatenate(c_oracle.forward(w, x, threads=1), axis=1)
     got = np.load(out)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_two_ranks_own_spawner_shards_match_single_process(tmp_path):
+    out = str(tmp_path / "gathered.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out, "gloo": False})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 2, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    stdout = procs[0].stdout.read().decode()
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+    _check(out, stdout)
+
+
+def test_two_ranks_under_torch_distributed_run_cross_checked_with_gloo(tmp_path):
+    out = str(tmp_path / "gathered.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out, "gloo": True})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("CLAIR_AMD_RDZV", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    _check(out, res.stdout)
+
+
+def test_bench_gpus_2_spawns_two_ranks_that_fail_loudly_without_a_device():
+    from clair_amd import _capi
+    if _capi.load().clair_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    env = dict(os.environ, BENCH_WARM_STEPS="0")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("no HIP device") >= 2, res.stderr[-2000:]
+    assert "rank 0 rc=" in res.stderr and "rank 1 rc=" in res.stderr
+    assert not res.stdout.strip()
+
+
+def test_rccl_communicator_fails_loudly_without_a_device():
+    import ctypes
+    from clair_amd import _capi
+    lib = _capi.load()
+    if lib.clair_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    uid = (ctypes.c_uint8 * 128)()
+    h = ctypes.c_void_p()
+    assert lib.clair_comm_create(0, 0, 1, uid, ctypes.byref(h)) != 0
+    assert b"no HIP device" in lib.clair_comm_last_error(None)
+    assert not h.value
+    assert lib.clair_comm_create(0, 3, 2, uid, ctypes.byref(h)) != 0
+    assert b"rank" in lib.clair_comm_last_error(None)
+
+
+def test_nothing_under_clair_amd_imports_torch():
+    pkg = os.path.join(ROOT, "clair_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                text = open(os.path.join(dp, f)).read()
+                assert "import torch" not in text and "from torch" not in text, os.path.join(dp, f)
