@@ -133,6 +133,10 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_and_relay(args)
+    # stdout carries exactly one JSON line: native libraries that print there (RCCL's start-up banner does) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     group = shard.NodeGroup()          # RCCL through the C ABI when WORLD_SIZE > 1
     rank, world, local_rank = group.rank, group.world, group.local_rank
     if world != args.gpus and rank == 0:
@@ -295,7 +299,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, x, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     eng.dataset_free(xd, od)
     eng.close()

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_parse_tensors",
-           "clair_host_decode_rows",
+           "clair_host_decode_rows", "clair_host_decode_rows_ex",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
            "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
@@ -29,6 +29,7 @@ def load():
                                                  ctypes.POINTER(i64)]
         lib.clair_host_decode_rows.argtypes = [vp, vp, vp, vp, vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                                ctypes.POINTER(i64), ctypes.POINTER(i32)]
+        lib.clair_host_decode_rows_ex.argtypes = lib.clair_host_decode_rows.argtypes + [vp]
         lib.clair_host_pileup_create.argtypes = [ctypes.c_char_p, i64, i64, vp, i64, i32, i32, i32, i32, i64, i32, ctypes.POINTER(vp)]
         lib.clair_host_pileup_destroy.argtypes = [vp]
         lib.clair_host_pileup_destroy.restype = None
@@ -51,8 +52,8 @@ def load():
         lib.clair_host_evc_reads.restype = i64
         lib.clair_host_evc_take.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
         lib.clair_host_evc_take_text.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
-        if lib.clair_host_abi_version() != 2:
-            raise RuntimeError("libclair_host.so has ABI version %d, expected 2: run `python -m clair_amd.build`"
+        if lib.clair_host_abi_version() != 3:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 3: run `python -m clair_amd.build`"
                                % lib.clair_host_abi_version())
         _lib = lib
     return _lib
@@ -78,12 +79,14 @@ def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):
     return taken.value, infos, used.value
 
 
-def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2):
-    """clair_host_decode_rows over one batch -> list of VCF row strings (input order, skipped candidates left out)."""
+def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2, with_status=False):
+    """clair_host_decode_rows over one batch -> list of VCF row strings (input order, skipped candidates left out).
+    with_status: also the per-candidate status bytes of clair_host_decode_rows_ex (bit 0: produced a row, bit 1: passed a
+    point where the reference would consult the BAM) -> (rows, status uint8 [n])."""
     lib = load()
     n = len(infos)
     if n == 0:
-        return []
+        return ([], np.zeros(0, np.uint8)) if with_status else []
     x = np.ascontiguousarray(X, dtype=np.float32).reshape(n, N_VALUES)
     gt21, genotype, len1, len2 = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
     parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
@@ -96,15 +99,16 @@ def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitiv
     cap = 4096 + 256 * n + 2 * len(meta)
     out = ctypes.create_string_buffer(cap)
     out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)
-    rc = lib.clair_host_decode_rows(x.ctypes.data, gt21.ctypes.data, genotype.ctypes.data, len1.ctypes.data, len2.ctypes.data,
-                                    meta, tok.ctypes.data, n, int(bool(show_reference)), int(bool(haploid_precision)),
-                                    int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
-                                    int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows))
+    status = np.zeros(n, dtype=np.uint8)
+    rc = lib.clair_host_decode_rows_ex(x.ctypes.data, gt21.ctypes.data, genotype.ctypes.data, len1.ctypes.data, len2.ctypes.data,
+                                       meta, tok.ctypes.data, n, int(bool(show_reference)), int(bool(haploid_precision)),
+                                       int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
+                                       int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows),
+                                       status.ctypes.data)
     if rc != 0:
         raise ValueError("native decode: " + lib.clair_host_last_error().decode())
-    if out_len.value == 0:
-        return []
-    return out.raw[:out_len.value - 1].decode("ascii").split("\n")
+    rows = out.raw[:out_len.value - 1].decode("ascii").split("\n") if out_len.value else []
+    return (rows, status) if with_status else rows
 
 
 class PileupBuilder(object):

@@ -48,7 +48,7 @@ def candidate_positions(args):
     finder = _hostapi.CandidateFinder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1,
                                       ctg_start=args.ctgStart if have_range else None, ctg_end=args.ctgEnd if have_range else None,
                                       bed=None if tree is None else tree[args.ctgName],
-                                      min_coverage=args.minCoverage, threshold=args.threshold, min_mq=0)
+                                      min_coverage=int(args.minCoverage), threshold=args.threshold, min_mq=0)   # callVarBam.py:75: int() before it reaches the extractor
     view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
                                text=False)
     chunks, tail = [], None

@@ -425,18 +425,31 @@ class VariantDecoder(object):
         self.native = native
 
     def decode_batch(self, X, infos, Y):
-        """Rows of one batch.  The common configuration (no BAM look-ups, no --debug, no --output_for_ensemble) runs in the
-        native decoder (include/clair_host.h: clair_host_decode_rows, byte-identical, ~100x); everything else on the
-        Python restatement below."""
+        """Rows of one batch.  The common configuration (no --debug, no --output_for_ensemble, no --pysam_for_all_indel_bases)
+        runs in the native decoder (include/clair_host.h: clair_host_decode_rows_ex, byte-identical, ~100x).  With a BAM open the
+        reference consults it only for indels of 16 bases or more and for the second allele of Ins/Ins calls
+        (call_var.py:498-524, 540-565, 805-823): the native decoder flags exactly those candidates and only they are decoded
+        again on the Python look-up path; everything else runs on the Python restatement below."""
         cfg = self.cfg
         if (self.native and not cfg.is_debug and not cfg.is_output_for_ensemble and not self.bases.always_use_bam
-                and self.lookup.sam is None and isinstance(cfg.quality_score_for_pass, (int, type(None)))):
+                and isinstance(cfg.quality_score_for_pass, (int, type(None)))):
             if len(Y[0]) != len(infos):
                 sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(Y[0])))
             from clair_amd import _hostapi
-            return _hostapi.decode_rows(X, infos, Y, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
-                                        cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass,
-                                        self.arith == "numpy2")
+            rows, status = _hostapi.decode_rows(X, infos, Y, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
+                                                cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass,
+                                                self.arith == "numpy2", with_status=True)
+            if self.lookup.sam is None or not (status & 2).any():
+                return rows
+            out, at = [], 0
+            Y = [np.asarray(a, dtype=np.float32) for a in Y]
+            for i, st in enumerate(status):
+                if st & 2:
+                    out.extend(self.decode_batch_py(X[i:i + 1], infos[i:i + 1], [a[i:i + 1] for a in Y]))
+                elif st & 1:
+                    out.append(rows[at])
+                at += int(st & 1)
+            return out
         return self.decode_batch_py(X, infos, Y)
 
     def decode_batch_py(self, X, infos, Y):
@@ -598,16 +611,30 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     use_async = hasattr(m, "submit") and hasattr(m, "wait")
     loaded = []
 
+    failures = []            # exc_info of a stage that died on its helper thread
+
     def load():
         try:
             loaded.append(next(generator))
         except StopIteration:
             loaded.append(None)
+        except BaseException:          # sys.exit of a failing upstream stage (samtools, a malformed record) included:
+            failures.append(sys.exc_info())   # a thread would swallow it and the loop would read "end of input"
+            loaded.append(None)
 
     def emit(batch, prediction):
-        writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
+        try:
+            writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
+        except BaseException:
+            failures.append(sys.exc_info())
+
+    def reraise():
+        if failures:
+            _, exc, tb = failures[0]
+            raise exc.with_traceback(tb)
 
     load()
+    reraise()
     current = loaded.pop()
     finished = None          # (batch, prediction) waiting to be written
     k = 0
@@ -630,6 +657,7 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
             m.prediction = prediction
         for t in threads:
             t.join()
+        reraise()            # the reference's callVarBam checks its stages' exit codes (callVarBam.py:218-233); here they are threads
         finished = (current, prediction) if current is not None else None
         current = loaded.pop() if loaded else None
         k += 1

@@ -140,7 +140,11 @@ struct Config { int show_ref, haploid_precision, haploid_sensitive, has_qual, qu
 
 // One candidate -> appends a row (without '\n') to out; returns 0 = no row, 1 = row, -1 = error (message set)
 int decode_one(const float *x, const float *g, const float *z, const float *l1, const float *l2, const char *ctg, int ctg_len,
-               long long position, const char *seq, int seq_len, const Config &cfg, Families &fam, std::string &out) {
+               long long position, const char *seq, int seq_len, const Config &cfg, Families &fam, std::string &out, bool &consulted) {
+    // consulted: the resolution passed a point where the reference asks the BAM when it has one (an indel of LONG_INDEL bases
+    // or more, call_var.py:498-524, 540-565; the second allele of an Ins/Ins call, :805-823).  This decoder answers every
+    // look-up with "" -- a caller that HAS a BAM re-decodes exactly those candidates on its own (clair_host_decode_rows_ex).
+    consulted = false;
     const char ref0 = seq[CENTER];
     if (!(ref0 == 'A' || ref0 == 'C' || ref0 == 'G' || ref0 == 'T' || ref0 == 'U')) return 0;   // call_var.py:1018
     float dsum[8];
@@ -215,6 +219,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
         else if (flags[F_HOMO_INS]) {
             const int idx = first[F_HOMO_INS];
             fam.alive[F_HOMO_INS][idx] = false;
+            consulted |= idx + 1 >= LONG_INDEL;
             const std::string ins = insertion_bases(x, idx + 1);
             if (!ins.empty()) { ref = r0; alt = r0 + ins; have = true; }
         } else if (flags[F_ACGT_INS]) {
@@ -222,6 +227,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
             fam.alive[F_ACGT_INS][idx] = false;
             const int length = idx / 4 + 1;
             const char base = "ACGT"[idx % 4];
+            consulted |= length >= LONG_INDEL;
             const std::string ins = insertion_bases(x, length);
             if (!ins.empty()) {
                 ref = r0; alt = r0 + ins;
@@ -233,8 +239,10 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
             fam.alive[F_INSINS][idx] = false;
             const int i = idx / 16 + 1, j = idx % 16 + 1;
             const int short_ = i <= j ? i : j, long_ = i <= j ? j : i;
+            consulted |= long_ >= LONG_INDEL;
             const std::string ins = insertion_bases(x, long_);
             if (!ins.empty()) {
+                consulted = true;
                 const std::string other = ins.substr(0, (size_t)short_ < ins.size() ? (size_t)short_ : ins.size());   // look-up "" -> ins[0:short]
                 const std::string firsts = r0 + other, second = r0 + ins;
                 if (firsts != second) { ref = r0; alt = firsts + "," + second; have = true; }
@@ -242,6 +250,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
         } else if (flags[F_HOMO_DEL]) {
             const int idx = first[F_HOMO_DEL];
             fam.alive[F_HOMO_DEL][idx] = false;
+            consulted |= idx + 1 >= LONG_INDEL;
             const std::string dele = deletion_bases(seq, seq_len, idx + 1);
             if (!dele.empty()) { ref = r0 + dele; alt = r0; have = true; }
         } else if (flags[F_ACGT_DEL]) {
@@ -249,6 +258,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
             fam.alive[F_ACGT_DEL][idx] = false;
             const int length = idx / 4 + 1;
             const char base = "ACGT"[idx % 4];
+            consulted |= length >= LONG_INDEL;
             const std::string dele = deletion_bases(seq, seq_len, length);
             if (!dele.empty()) {
                 ref = r0 + dele; alt = r0;
@@ -260,6 +270,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
             fam.alive[F_DELDEL][idx] = false;
             const int i = idx / 15 + 1, jj = idx % 15, j = (jj < i - 1 ? jj : jj + 1) + 1;   // pairs (i, j), j != i, in list order
             const int short_ = i < j ? i : j, long_ = i < j ? j : i;
+            consulted |= long_ >= LONG_INDEL;
             const std::string dele = deletion_bases(seq, seq_len, long_);
             if (!dele.empty()) {
                 const std::string full = r0 + dele;
@@ -271,6 +282,7 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
             fam.alive[F_INSDEL][idx] = false;
             const int i = (idx / 2) / 16 + 1, j = (idx / 2) % 16 + 1;
             const int del_len = idx % 2 == 0 ? j : i, ins_len = idx % 2 == 0 ? i : j;
+            consulted |= ins_len >= LONG_INDEL || del_len >= LONG_INDEL;
             const std::string ins = insertion_bases(x, ins_len), dele = deletion_bases(seq, seq_len, del_len);
             if (!ins.empty() && !dele.empty()) { ref = r0 + dele; alt = r0 + "," + r0 + ins + ref.substr(1); have = true; }
         }
@@ -346,12 +358,13 @@ int decode_one(const float *x, const float *g, const float *z, const float *l1, 
 
 }  // namespace
 
-extern "C" int clair_host_decode_rows(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
-                                      const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
-                                      int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
-                                      int64_t *out_len, int *n_rows) {
+extern "C" int clair_host_decode_rows_ex(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
+                                         const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
+                                         int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
+                                         int64_t *out_len, int *n_rows, uint8_t *status) {
     if (!x || !gt21 || !genotype || !len1 || !len2 || !meta || !meta_tok || !out || !out_len || !n_rows || n < 0)
         return clair_host_fail("clair_host_decode_rows: bad arguments");
+    if (status) memset(status, 0, (size_t)n);
     Config cfg{show_reference, haploid_precision, haploid_sensitive, qual_threshold >= 0, qual_threshold, arith_numpy2};
     // candidates are independent: contiguous ranges per thread, rows concatenated in input order
     const int nthreads = clair_host_threads(n);
@@ -374,10 +387,12 @@ extern "C" int clair_host_decode_rows(const float *x, const float *gt21, const f
                 if (endp == ptxt.c_str() || *endp) { clair_host_fail("candidate %d: position %s is not an integer", i, ptxt.c_str()); rc = -1; }
                 else {
                     const size_t before = buf.size();
+                    bool consulted = false;
                     rc = decode_one(x + (size_t)i * CLAIR_HOST_VALUES, gt21 + (size_t)i * 21, genotype + (size_t)i * 3, len1 + (size_t)i * 33,
-                                    len2 + (size_t)i * 33, ctg, tk[1], position, seq, tk[5], cfg, fam, buf);
+                                    len2 + (size_t)i * 33, ctg, tk[1], position, seq, tk[5], cfg, fam, buf, consulted);
                     if (rc == 1) { buf.push_back('\n'); ++part_rows[(size_t)t]; }
                     else buf.resize(before);
+                    if (status && rc >= 0) status[i] = (uint8_t)((rc == 1 ? 1 : 0) | (consulted ? 2 : 0));
                 }
             }
             if (rc < 0) { errs[(size_t)t] = clair_host_last_error(); err_at[(size_t)t] = i; return; }   // thread-local message -> caller
@@ -399,4 +414,12 @@ extern "C" int clair_host_decode_rows(const float *x, const float *gt21, const f
     *out_len = (int64_t)buf.size();
     *n_rows = rows;
     return 0;
+}
+
+extern "C" int clair_host_decode_rows(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
+                                      const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
+                                      int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
+                                      int64_t *out_len, int *n_rows) {
+    return clair_host_decode_rows_ex(x, gt21, genotype, len1, len2, meta, meta_tok, n, show_reference, haploid_precision, haploid_sensitive,
+                                     qual_threshold, arith_numpy2, out, out_cap, out_len, n_rows, nullptr);
 }

@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define CLAIR_HOST_ABI_VERSION 2
+#define CLAIR_HOST_ABI_VERSION 3
 #define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
 
 int clair_host_abi_version(void);
@@ -50,6 +50,15 @@ int clair_host_decode_rows(const float *x, const float *gt21, const float *genot
                            const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
                            int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
                            int64_t *out_len, int *n_rows);
+/* The same with a per-candidate status byte (status[n], may be NULL): bit 0 = the candidate produced a row, bit 1 = its
+ * resolution passed a point where the reference consults the BAM when it has one (an indel of 16 bases or more,
+ * call_var.py:498-524, 540-565; the second allele of an Ins/Ins call, :805-823).  A caller that holds a BAM decodes exactly the
+ * candidates with bit 1 on its own look-up path and splices their rows in (clair_amd/call_var.py: VariantDecoder.decode_batch);
+ * for every other candidate the BAM cannot change the row. */
+int clair_host_decode_rows_ex(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
+                              const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
+                              int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
+                              int64_t *out_len, int *n_rows, uint8_t *status);
 
 /* -- pileup: alignments -> [33][8][4] count windows, the work of dataPrepScripts/CreateTensor.py:179-394 (OutputAlnTensor) and
  *    :29-65 (generate_tensor) as a streaming builder.  The caller supplies what the reference obtains from its sub-processes:

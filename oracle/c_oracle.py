@@ -33,6 +33,35 @@ def lib():
     return _LIB
 
 
+_PORT = None
+
+
+def port_lib():
+    global _PORT
+    if _PORT is None:
+        path = os.path.join(_HERE, "libclair_cpu_port.so")
+        if not os.path.isfile(path):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libclair_cpu_port.so"])
+        _PORT = ctypes.CDLL(path)
+        _PORT.clair_cpu_port_forward.restype = ctypes.c_int
+    return _PORT
+
+
+def port_forward(w, x, threads=0):
+    """The blocked CPU port (clair_cpu_port.c): same interface as forward(), float32 only, no intermediates."""
+    L = port_lib()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[0]
+    keep = [np.ascontiguousarray(w[k], dtype=np.float32) for k in TENSOR_ORDER]
+    ptrs = (ctypes.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+    outs = [np.empty((n, m), dtype=np.float32) for m in (21, 3, 33, 33)]
+    rc = L.clair_cpu_port_forward(ptrs, ctypes.c_void_p(x.ctypes.data), ctypes.c_int(n),
+                                  *[ctypes.c_void_p(o.ctypes.data) for o in outs], ctypes.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("clair_cpu_port_forward failed (rc=%d)" % rc)
+    return outs
+
+
 def max_threads():
     return int(lib().clair_oracle_max_threads())
 

@@ -185,3 +185,102 @@ def test_argparse_surface():
                      "--pysam_for_all_indel_bases --haploid_precision --haploid_sensitive --input_probabilities "
                      "--output_for_ensemble".split())
     assert a.qual == 7 and a.threads == 3 and a.parallel_level == 0 and a.workers == 2
+
+
+# ---- BAM look-ups (call_var.py:102-170, 498-524, 540-565, 805-823) against rows the reference wrote with the same fake pysam ----
+@pytest.fixture
+def fake_pysam(monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_pysam as fp
+    monkeypatch.setitem(sys.modules, "pysam", fp)
+    return fp
+
+
+def _pysam_case():
+    z = np.load(os.path.join(GOLD, "pysam_cases.npz"))
+    x = z["x"].astype(np.float32)
+    infos = json.loads(str(z["infos"]))
+    P = z["probs"]
+    with gzip.open(os.path.join(GOLD, "pysam_rows.json.gz"), "rt") as f:
+        rows = json.load(f)
+    return x, infos, [P[:, 0:21], P[:, 21:24], P[:, 24:57], P[:, 57:90]], rows
+
+
+@pytest.mark.parametrize("native", [False, True])
+@pytest.mark.parametrize("mode", ["default", "pysam_all"])
+def test_bam_lookups_match_reference_rows_minted_with_the_same_fake_pysam(fake_pysam, native, mode):
+    x, infos, Y, rows = _pysam_case()
+    lookup = cvar.AlignmentLookup(os.path.join(GOLD, "pysam_bam.json"), os.path.join(GOLD, "pysam_ref.json"))
+    assert lookup.sam is not None and lookup.fasta is not None
+    dec = cvar.VariantDecoder(cvar.OutputConfig(False, False, False, False, False, None), lookup,
+                              always_use_bam=(mode == "pysam_all"), arith="numpy2", native=native)
+    got = dec.decode_batch(x, infos, Y)
+    want = [ln for r in rows[mode] for ln in r]
+    assert got == want
+    assert sum(1 for ln in want if max(len(a) for a in (ln.split("\t")[3] + "," + ln.split("\t")[4]).split(",")) > 16) > 50
+    if native and mode == "default":
+        # only the candidates that pass a look-up point went through pysam: far fewer pile-ups than candidates
+        assert 0 < lookup.sam.queries < len(infos)
+    lookup.close()
+    assert lookup.sam.closed and lookup.fasta.closed
+
+
+def test_native_decoder_flags_exactly_the_candidates_a_bam_can_change(fake_pysam):
+    from clair_amd import _hostapi
+    x, infos, Y, rows = _pysam_case()
+    no_bam = cvar.VariantDecoder(cvar.OutputConfig(False, False, False, False, False, None), arith="numpy2", native=False)
+    with_bam = cvar.VariantDecoder(cvar.OutputConfig(False, False, False, False, False, None),
+                                   cvar.AlignmentLookup(os.path.join(GOLD, "pysam_bam.json"), os.path.join(GOLD, "pysam_ref.json")),
+                                   arith="numpy2", native=False)
+    _, status = _hostapi.decode_rows(x, infos, Y, False, False, False, None, True, with_status=True)
+    changed = 0
+    for i in range(len(infos)):
+        a = no_bam.decode_batch_py(x[i:i + 1], infos[i:i + 1], [y[i:i + 1] for y in Y])
+        b = with_bam.decode_batch_py(x[i:i + 1], infos[i:i + 1], [y[i:i + 1] for y in Y])
+        if a != b:
+            changed += 1
+            assert status[i] & 2, "candidate %d: the BAM changes its row but the native decoder did not flag it" % i
+        assert bool(status[i] & 1) == bool(a)
+    assert changed > 20 and int((status & 2).astype(bool).sum()) < len(infos)
+
+
+def test_a_failing_stage_on_a_helper_thread_fails_call_variants():
+    """call_variants runs the batch source and the decode on helper threads: a sys.exit / exception raised there (a failing
+    `samtools view` inside callVarBam's generator, a malformed record, a decode error) must surface in the caller instead of
+    reading as end of input (the reference checks its stages' exit codes, clair/callVarBam.py:218-233)."""
+    import sys
+    import types
+
+    class Sink(object):
+        rows = 0
+
+        def write_header(self):
+            pass
+
+        def write_rows(self, rows):
+            self.rows += len(rows)
+
+    class Model(object):
+        def predict(self, x):
+            return [np.full((len(x), k), 1.0 / k, np.float32) for k in (21, 3, 33, 33)]
+
+    def failing_source():
+        yield np.zeros((2, 33, 8, 4), np.float32), [["c", "1", "A" * 33], ["c", "2", "A" * 33]]
+        sys.exit("[ERROR] `samtools view` failed")
+
+    dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
+    with pytest.raises(SystemExit) as ei:
+        cvar.call_variants(types.SimpleNamespace(tensor_fn=None), Model(), dec, Sink(), 2, generator=failing_source())
+    assert "samtools view" in str(ei.value)
+
+    class BadDecoder(object):
+        def decode_batch(self, *a):
+            raise ValueError("decode blew up")
+
+    def two_batches():
+        for _ in range(2):
+            yield np.zeros((2, 33, 8, 4), np.float32), [["c", "1", "A" * 33], ["c", "2", "A" * 33]]
+
+    with pytest.raises(ValueError):
+        cvar.call_variants(types.SimpleNamespace(tensor_fn=None), Model(), BadDecoder(), Sink(), 2, generator=two_batches())

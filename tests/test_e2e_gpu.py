@@ -1,0 +1,128 @@
+"""Widened rows on the MI355X: the single-process BAM -> VCF driver, the binary tensor
+records and the BAM look-up path, each through the HIP forward pass, compared with the text pipeline over the same inputs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+FAKE_SAMTOOLS = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
+
+
+def _bam_case(tmp, seed=91, **kw):
+    import pileup_synth
+    case = pileup_synth.synth_case(seed=seed, **kw)
+    fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\nchrOther\t120\t3100\t120\t121\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"])
+    return case, fa, sam
+
+
+def _model(tmp):
+    from clair_amd import weights
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    return weights.save_weights(os.path.join(tmp, "model"), w)[:-4]
+
+
+def _run(argv, **kw):
+    r = subprocess.run([sys.executable, "-m"] + argv, cwd=ROOT, capture_output=True, text=True, **kw)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r
+
+
+def _rows(path):
+    return [ln for ln in open(path).read().splitlines() if not ln.startswith("#")]
+
+
+@pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
+def test_callVarBam_vcf_equals_the_three_stage_text_pipeline(tmp_path, region):
+    """clair_amd.callVarBam (one process, arrays handed between the stages, int16 counts to the GPU) writes byte for byte the VCF of
+    extract_variant_candidates | create_tensor | call_var over their text interfaces (clair/callVarBam.py:185-201)."""
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp)
+    ck = _model(tmp)
+    common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS] + region
+    one = os.path.join(tmp, "one.vcf")
+    _run(["clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", one, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64"] + common)
+    r1 = _run(["clair_amd.extract_variant_candidates", "--threshold", "0.15", "--minCoverage", "5"] + common)
+    tensors = os.path.join(tmp, "t.gz")
+    _run(["clair_amd.create_tensor", "--tensor_fn", tensors] + common, input=r1.stdout)
+    three = os.path.join(tmp, "three.vcf")
+    _run(["clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors, "--call_fn", three, "--batch_size", "64", "--ref_fn", fa])
+    assert len(_rows(three)) > 20
+    assert open(one).read() == open(three).read()
+
+
+def test_binary_tensor_records_give_the_same_vcf_as_text_records(tmp_path):
+    """create_tensor --binary -> call_var (counts go to the GPU as int16, clair_submit_counts) == the text records' VCF."""
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp, seed=303)
+    ck = _model(tmp)
+    common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS]
+    outs = {}
+    for tag, extra in (("text", []), ("binary", ["--binary"])):
+        tensors = os.path.join(tmp, "t_%s.gz" % tag)
+        _run(["clair_amd.create_tensor", "--tensor_fn", tensors] + common + extra, input=case["candidates"])
+        outs[tag] = os.path.join(tmp, "o_%s.vcf" % tag)
+        _run(["clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors, "--call_fn", outs[tag], "--batch_size", "50", "--showRef"])
+    assert len(_rows(outs["text"])) > 50
+    assert open(outs["text"]).read() == open(outs["binary"]).read()
+
+
+def test_failing_upstream_stage_fails_the_run(tmp_path):
+    """A `samtools view` that dies in the middle of the pileup stage must fail callVarBam (the reference checks its stages' exit
+    codes, clair/callVarBam.py:218-233) instead of ending the VCF early with status 0."""
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp)
+    ck = _model(tmp)
+    flaky = os.path.join(tmp, "flaky_samtools.py")
+    marker = os.path.join(tmp, "views")
+    open(flaky, "w").write(
+        "import os, subprocess, sys\n"
+        "if sys.argv[1] == 'view':\n"
+        "    n = int(open(%r).read()) if os.path.exists(%r) else 0\n"
+        "    open(%r, 'w').write(str(n + 1))\n"
+        "    if n >= 1:\n"                                   # the first view feeds the candidate finder, the second the pileup
+        "        out = subprocess.run([sys.executable, %r] + sys.argv[1:], capture_output=True).stdout\n"
+        "        sys.stdout.buffer.write(out[:len(out) // 2]); sys.stdout.flush(); sys.exit(3)\n"
+        "sys.exit(subprocess.run([sys.executable, %r] + sys.argv[1:]).returncode)\n"
+        % (marker, marker, marker, os.path.join(HERE, "fake_samtools.py"), os.path.join(HERE, "fake_samtools.py")))
+    out = os.path.join(tmp, "o.vcf")
+    r = subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", out, "--bam_fn", sam, "--ref_fn", fa,
+                        "--ctgName", case["ctg"], "--samtools", "%s %s" % (sys.executable, flaky), "--batch_size", "64"],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0, "callVarBam returned 0 although samtools view failed: %s" % r.stderr[-500:]
+
+
+def test_call_var_with_bam_lookups_through_fake_pysam(tmp_path):
+    """call_var --bam_fn / --ref_fn with a pysam in place: candidates that pass a look-up point are decoded on the BAM path, the
+    rest natively; rows of candidates the BAM cannot change are identical to the run without --bam_fn."""
+    tmp = str(tmp_path)
+    from clair_amd import synth
+    ck = _model(tmp)
+    raw, infos = synth.synthetic_candidates(300, "ont", seed=123)
+    tensors = os.path.join(tmp, "t.txt")
+    open(tensors, "w").write("".join(ln + "\n" for ln in synth.tensor_records(raw, infos)))
+    env = dict(os.environ, PYTHONPATH=HERE + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    shim = os.path.join(tmp, "pysam.py")
+    open(shim, "w").write("from fake_pysam import *  # noqa\n")
+    env["PYTHONPATH"] = tmp + os.pathsep + env["PYTHONPATH"]
+    import shutil
+    bam, fa = os.path.join(tmp, "reads.bam.json"), os.path.join(tmp, "ref.fa.json")
+    shutil.copy(os.path.join(HERE, "golden", "pysam_bam.json"), bam)
+    shutil.copy(os.path.join(HERE, "golden", "pysam_ref.json"), fa)
+    open(fa + ".fai", "w").write("chr20\t60000\t7\t60\t61\n")          # the VCF header reads the contig lines from it
+    a, b = os.path.join(tmp, "a.vcf"), os.path.join(tmp, "b.vcf")
+    base = ["clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", tensors, "--batch_size", "128", "--showRef"]
+    _run(base + ["--call_fn", a])
+    _run(base + ["--call_fn", b, "--bam_fn", bam, "--ref_fn", fa], env=env)
+    ra, rb = _rows(a), _rows(b)
+    assert len(ra) == len(rb) > 100
+    same = sum(x == y for x, y in zip(ra, rb))
+    assert same >= len(ra) * 0.8          # the fake BAM has no reads at these positions: only look-up fall-backs may differ

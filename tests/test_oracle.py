@@ -129,3 +129,19 @@ def test_l3_flat_layout_is_u_times_256_plus_c():
     w2["l4_kernel"] = k4
     _, inter2 = model_np.forward(w2, x, keep_intermediates=True)
     assert np.allclose(inter2["l4"][:, 5], model_np.selu(inter["l3"][:, u, c]), atol=1e-7)
+
+
+@pytest.mark.parametrize("n,platform", [(1, "ont"), (47, "ont"), (48, "illumina"), (100, "pacbio_ccs")])
+def test_blocked_cpu_port_matches_the_checker(n, platform):
+    """oracle/clair_cpu_port.c (bench.py's timed CPU baseline: 48-candidate blocks, register-tiled GEMMs, polynomial exp) against
+    the checker, ragged last block included; same tolerance as the HIP path."""
+    from clair_amd import synth, weights
+    from oracle import c_oracle
+    w = weights.synthetic_weights(seed=11, head_gain=4.0, lstm_bias_scale=0.1)
+    x, _ = synth.synthetic_input(n, platform, seed=50 + n)
+    want = c_oracle.forward(w, x)
+    got = c_oracle.port_forward(w, x, threads=2)
+    for g, t in zip(got, want):
+        assert g.shape == t.shape and np.isfinite(g).all()
+        assert np.abs(g - t).max() <= 1e-5
+        assert np.abs(g.sum(axis=1) - 1).max() < 1e-5
