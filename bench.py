@@ -121,6 +121,9 @@ def cpu_baseline(w, x, seconds):
             if dt >= budget:
                 return done / dt, done, dt
 
+    per_call = 96 * cores                     # two 48-candidate blocks per thread and call
+    if x.shape[0] < per_call:
+        x = np.concatenate([x] * ((per_call + x.shape[0] - 1) // x.shape[0]))[:per_call]
     rate_all, n_all, dt_all = timed(0, seconds, x.shape[0])
     rate_4, n_4, dt_4 = timed(4, min(seconds, 5.0), min(x.shape[0], 1536))
     return {"value": round(rate_all, 1), "unit": "candidates/s", "cores": cores, "kind": "port",

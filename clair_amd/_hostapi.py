@@ -6,7 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
-SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_parse_tensors",
+SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_crc32c", "clair_host_parse_tensors",
            "clair_host_decode_rows", "clair_host_decode_rows_ex",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
@@ -25,6 +25,8 @@ def load():
         vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         lib.clair_host_abi_version.restype = i32
         lib.clair_host_last_error.restype = ctypes.c_char_p
+        lib.clair_host_crc32c.restype = ctypes.c_uint32
+        lib.clair_host_crc32c.argtypes = [ctypes.c_char_p, i64]
         lib.clair_host_parse_tensors.argtypes = [vp, i64, i32, i32, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(i32),
                                                  ctypes.POINTER(i64)]
         lib.clair_host_decode_rows.argtypes = [vp, vp, vp, vp, vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64,
@@ -57,6 +59,11 @@ def load():
                                % lib.clair_host_abi_version())
         _lib = lib
     return _lib
+
+
+def crc32c(data):
+    """CRC32C (Castagnoli) of a bytes object."""
+    return int(load().clair_host_crc32c(data, len(data)))
 
 
 def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):

@@ -207,3 +207,33 @@ int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_ro
 }
 
 }  // extern "C"
+
+// CRC32C (Castagnoli, reflected polynomial 0x82F63B78) of a byte range, slicing-by-8: what the TensorFlow bundle format
+// protects its index blocks and tensor data with (clair_amd/tf_bundle.py masks it the LevelDB way).  Known answer:
+// "123456789" -> 0xE3069283.
+extern "C" uint32_t clair_host_crc32c(const uint8_t *data, int64_t n) {
+    static uint32_t table[8][256];
+    static bool ready = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        return true;
+    }();
+    (void)ready;
+    uint32_t crc = 0xFFFFFFFFu;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, data + i, 4);
+        memcpy(&hi, data + i + 4, 4);
+        lo ^= crc;
+        crc = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+              table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    }
+    for (; i < n; ++i) crc = table[0][(crc ^ data[i]) & 0xFF] ^ (crc >> 8);
+    return crc ^ 0xFFFFFFFFu;
+}

@@ -4,11 +4,17 @@ The reference saves/restores its weights with ``tf.train.Saver`` (/root/referenc
 1016-1020); a checkpoint is ``prefix.index`` + ``prefix.data-00000-of-00001`` (README.md:231,
 clair/callVarBam.py:72 checks ``prefix.meta``).  The published Clair models (README.md:94-110) are
 only downloadable, so this reader cannot be tested against a real file here: the format below is the
-published one (LevelDB table + BundleEntryProto), exercised by a round trip through the writer in
-tests/test_weights.py, and the variable names come from clair_amd/weights.py:tf_variable_names().
+published one (LevelDB table + BundleEntryProto).  It is exercised (tests/test_weights.py) by a round trip through
+the writer below AND by a small bundle assembled byte by byte from the format description by an independent script
+(tools/make_tf_bundle_fixture.py -> tests/golden/tf_bundle_small.*: snappy-compressed and plain blocks, block and
+tensor CRCs, prefix-compressed keys over several restart points, optimizer slots and non-float variables to skip,
+a variable saved as /part_N pieces).  The variable names come from clair_amd/weights.py:tf_variable_names() and are
+[TF-recall]: when a real checkpoint names them differently, load_checkpoint lists what the file holds and a JSON
+override (prefix + ".names.json" or $CLAIR_AMD_TF_NAMES) maps expected -> actual names without touching code.
 
-.index   LevelDB SSTable, uncompressed blocks: key "" -> BundleHeaderProto, key <variable name> ->
-         BundleEntryProto {1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: crc32c}
+.index   LevelDB SSTable; blocks plain (type 0) or snappy (type 1), each followed by type byte + masked CRC32C:
+         key "" -> BundleHeaderProto, key <variable name> ->
+         BundleEntryProto {1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: crc32c (masked)}
 .data-*  raw little-endian tensor bytes at [offset, offset+size)
 """
 import os
@@ -19,6 +25,7 @@ import numpy as np
 
 TABLE_MAGIC = 0xdb4775248b80fb57
 DT_FLOAT = 1
+VERIFY_TENSOR_CRC_BELOW = 1 << 26      # tensors up to 64 MiB have their CRC32C checked on load (pure-Python CRC: ~10 MB/s)
 
 
 # ---- varint / protobuf helpers ---------------------------------------------------------------
@@ -87,6 +94,10 @@ def _parse_entry(buf):
             entry["offset"] = val
         elif num == 5:
             entry["size"] = val
+        elif num == 6:
+            entry["crc32c"] = val
+        elif num == 7:
+            entry["slices"] = entry.get("slices", 0) + 1
     return entry
 
 
@@ -106,10 +117,58 @@ def _block_entries(block):
         pos += vlen
 
 
+def snappy_decompress(buf):
+    """Raw snappy block format (format_description.txt): varint uncompressed length, then literal / copy elements."""
+    want, pos = _get_varint(buf, 0)
+    out = bytearray()
+    n = len(buf)
+    while pos < n:
+        tag = buf[pos]
+        pos += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(buf[pos:pos + nb], "little")
+                pos += nb
+            ln += 1
+            if pos + ln > n:
+                raise ValueError("snappy: literal runs past the end of the block")
+            out += buf[pos:pos + ln]
+            pos += ln
+            continue
+        if kind == 1:
+            ln, off = ((tag >> 2) & 7) + 4, ((tag >> 5) << 8) | buf[pos]
+            pos += 1
+        elif kind == 2:
+            ln, off = (tag >> 2) + 1, int.from_bytes(buf[pos:pos + 2], "little")
+            pos += 2
+        else:
+            ln, off = (tag >> 2) + 1, int.from_bytes(buf[pos:pos + 4], "little")
+            pos += 4
+        if off == 0 or off > len(out):
+            raise ValueError("snappy: copy offset %d outside the %d bytes produced so far" % (off, len(out)))
+        for _ in range(ln):            # byte by byte: copies may overlap their own output
+            out.append(out[-off])
+    if len(out) != want:
+        raise ValueError("snappy: block decompressed to %d bytes, header says %d" % (len(out), want))
+    return bytes(out)
+
+
 def _read_block(data, offset, size):
-    if data[offset + size] != 0:
-        raise ValueError("compressed table blocks are not supported (TF writes bundle indexes uncompressed)")
-    return data[offset:offset + size]
+    """Block contents at [offset, offset+size): trailer = 1 type byte (0 plain, 1 snappy) + masked CRC32C of contents + type."""
+    if offset + size + 5 > len(data):
+        raise ValueError("table block [%d, +%d) runs past the end of the file" % (offset, size))
+    raw, kind = data[offset:offset + size], data[offset + size]
+    stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+    if stored != _masked_crc(data[offset:offset + size + 1]):
+        raise ValueError("table block at %d: CRC32C mismatch (corrupt index file)" % offset)
+    if kind == 0:
+        return raw
+    if kind == 1:
+        return snappy_decompress(raw)
+    raise ValueError("table block at %d has unknown compression type %d" % (offset, kind))
 
 
 def read_index(path):
@@ -133,8 +192,9 @@ def read_index(path):
     return entries
 
 
-def read_tensors(prefix):
-    """All float32 tensors of a checkpoint prefix -> OrderedDict name -> ndarray."""
+def read_tensors(prefix, verify_crc=True):
+    """All float32 tensors of a checkpoint prefix -> OrderedDict name -> ndarray (optimizer slots and counters included;
+    non-float variables such as global_step are skipped)."""
     entries = read_index(prefix + ".index")
     shards = {}
     out = OrderedDict()
@@ -144,27 +204,94 @@ def read_tensors(prefix):
         if e["shard_id"] not in shards:
             n_shards = 1 + max(x["shard_id"] for x in entries.values())
             shards[e["shard_id"]] = np.memmap("%s.data-%05d-of-%05d" % (prefix, e["shard_id"], n_shards), dtype=np.uint8, mode="r")
-        raw = shards[e["shard_id"]][e["offset"]:e["offset"] + e["size"]]
-        out[name] = np.frombuffer(bytes(raw), dtype="<f4").reshape(e["shape"]).copy()
+        if e.get("slices"):
+            raise ValueError("variable %s is stored as TensorSlice pieces (a partitioned variable saved through SaveSlice); "
+                             "this reader handles whole tensors and /part_N variables only" % name)
+        raw = bytes(shards[e["shard_id"]][e["offset"]:e["offset"] + e["size"]])
+        if len(raw) != e["size"] or e["size"] != 4 * int(np.prod(e["shape"], dtype=np.int64)):
+            raise ValueError("variable %s: %d bytes on disk for shape %s" % (name, len(raw), (e["shape"],)))
+        if e.get("crc32c") and e["size"] <= VERIFY_TENSOR_CRC_BELOW and verify_crc and e["crc32c"] != _masked_crc(raw):
+            raise ValueError("variable %s: CRC32C mismatch (corrupt data file)" % name)
+        out[name] = np.frombuffer(raw, dtype="<f4").reshape(e["shape"]).copy()
+    # a variable created under a partitioner is saved piecewise as <name>/part_0 .. part_k (split along axis 0): join them
+    parts = {}
+    for name in list(out):
+        head, sep, tail = name.rpartition("/part_")
+        if sep and tail.isdigit() and head not in out:
+            parts.setdefault(head, {})[int(tail)] = name
+    for head, pieces in parts.items():
+        if sorted(pieces) == list(range(len(pieces))):
+            out[head] = np.concatenate([out.pop(pieces[i]) for i in range(len(pieces))], axis=0)
     return out
+
+
+def _name_overrides(prefix):
+    """{"rename": {expected: actual}, "rename_prefix": {expected_prefix: actual_prefix}} from prefix.names.json or
+    $CLAIR_AMD_TF_NAMES -- for a checkpoint whose variable names differ from the table in clair_amd/weights.py."""
+    import json
+    path = os.environ.get("CLAIR_AMD_TF_NAMES") or (prefix + ".names.json")
+    if not os.path.isfile(path):
+        return {}, {}, None
+    with open(path) as f:
+        doc = json.load(f)
+    unknown = set(doc) - {"rename", "rename_prefix"}
+    if unknown:
+        raise ValueError("%s: unknown keys %s (expected \"rename\" and / or \"rename_prefix\")" % (path, sorted(unknown)))
+    return dict(doc.get("rename", {})), dict(doc.get("rename_prefix", {})), path
+
+
+def candidate_names(tf_name, rename, rename_prefix):
+    """Names under which `tf_name` may be stored, most specific first: explicit override, prefix override, the table's
+    own name, and for the LSTM variables the same canonical name inside the CudnnLSTM layer's own scope ("cudnn_lstm"),
+    where a GPU-trained graph may have created its saveable [TF-recall]."""
+    out = []
+    if tf_name in rename:
+        out.append(rename[tf_name])
+    for old, new in sorted(rename_prefix.items(), key=lambda kv: -len(kv[0])):
+        if tf_name.startswith(old):
+            out.append(new + tf_name[len(old):])
+    out.append(tf_name)
+    if tf_name.startswith("LSTM"):
+        head, _, tail = tf_name.partition("/")
+        out.append("%s/cudnn_lstm/%s" % (head, tail))
+    seen, uniq = set(), []
+    for n in out:
+        if n not in seen:
+            seen.add(n)
+            uniq.append(n)
+    return uniq
 
 
 def load_checkpoint(prefix):
     """Checkpoint prefix -> weight dict keyed as clair_amd.weights.TENSOR_TABLE."""
     from clair_amd import weights
     tensors = read_tensors(prefix)
+    rename, rename_prefix, override_path = _name_overrides(prefix)
     names = weights.tf_variable_names()
     w = OrderedDict((k, np.zeros(shape, dtype=np.float32)) for k, shape in weights.TENSOR_TABLE.items())
-    seen = set()
+
+    def listing():
+        rows = ["  %s %s" % (n, tuple(a.shape)) for n, a in sorted(tensors.items())
+                if not (n.endswith("/Adam") or n.endswith("/Adam_1"))]
+        more = "" if len(rows) <= 80 else "\n  ... %d more" % (len(rows) - 80)
+        return ("float32 variables in %s (optimizer slots left out):\n%s%s\nTo map names, write %s.names.json "
+                "{\"rename\": {expected: actual}, \"rename_prefix\": {expected_prefix: actual_prefix}} (or point "
+                "$CLAIR_AMD_TF_NAMES at such a file)." % (prefix, "\n".join(rows[:80]), more, prefix))
+
     for tf_name, (key, index) in names.items():
-        if tf_name not in tensors:
-            raise KeyError("variable %s not found in checkpoint %s (has: %s ...)"
-                           % (tf_name, prefix, ", ".join(list(tensors)[:4])))
+        tried = candidate_names(tf_name, rename, rename_prefix)
+        found = next((n for n in tried if n in tensors), None)
+        if found is None:
+            raise KeyError("variable %s not found in checkpoint %s (tried: %s%s)\n%s"
+                           % (tf_name, prefix, ", ".join(tried), "; overrides from " + override_path if override_path else "", listing()))
+        want = w[key].shape if index is None else w[key][index].shape
+        if int(np.prod(tensors[found].shape)) != int(np.prod(want)):
+            raise ValueError("variable %s in checkpoint %s has shape %s, the graph needs %s\n%s"
+                             % (found, prefix, tuple(tensors[found].shape), tuple(want), listing()))
         if index is None:
-            w[key][...] = tensors[tf_name].reshape(w[key].shape)
+            w[key][...] = tensors[found].reshape(want)
         else:
-            w[key][index] = tensors[tf_name].reshape(w[key][index].shape)
-        seen.add(key)
+            w[key][index] = tensors[found].reshape(want)
     weights.check_weights(w)
     return w
 
@@ -175,6 +302,12 @@ _CRC_TABLE = None
 
 def _crc32c(data):
     global _CRC_TABLE
+    if len(data) >= 4096:          # big ranges through the host library when it is built (1 GB/s vs 10 MB/s here)
+        try:
+            from clair_amd import _hostapi
+            return _hostapi.crc32c(bytes(data))
+        except Exception:
+            pass
     if _CRC_TABLE is None:
         tbl = []
         for i in range(256):
@@ -227,7 +360,7 @@ def write_checkpoint(prefix, tensors, entries_per_block=64):
         shape = _shape_proto(a.shape)
         entry = (b"\x08" + _put_varint(DT_FLOAT) + b"\x12" + _put_varint(len(shape)) + shape
                  + b"\x20" + _put_varint(len(blob)) + b"\x28" + _put_varint(len(raw))
-                 + b"\x35" + struct.pack("<I", _masked_crc(raw) if len(raw) < (1 << 16) else 0))
+                 + b"\x35" + struct.pack("<I", _masked_crc(raw)))
         items.append((name.encode(), entry))
         blob += raw
     with open(prefix + ".data-00000-of-00001", "wb") as f:

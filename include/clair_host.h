@@ -22,6 +22,8 @@ const char *clair_host_last_error(void);
 /* worker threads a call over `work_items` lines / candidates uses: CLAIR_HOST_THREADS from the environment, else up to 16
  * hardware threads, one per 128 items (results do not depend on it: rows keep their input order) */
 int clair_host_threads(int work_items);
+/* CRC32C (Castagnoli) of a byte range -- the checksum of TensorFlow's bundle format (clair_amd/tf_bundle.py); "123456789" -> 0xE3069283 */
+uint32_t clair_host_crc32c(const uint8_t *data, int64_t n);
 
 /* -- ingest: the parsing work of clair/utils.py:72-109 (tensor_generator_from) for one chunk of text ---------------
  * Record format (dataPrepScripts/CreateTensor.py:60-65): "ctg pos refseq33 v0 ... v1055", whitespace separated.

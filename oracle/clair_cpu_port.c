@@ -193,15 +193,25 @@ int clair_cpu_port_forward(const float *const *w, const float *x, int n, float *
     if (!fail) {
 #pragma omp parallel
         {
-            float *xb = aligned_alloc(64, sizeof(float) * PB * T * FIN);
-            float *a1 = aligned_alloc(64, sizeof(float) * T * PB * 256);
-            float *a2 = aligned_alloc(64, sizeof(float) * T * PB * 256);
-            float *z = aligned_alloc(64, sizeof(float) * PB * G4);
-            float *h = aligned_alloc(64, sizeof(float) * PB * H), *c = aligned_alloc(64, sizeof(float) * PB * H);
-            float *l3 = aligned_alloc(64, sizeof(float) * PB * L3U * 256);
-            float *t3 = aligned_alloc(64, sizeof(float) * PB * L3P);
-            float *l4 = aligned_alloc(64, sizeof(float) * PB * L4U), *l5 = aligned_alloc(64, sizeof(float) * PB * L5U);
-            float *lg = aligned_alloc(64, sizeof(float) * PB * 48);
+            /* one workspace per OpenMP thread, kept for the life of the process: 5 MB per thread allocated and released on
+             * every call is 1.3 GB of page faults per call on a 256-thread host, all serialised in the kernel */
+            static __thread float *ws = 0;
+            const size_t ws_floats = (size_t)PB * T * FIN + 2 * (size_t)T * PB * 256 + (size_t)PB * G4 + 2 * (size_t)PB * H +
+                                     (size_t)PB * L3U * 256 + (size_t)PB * L3P + (size_t)PB * L4U + (size_t)PB * L5U + (size_t)PB * 48;
+            if (!ws) ws = aligned_alloc(64, (ws_floats * sizeof(float) + 63) / 64 * 64);
+            float *xb = ws, *a1 = 0, *a2 = 0, *z = 0, *h = 0, *c = 0, *l3 = 0, *t3 = 0, *l4 = 0, *l5 = 0, *lg = 0;
+            if (ws) {
+                a1 = xb + (size_t)PB * T * FIN;
+                a2 = a1 + (size_t)T * PB * 256;
+                z = a2 + (size_t)T * PB * 256;
+                h = z + (size_t)PB * G4;
+                c = h + (size_t)PB * H;
+                l3 = c + (size_t)PB * H;
+                t3 = l3 + (size_t)PB * L3U * 256;
+                l4 = t3 + (size_t)PB * L3P;
+                l5 = l4 + (size_t)PB * L4U;
+                lg = l5 + (size_t)PB * L5U;
+            }
             if (!xb || !a1 || !a2 || !z || !h || !c || !l3 || !t3 || !l4 || !l5 || !lg) {
 #pragma omp atomic write
                 fail = 1;
@@ -253,7 +263,6 @@ int clair_cpu_port_forward(const float *const *w, const float *x, int n, float *
                     }
                 }
             }
-            free(xb); free(a1); free(a2); free(z); free(h); free(c); free(l3); free(t3); free(l4); free(l5); free(lg);
         }
     }
     for (int ld = 0; ld < 4; ++ld) { free(P.lstm[ld][0]); free(P.lstm[ld][1]); }

@@ -71,3 +71,105 @@ def test_tf_bundle_rejects_garbage(tmp_path):
     p.write_bytes(b"\x00" * 100)
     with pytest.raises(ValueError):
         tf_bundle.read_index(str(p))
+
+
+# ---- the reader against bytes assembled independently of its own writer (tools/make_tf_bundle_fixture.py) ----
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_crc32c_known_answers():
+    assert tf_bundle._crc32c(b"123456789") == 0xE3069283            # RFC 3720 B.4
+    assert tf_bundle._crc32c(b"\x00" * 32) == 0x8A9136AA
+    big = bytes(range(256)) * 64                                      # >= 4096 bytes: the host-library path
+    table_only = 0xFFFFFFFF
+    tf_bundle._crc32c(b"x")                                           # builds the table
+    for b in big:
+        table_only = tf_bundle._CRC_TABLE[(table_only ^ b) & 0xFF] ^ (table_only >> 8)
+    assert tf_bundle._crc32c(big) == table_only ^ 0xFFFFFFFF
+
+
+def test_reader_on_a_bundle_assembled_from_the_format_description():
+    import json
+    prefix = os.path.join(GOLD, "tf_bundle_small")
+    want = json.load(open(prefix + ".json"))
+    entries = tf_bundle.read_index(prefix + ".index")
+    assert sorted(entries) == sorted(want)
+    for name, e in entries.items():
+        assert e["dtype"] == want[name]["dtype"] and list(e["shape"]) == want[name]["shape"], name
+    tensors = tf_bundle.read_tensors(prefix)
+    assert "global_step" not in tensors                               # DT_INT64
+    assert "emb" in tensors and "emb/part_0" not in tensors           # /part_N pieces joined along axis 0
+    assert tensors["emb"].shape == (5, 5)
+    assert tensors["emb"].ravel().tolist() == want["emb/part_0"]["values"] + want["emb/part_1"]["values"]
+    for name in ("L4/bias", "L4/bias/Adam", "L5_1/kernel", "Prediction/Y_genotype_logits/bias", "Training_Operation/beta1_power"):
+        assert tensors[name].shape == tuple(want[name]["shape"])
+        assert np.array_equal(tensors[name].ravel(), np.array(want[name]["values"], dtype=np.float32)), name
+
+
+def test_reader_detects_corruption(tmp_path):
+    import shutil
+    for suffix in (".index", ".data-00000-of-00001"):
+        shutil.copy(os.path.join(GOLD, "tf_bundle_small" + suffix), str(tmp_path / ("c" + suffix)))
+    idx = bytearray((tmp_path / "c.index").read_bytes())
+    idx[10] ^= 0x40                                                   # inside the first (snappy) block
+    (tmp_path / "bad.index").write_bytes(bytes(idx))
+    with pytest.raises(ValueError, match="CRC32C"):
+        tf_bundle.read_index(str(tmp_path / "bad.index"))
+    data = bytearray((tmp_path / "c.data-00000-of-00001").read_bytes())
+    data[5] ^= 1
+    (tmp_path / "c.data-00000-of-00001").write_bytes(bytes(data))
+    with pytest.raises(ValueError, match="CRC32C"):
+        tf_bundle.read_tensors(str(tmp_path / "c"))
+    assert "L4/bias" in tf_bundle.read_tensors(str(tmp_path / "c"), verify_crc=False)
+
+
+def test_snappy_decoder_rejects_bad_streams():
+    assert tf_bundle.snappy_decompress(b"\x05" + bytes([4 << 2]) + b"hello") == b"hello"
+    assert tf_bundle.snappy_decompress(b"\x0a" + bytes([1 << 2]) + b"ab" + bytes([1 | (4 << 2), 2])) == b"ababababab"   # overlapping copy
+    with pytest.raises(ValueError):
+        tf_bundle.snappy_decompress(b"\x05" + bytes([4 << 2]) + b"hel")
+    with pytest.raises(ValueError):
+        tf_bundle.snappy_decompress(b"\x08" + bytes([1 << 2]) + b"ab" + bytes([1 | (0 << 2), 9]))                       # offset beyond the output
+    with pytest.raises(ValueError):
+        tf_bundle.snappy_decompress(b"\x09" + bytes([4 << 2]) + b"hello")
+
+
+def test_checkpoint_with_other_variable_names_loads_through_fallback_and_override(tmp_path, monkeypatch):
+    """The TF names are recalled, not verified: (1) the LSTM variables are also looked for inside the CudnnLSTM
+    layer's own scope; (2) a JSON file maps expected -> actual names; (3) a miss lists what the checkpoint holds."""
+    import json
+    monkeypatch.delenv("CLAIR_AMD_TF_NAMES", raising=False)
+    w = weights.synthetic_weights(seed=8)
+    tensors = {}
+    for tf_name, (key, index) in weights.tf_variable_names().items():
+        a = w[key] if index is None else w[key][index]
+        if tf_name.startswith("LSTM"):
+            head, _, tail = tf_name.partition("/")
+            tf_name = "%s/cudnn_lstm/%s" % (head, tail)
+        elif tf_name.startswith("L4/"):
+            tf_name = "Dense4/" + tf_name[3:]
+        elif tf_name == "Prediction/Y_genotype_logits/bias":
+            tf_name = "heads/zygosity_b"
+        tensors[tf_name] = a
+        if tf_name.endswith("kernel"):
+            tensors[tf_name + "/Adam"] = np.zeros_like(a)              # optimizer slots ride along
+    prefix = str(tmp_path / "model")
+    tf_bundle.write_checkpoint(prefix, tensors)
+    with pytest.raises(KeyError) as ei:
+        weights.load_weights(prefix)
+    msg = str(ei.value)
+    assert "L4/kernel" in msg and "Dense4/kernel (7680, 192)" in msg and ".names.json" in msg and "/Adam" not in msg.split("float32 variables")[1]
+    json.dump({"rename_prefix": {"L4/": "Dense4/"}, "rename": {"Prediction/Y_genotype_logits/bias": "heads/zygosity_b"}},
+              open(prefix + ".names.json", "w"))
+    r = weights.load_weights(prefix)
+    for k in w:
+        assert np.array_equal(w[k], r[k]), k
+    json.dump({"renamed": {}}, open(prefix + ".names.json", "w"))
+    with pytest.raises(ValueError, match="unknown keys"):
+        weights.load_weights(prefix)
+    # a variable of the wrong size is reported with its shape
+    json.dump({"rename_prefix": {"L4/": "Dense4/"}, "rename": {"Prediction/Y_genotype_logits/bias": "L4/bias"}}, open(prefix + ".names.json", "w"))
+    tensors["L4/bias"] = np.zeros(5, np.float32)
+    tf_bundle.write_checkpoint(prefix, tensors)
+    with pytest.raises(ValueError, match="has shape"):
+        weights.load_weights(prefix)

@@ -1,5 +1,5 @@
 // Stand-alone timing of the LSTM2 projection GEMM (gemm_split.hip.h) on a batch-1024 problem, by workgroup-group count.
-#include "gemm_split.hip.h"
+#include "probed/gemm_split.hip.h"   // frozen round-1 copy with the GEMM_PROBE_* modes
 #include <cstdio>
 #include <vector>
 using namespace clair;

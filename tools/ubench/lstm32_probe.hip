@@ -1,7 +1,7 @@
 // Phase timing of the recurrent kernels (lstm32.hip.h) from inside: s_memtime stamps of workgroup 0 / wave 0
 // at step start, after each of the four blocks, after the exposed gate tail and after the barrier.
 #define L32_PROBE 1
-#include "lstm32.hip.h"
+#include "probed/lstm32.hip.h"   // frozen round-1 copy of the recurrent kernels WITH the probe build modes (production headers carry none)
 #include <cstdio>
 #include <vector>
 using namespace clair;

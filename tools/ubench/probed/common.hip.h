@@ -1,0 +1,90 @@
+// Shared device helpers for the Clair forward-pass kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace clair {
+
+constexpr int T_POS = 33;      // positions (shared/param.py:9 -> 2*16+1)
+constexpr int F_IN = 32;       // features per position (8 rows x 4 channels)
+constexpr int HID = 128;       // LSTM units per direction (clair/model.py:92-93)
+constexpr int GATES = 512;     // 4*HID, column order i | c~ | f | o
+constexpr int L3_UNITS = 30;   // clair/model.py:81
+constexpr int L3_OUT = 7680;   // 30*256, flat index u*256+c (clair/model.py:474-478)
+constexpr int L4_UNITS = 192;  // clair/model.py:82
+constexpr int L5_UNITS = 96;   // clair/model.py:84-91
+constexpr int OUT_FLOATS = 90; // 21 + 3 + 33 + 33
+constexpr int L4_SPLITS = 16;  // split-K factor of the 7680->192 GEMM
+
+// exp via v_exp_f32 (2^x); relative error ~1 ulp, enough for the 2e-6 probability tolerance.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sigmoid / tanh as the LSTMBlockCell gate non-linearities (TF 1.13 lstm_ops; reached from
+// clair/model.py:301).  Both saturate cleanly: exp -> inf gives rcp -> 0.
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
+
+// clair/selu.py:26-30 : scale * where(x >= 0, x, alpha * elu(x))
+// elu needs expm1, not exp - 1: near 0 the subtraction leaves 6e-8 ABSOLUTE, i.e. 1e-5 relative on an activation of
+// 0.01 -- visible as 1e-5 on the probabilities once a layer with small outputs feeds one with large weights
+// (tools/parity_sweep.py, cell "L4 kernel x0.01").  On (-0.25, 0] the degree-7 Taylor polynomial is exact to 5e-8
+// relative; below, exp - 1 is (<= 2e-7 relative).
+__device__ __forceinline__ float selu_f(float x) {
+    constexpr float alpha = 1.6732632423543772848170429916717f;
+    constexpr float scale = 1.0507009873554804934193349852946f;
+    float p = fmaf(x, 1.0f / 5040.0f, 1.0f / 720.0f);
+    p = fmaf(p, x, 1.0f / 120.0f);
+    p = fmaf(p, x, 1.0f / 24.0f);
+    p = fmaf(p, x, 1.0f / 6.0f);
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    const float em1 = x > -0.25f ? p * x : fast_exp(x) - 1.0f;
+    return scale * (x >= 0.0f ? x : alpha * em1);
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- 2-way fp16 split of fp32 values (gemm_split.hip.h, lstm32.hip.h, dense.hip.h) ------------------------------------
+// x ~= x1 + x2 with x1 = fp16(x), x2 = fp16(x - x1): 22 significand bits (relative error <= 2^-22, absolute
+// error <= 3e-8 once x2 falls into the fp16 subnormal range), round-to-nearest-even both times.  Products of
+// two fp16 values are exact in fp32, so  a*b ~= a1*b1 + a1*b2 + a2*b1  on v_mfma_f32_16x16x32_f16 (16x the
+// rate of the fp32 MFMA) reproduces the fp32 product to ~3e-7 relative: end to end the probabilities stay as
+// close to a float64 evaluation as with fp32 MFMAs (4.6e-7..8e-7 vs 3.5e-7..4.6e-7, tools/split_emulation.py).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // one MFMA A/B operand (4 VGPRs)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)x;
+    // ONE definition of hi.  Under hipcc's default -ffp-contract=fast the compiler may otherwise materialise hi twice --
+    // once as v_cvt_f16_f32 of the rounded fp32 value, once fused with the producing multiply (v_fma_mixlo_f16, single
+    // rounding) -- and the two disagree by one fp16 ulp about once in 30 000 values: the stored hi plane and the
+    // residual then belong to different splits (found as 1e-5 instead of 2e-6 error on L4, tools/debug_taps.py).
+    asm("" : "+v"(hi));
+    lo = (_Float16)(x - (float)hi);
+}
+
+__device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
+    // v_mfma_f32_16x16x32_f16: lane (i = l&15, q = l>>4) supplies A[i][8q..8q+7] / B[8q..8q+7][i]; C/D as mfma16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).
+// Inline asm on purpose: hipcc then neither counts it nor fences later ds_reads of the same __shared__
+// array behind it with vmcnt(0).  M0 carries the LDS base and is compiler-reserved, so it is
+// saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const f32x4 *gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+}  // namespace clair

@@ -23,7 +23,7 @@
 // so an activation slab is fetched from HBM once per XCD and served to the other seven from that XCD's L2.
 #pragma once
 #include "common.hip.h"
-#include "lstm32.hip.h"
+#include "lstm32.hip.h"   // resolves to the sibling probed copy
 
 namespace clair {
 
@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
+#ifdef GEMM_PROBE_NOSTORE   // tools/ubench/gemm_split_probe.hip only
+                    if (acc[mi][ni][4 * a] == 12345.678f)
+#endif
                     __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)(dst + a * 256));
             }
         }

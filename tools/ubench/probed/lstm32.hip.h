@@ -48,6 +48,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace clair {
 
+#ifndef L32_PROBE_GATES
+#define L32_PROBE_GATES 1   // 0 only in tools/ubench/lstm32_probe.hip variants: hidden gate math left out
+#endif
+#ifndef L32_PROBE_ZQ
+#define L32_PROBE_ZQ 1
+#endif
+#ifndef L32_PROBE_COPY
+#define L32_PROBE_COPY 1
+#endif
+#ifdef L32_PROBE_TWOTILE
+#define L32_TWOTILE_PROBE 1
+#else
+#define L32_TWOTILE_PROBE 0
+#endif
+#ifdef L32_PROBE   // tools/ubench/lstm32_probe.hip only: s_memtime stamps of workgroup 0, wave 0
+__device__ long long *l32_stamps;   // [33 steps][16]
+#ifdef L32_PROBE_NOSTAMP   // launch time and the first / last stamp only (for the -DL32_PROBE_* ablations)
+#define L32_STAMP(i) if ((i) == 0 && s == 0 && blockIdx.x == 0 && tid == 0) l32_stamps[0] = __builtin_readcyclecounter(); \
+                     if ((i) == 6 && s == T_POS - 1 && blockIdx.x == 0 && tid == 0) l32_stamps[1] = __builtin_readcyclecounter();
+#else
+#define L32_STAMP(i) if (blockIdx.x == 0 && tid == 0) l32_stamps[s * 16 + (i)] = __builtin_readcyclecounter();
+#endif
+#else
+#define L32_STAMP(i)
+#endif
+
 constexpr int L32_TILE = 32;      // candidates per workgroup
 // Layer 1's input is raw pileup counts (0..250 by CreateTensor's depth cap, 32767 at the int16 boundary) against weights
 // of ~0.1 and below: the fp16 low plane of such a weight is subnormal (3e-8 ABSOLUTE, common.hip.h), and 250 x 3e-8 per term
@@ -89,7 +115,11 @@ __device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
 //   * accumulator chains (D of one MFMA = C of the next) need no wait states;
 //   * the first reader of a finished accumulator is kept 12 wait states away by construction (see the step).
 __device__ __forceinline__ void mfma32_av(f32x16 &acc, const f16x8 &w, const f16x8 &b) {
+#ifndef L32_PROBE_NO_MFMA
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));
+#else
+    asm volatile("" : "+v"(acc) : "a"(w), "v"(b));
+#endif
 }
 __device__ __forceinline__ void mfma32_av_first(f32x16 &acc, const f16x8 &w, const f16x8 &b, const f32x16 &c) {   // D = A.B + C, D != C
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(w), "v"(b), "v"(c));
@@ -199,7 +229,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         } else {
             const int sc = s < T_POS ? s : T_POS - 1;   // the prefetch past the last step re-reads the last one
+#ifdef L32_PROBE_SAMEPAGE
+            const int t = 0 * sc;
+#else
             const int t = d ? T_POS - 1 - sc : sc;
+#endif
             const float *src = zx0 + ((size_t)t * 16 + b) * 1024;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -293,8 +327,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // below the MFMA that closes it.  (Pinning inputs as well costs an s_nop per op: hipcc pads every asm output
     // that the next VALU touches.)
 #define L32_PIN(x) asm volatile("" : "+v"(x));
+#ifdef L32_PROBE_NOTRANS   // tools/ubench ablation: full-rate stand-ins for v_exp_f32 / v_rcp_f32 (results are garbage)
+#define L32_EXP2(x) ((x) * 1.0001f + 0.5f)
+#define L32_RCP(x) ((x) * 0.999f + 0.25f)
+#else
 #define L32_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define L32_RCP(x) fast_rcp(x)
+#endif
 #define L32_OP_E(R, C, e) { R[e] = L32_EXP2(Z[4 * (e) + (C)]); L32_PIN(R[e]) }
 #define L32_OP_A(R, e) { R[e] += 1.0f; L32_PIN(R[e]) }
 #define L32_OP_R(R, e) { R[e] = L32_RCP(R[e]); L32_PIN(R[e]) }
@@ -347,11 +386,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), and in block 0 the copy-out of h_{s-1}.
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
-    if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
-    if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                                     \
+    if ((B) == 0 && (M) % 3 == 0) { L32_STAMP(8 + (M) / 3) }                                                      \
+    if (!FIRST && (M) == 3 && L32_PROBE_ZQ) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
+    if ((L32_PROBE_GATES || (M) == 23) && (B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                  \
     if (!FIRST && (M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */ \
     if (FIRST && (B) > 0 && (M) == 8) load_seed(xacc[(B) - 1], 0, (B) - 1);   /* the gates above read their accumulators in gaps 1-7: block B-1's restarts from its bias */ \
-    if ((B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
+    if (L32_PROBE_COPY && (B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
         if ((M) >= 12 && (M) < 20 && ((M) & 1) == 0) copy_write(s_prev, ((M) - 12) >> 1);                          \
@@ -361,6 +401,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if ((M) == 23) stage_x(s + 2);                                                                            \
     }                                                                                                             \
     if (FIRST && (B) == 1 && (M) == 0) xreg = load_x(s + 3);                                                      \
+    if (L32_TWOTILE_PROBE && (B) == 3 && (M) % 3 == 2) {   /* probe: next fragments into the slot just used for the last time */ \
+        hf[(M) / 3][0] = *(const f16x8 *)&hbuf[s & 1][0][cand][((M) / 3) * 16 + hq * 8];                           \
+        hf[(M) / 3][1] = *(const f16x8 *)&hbuf[s & 1][1][cand][((M) / 3) * 16 + hq * 8];                           \
+    }                                                                                                             \
     if (FIRST && (B) == 3) {   /* operands of the x-part that follows block 3: x_{s+1} fragments, Wx1 fragments of blocks 0 and 1 */ \
         if ((M) == 12) read_xfrag(s + 1);                                                                         \
         if ((M) == 14) load_wx(wxa[0], 0);                                                                        \
@@ -379,6 +423,7 @@ _Pragma("unroll")                                                               
                 else mfma32_av(L32_ACC(b), Aw[b][kk][term == 0 ? 1 : 0], hf[kk][term == 1 ? 1 : 0]);             \
                 L32_AFTER_MFMA(m, NM, b)                                                                         \
             }                                                                                                    \
+            L32_STAMP(1 + b)                                                                                     \
     }
 
     // Layer 1: the x-part of the NEXT step (K = 32 = two k-steps per block, 24 MFMAs; Wx1 fragments from LDS) does not depend on
@@ -390,7 +435,7 @@ _Pragma("unroll")                                                               
         const int xb = q / 6, kk = (q % 6) / 3, term = q % 3;                                                     \
         mfma32_vv(xacc[xb], wxa[xb & 1][kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);                     \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if ((GATES) && q >= 1) L32_GAP(q, 3)                                                                      \
+        if ((GATES) && (L32_PROBE_GATES || q == 23) && q >= 1) L32_GAP(q, 3)                                                   \
         if ((GATES) && q == 8) load_seed(xacc[3], 0, 3);                                                          \
         if (q == 5) load_wx(wxa[0], 2);                                                                           \
         if (q == 11) load_wx(wxa[1], 3);                                                                          \
@@ -406,6 +451,10 @@ _Pragma("unroll")                                                               
     };
     unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
     float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
+    if (!L32_PROBE_GATES) {   // ablation builds only (tools/ubench): gap 23 still packs and stores
+        hp[0] = hp[1] = lp[0] = lp[1] = 0;
+        tt[0] = tt[1] = tt[2] = tt[3] = 0.f;
+    }
     if (FIRST) {   // bias + x-part of step 0
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_seed(xacc[b], 0, b);
@@ -420,20 +469,41 @@ _Pragma("unroll")                                                               
         __syncthreads();   // step 0 re-stages the tile just read
     }
 
+#ifdef L32_PROBE_TWOTILE   // tools/ubench only: what a step would cost in a two-tile workgroup (timing only, results are wrong):
+                            // h fragments replaced in place inside block 3, the step barrier in mid-stream after block 0, the last
+                            // block's gates left out (they would hide under the other tile's block 0)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[1][pl][cand][kk * 16 + hq * 8];
+#endif
     for (int s = 0; s < T_POS; ++s) {
+        L32_STAMP(0)
+#ifndef L32_PROBE_TWOTILE
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
+#endif
+        L32_STAMP(7)
         const int s_prev = s > 0 ? s - 1 : 0;
         // x-part first (layer 1: K = 32 = two k-steps, Wx1 fragments from LDS), then the h-part (K = 128 = eight k-steps);
         // terms per k-step: w_lo.h_hi, w_hi.h_lo, w_hi.h_hi.  The C operand of a block's first MFMA (D != C there) is kept alive
         // two MFMAs longer by L32_AFTER_MFMA: hipcc knows nothing about the asm MFMA still reading it and would hand the
         // registers to the next VALU result.
         L32_BLOCK(0)
+#ifdef L32_PROBE_TWOTILE
+        __syncthreads();
+#endif
         L32_BLOCK(1)
         L32_BLOCK(2)
         L32_BLOCK(3)
+#ifdef L32_PROBE_TWOTILE
+        {
+#pragma unroll
+            for (int g = 23; g <= 23; ++g) L32_GAP(g, 3)
+        }
+#else
         if (FIRST) {
             L32_XTAIL(1)
         } else {
@@ -441,9 +511,14 @@ _Pragma("unroll")                                                               
             asm volatile("s_nop 11" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 1; g <= 23; ++g) L32_GAP(g, 3)
+            for (int g = L32_PROBE_GATES ? 1 : 23; g <= 23; ++g) L32_GAP(g, 3)
         }
+#endif
+        L32_STAMP(5)
+#ifndef L32_PROBE_TWOTILE
         __syncthreads();
+#endif
+        L32_STAMP(6)
     }
 #undef L32_BLOCK
 #undef L32_XTAIL
