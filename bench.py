@@ -109,7 +109,8 @@ def cpu_baseline(w, x, seconds):
     port = getattr(c_oracle, "port_forward", None)
     fwd = port if port is not None else c_oracle.forward
     what = "oracle/clair_cpu_port.c (blocked: 48 candidates per GEMM block)" if port is not None else "oracle/clair_oracle.c"
-    cores = c_oracle.max_threads()
+    host_threads = c_oracle.max_threads()
+    cores = c_oracle.usable_threads()          # capped by the cgroup CPU quota: more OpenMP threads than that only get throttled
 
     def timed(threads, budget, n):
         fwd(w, x[:min(96, x.shape[0])], threads=threads)          # warm-up (library load, thread pool)
@@ -124,10 +125,11 @@ def cpu_baseline(w, x, seconds):
     per_call = 96 * cores                     # two 48-candidate blocks per thread and call
     if x.shape[0] < per_call:
         x = np.concatenate([x] * ((per_call + x.shape[0] - 1) // x.shape[0]))[:per_call]
-    rate_all, n_all, dt_all = timed(0, seconds, x.shape[0])
+    rate_all, n_all, dt_all = timed(cores, seconds, x.shape[0])
     rate_4, n_4, dt_4 = timed(4, min(seconds, 5.0), min(x.shape[0], 1536))
     return {"value": round(rate_all, 1), "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": "%d candidates of the same synthetic batches, %s, OpenMP over %d threads, %.1f s" % (n_all, what, cores, dt_all),
+            "sample": "%d candidates of the same synthetic batches, %s, OpenMP over %d threads (host: %d hardware threads, cgroup CPU "
+                      "quota: %d), %.1f s" % (n_all, what, cores, host_threads, cores, dt_all),
             "value_4_threads": round(rate_4, 1),
             "sample_4_threads": "%d candidates, 4 OpenMP threads (the reference's default --threads), %.1f s" % (n_4, dt_4)}
 

@@ -87,4 +87,12 @@ __device__ __forceinline__ void glds16(const f32x4 *gsrc, unsigned lds_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: a persistent kernel keeps its lane
+// offsets in registers for its whole life and only re-bases (scalar arithmetic) from piece to piece.
+__device__ __forceinline__ void glds16_s(unsigned lane_off, const void *sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_base) : "memory");
+}
+
 }  // namespace clair

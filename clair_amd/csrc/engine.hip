@@ -61,7 +61,7 @@ struct clair_engine {
     int max_pad = 0;
     bool weights_ready = false;
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
-    int proj2_groups = 4;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 8 gate tiles x groups workgroups (see clair_engine_create)
+    int proj2_groups = 8;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 4 gate tiles x groups workgroups (see clair_engine_create)
     int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
@@ -230,10 +230,10 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split; weight-stationary persistent workgroups
         KernelTimer kt(e, s, CLAIR_K_PROJ2);
-        const int x_tiles = (m_rows + 127) / 128;
+        const int x_tiles = (m_rows + GS_ROWS - 1) / GS_ROWS;
         const int groups = std::min(e->proj2_groups, (x_tiles + 7) / 8);
         GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows, groups};
-        hipLaunchKernelGGL(gemm_split_kernel, dim3(64 * groups), dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL(gemm_split_kernel, dim3(32 * groups), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
@@ -292,11 +292,11 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     e->max_batch = max_batch;
     e->max_pad = (max_batch + 31) & ~31;
     { const char *t = getenv("CLAIR_AMD_TAP_L3"); e->tap_l3 = t && t[0] == '1'; }
-    // A handle with one slot runs its kernels alone: the projection GEMM takes every CU (8 XCDs x 8 gate tiles x 4 groups).  With
+    // A handle with one slot runs its kernels alone: the projection GEMM takes every CU (8 XCDs x 4 gate tiles x 8 groups).  With
     // batches in flight on several slots the 64-workgroup recurrent kernels of the other slots hold whole CUs for ~80 us; a
-    // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Two groups (128
+    // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Four groups (128
     // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
-    e->proj2_groups = n_slots > 1 ? 2 : 4;
+    e->proj2_groups = n_slots > 1 ? 4 : 8;
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
@@ -602,10 +602,10 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
     if (!workgroups) return fail(e, "workgroups is NULL");
     if (n < 1 || n > e->max_batch) return fail(e, "n %d out of range [1,%d]", n, e->max_batch);
     const int n_pad = (n + 31) & ~31, ntiles = n_pad / 32;
-    const int x_tiles = (T_POS * n_pad + 127) / 128;
+    const int x_tiles = (T_POS * n_pad + GS_ROWS - 1) / GS_ROWS;
     for (int k = 0; k < CLAIR_K_COUNT; ++k) workgroups[k] = 0;
     workgroups[CLAIR_K_LSTM1] = workgroups[CLAIR_K_LSTM2] = ntiles * 2;
-    workgroups[CLAIR_K_PROJ2] = 64 * std::min(e->proj2_groups, (x_tiles + 7) / 8);
+    workgroups[CLAIR_K_PROJ2] = 32 * std::min(e->proj2_groups, (x_tiles + 7) / 8);
     workgroups[CLAIR_K_L4] = (n_pad / L34_CAND) * L4_SPLITS;
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
     return 0;

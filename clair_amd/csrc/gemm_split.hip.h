@@ -11,16 +11,15 @@
 //
 // Weight-stationary, persistent.  K is only 256, so the whole K extent of a wave's 64 gate rows (both fp16
 // planes: 64 KiB) fits the 256 accumulation VGPRs of a one-wave-per-SIMD kernel -- the same trick as the
-// recurrent kernels.  A workgroup (2x2 waves of 64 gate rows x 64 activation rows) therefore loads its 128-row
-// weight tile ONCE and then walks over activation tiles; per 32-wide k-slab only the activation tile (two
-// planes, 16 KiB) goes through LDS, double-buffered, one barrier per slab, register-prefetched two slabs ahead
-// across tile boundaries.  Compared with the tile-per-workgroup version this halves the LDS traffic and the
-// staging instructions per MFMA, removes the weight re-reads (270 MB of L2 traffic per launch) and the
-// per-workgroup launch / first-tile latency (profiles/r01_microbench.txt, gemm_split_probe).
+// recurrent kernels.  A workgroup is four waves with FOUR DIFFERENT 64-row weight slices (256 gate rows) that all
+// multiply the SAME 64-row activation tile.  The activation tile streams through a four-deep LDS ring of 64-wide
+// k-phases (16 KiB each) by LDS-DMA, issued THREE phases (144 MFMAs, ~2 us) ahead: with several batches in flight a
+// load takes microseconds to come back, and the round-1 kernel (registers two 24-MFMA slabs ahead, then ds_write)
+// stalled on it at every slab (73 % matrix-pipe utilisation in its main loop).  One barrier per phase of 48 MFMAs.
 //
-// Workgroup -> work.  id & 7 = XCD (hardware round-robin); on an XCD, local id l = id >> 3: gate tile l & 7, group
-// l >> 3.  The eight workgroups of a group walk the SAME activation tiles (x_tile = xcd + 8 * (group + groups * j)),
-// so an activation slab is fetched from HBM once per XCD and served to the other seven from that XCD's L2.
+// Workgroup -> work.  id & 7 = XCD (hardware round-robin); on an XCD, local id l = id >> 3: gate tile l & 3 (256 rows),
+// group l >> 2.  The four workgroups of a group walk the SAME activation tiles (x_tile = xcd + 8 * (group + groups * j)),
+// so an activation tile is fetched from HBM once per XCD and served to the other three from that XCD's L2.
 #pragma once
 #include "common.hip.h"
 #include "lstm32.hip.h"
@@ -31,43 +30,49 @@ typedef unsigned short f16bits_t;   // raw fp16 storage
 
 struct GemmSplitArgs {
     const f16bits_t *X3;    // [2][33*n_pad][256]  fp16 planes of a1 (rows in (t, n) order)
-    const f16bits_t *W3;    // [8 gate tiles][2 wm][2 mi][16 kk][2 planes][64 lanes][8]  A fragments of the gate-scaled Wx2^T:
-                            // gate row R = gtile*128 + wm*64 + mi*32 + lane%32, k = 16*kk + 8*(lane/32) + j;
+    const f16bits_t *W3;    // [16 slices of 64 gate rows][2 mi][16 kk][2 planes][64 lanes][8]  A fragments of the gate-scaled Wx2^T:
+                            // gate row R = slice*64 + mi*32 + lane%32, k = 16*kk + 8*(lane/32) + j;
                             // R = ((d*4 + w)*4 + b)*32 + 8a + 4h' + c  <->  column d*512 + c*128 + 32w + 8b + 4h' + a
     const float *bias;      // [1024] gate-scaled, in gate-row order
     float *C;               // zx in lstm32_kernel's layout: [2 dir][n_pad/32][33][4 wave][4 b][4 a][64 lane][4 c]
     int n_pad;
     int ntiles;             // n_pad / 32
     int m_rows;             // 33 * n_pad
-    int groups;             // workgroup groups per XCD (grid = 64 * groups)
+    int groups;             // workgroup groups per XCD (grid = 32 * groups)
 };
 
-// LDS image of one activation slab plane: 128 rows x 32 fp16 = 64 B per row, four 16-byte chunks per row.  The
+constexpr int GS_ROWS = 64;                       // activation rows per tile
+constexpr int GS_PLANE = GS_ROWS * 32;            // fp16 units of one plane of one 32-wide k-slab
+constexpr int GS_PHASE = 2 * 2 * GS_PLANE;        // one phase = two slabs x two planes = 16 KiB
+
+// LDS image of one activation slab plane: 64 rows x 32 fp16 = 64 B per row, four 16-byte chunks per row.  The
 // fragment read of the 32x32x16 MFMA is ds_read_b128 of row l%32, chunk 2*kk + l/32; the hardware serves it in the
 // lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) (MI355X_MICROARCH.md, LDS): XOR-ing the chunk with
 // (row >> 3) & 3 puts the 16 rows of every group on 16 different 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 3) & 3)) << 3); }   // in fp16 units
 
+constexpr int GS_RING = 4;                        // phases resident in LDS
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_split_kernel(GemmSplitArgs p) {
-    __shared__ __attribute__((aligned(16))) f16bits_t Xs[2][2 * 128 * 32];   // [buffer][plane][row][k]
+    __shared__ __attribute__((aligned(16))) f16bits_t Xs[GS_RING][GS_PHASE];   // [ring slot][slab][plane][row][k]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     const int l32 = lane & 31, lh = lane >> 5;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int gtile = local & 7, group = local >> 3;
-    const int x_tiles = (p.m_rows + 127) >> 7;
+    const int gtile = local & 3, group = local >> 2;
+    const int x_tiles = (p.m_rows + GS_ROWS - 1) / GS_ROWS;
     const int x_step = 8 * p.groups;
     const int x_first = xcd + 8 * group;
     if (x_first >= x_tiles) return;
     const int n_my = (x_tiles - x_first + x_step - 1) / x_step;   // activation tiles of this workgroup
+    const int slice = gtile * 4 + wave;                           // this wave's 64 gate rows
 
     // resident weights: Wr[mi][kk][plane]
     f16x8 Wr[2][16][2];
     {
-        const f16x8 *wp = (const f16x8 *)p.W3 + ((size_t)(gtile * 2 + wm) * (2 * 16 * 2 * 64)) + lane;
+        const f16x8 *wp = (const f16x8 *)p.W3 + ((size_t)slice * (2 * 16 * 2 * 64)) + lane;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -85,57 +90,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) bq[mi][a] = *(const f32x4 *)(p.bias + gtile * 128 + wm * 64 + mi * 32 + 8 * a + 4 * lh);
+        for (int a = 0; a < 4; ++a) bq[mi][a] = *(const f32x4 *)(p.bias + slice * 64 + mi * 32 + 8 * a + 4 * lh);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) asm volatile("" : "+v"(bq[mi][a]));   // hipcc waits for its own loads HERE, not after the DMA prologue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on this kernel counts its vector-memory operations itself
 
-    // staging map of a slab (2 planes x 128 rows x 4 chunks = 1024 chunks of 16 B): chunk f = tid + 256*j -> plane f>>9,
-    // row (f>>2)&127, chunk f&3; slab q = 8*tile_index + ks.  Rows past m_rows of a ragged last tile are read as they
-    // come (the a1 workspace carries 128 rows of slack) -- their accumulator blocks are never stored.
-    const size_t x_plane = (size_t)p.m_rows * 256;
-    int lds_dst[4];
-    const f16bits_t *g_src[4];
+    // Staging.  A phase is 2 slabs x 2 planes x 64 rows x 64 B = 16 one-KiB DMA pieces; wave w moves the four pieces of
+    // plane-slab w (slab w>>1, plane w&1): piece j = rows 16j .. 16j+15, lane l -> LDS row 16j + l/4, 16-byte slot l%4, which
+    // holds chunk (l%4) ^ ((row>>3)&3) of that row (split_lds_off).  Per-lane byte offsets are fixed for the kernel's life; the
+    // base is wave-uniform scalar arithmetic.  Rows past m_rows of a ragged last tile are read as they come (the a1 workspace
+    // carries slack rows) -- their accumulator blocks are never stored.
+    const int my_slab = wave >> 1, my_plane = wave & 1;
+    unsigned lane_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int f = tid + 256 * j, pl = f >> 9, r = (f >> 2) & 127, c = f & 3;
-        lds_dst[j] = pl * (128 * 32) + split_lds_off(r, c);
-        g_src[j] = p.X3 + pl * x_plane + (size_t)r * 256 + c * 8;
+        const int row = 16 * j + (lane >> 2), c = (lane & 3) ^ ((row >> 3) & 3);
+        lane_off[j] = (unsigned)(row * 512 + c * 16);
     }
-    const int n_slabs = n_my * 8;
-    auto slab_off = [&](int q) -> size_t {   // wave-uniform offset of slab q from the staging pointers
-        const int qq = q < n_slabs ? q : n_slabs - 1;   // the prefetch past the end re-reads the last slab
-        return ((size_t)(x_first + (qq >> 3) * x_step) * 128 * 256) + (qq & 7) * 32;
+    const f16bits_t *my_base = p.X3 + (size_t)my_plane * p.m_rows * 256 + my_slab * 32;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)&Xs[0][0]) + (unsigned)(wave * GS_PLANE * 2);
+    const int n_phases = n_my * 4;
+    auto phase_base = [&](int P) -> const f16bits_t * {
+        const int q = P < n_phases ? P : n_phases - 1;   // the prefetch past the end re-reads the last phase
+        return my_base + ((size_t)(x_first + (q >> 2) * x_step) * GS_ROWS * 256) + (q & 3) * 64;
     };
-    auto gload = [&](f32x4 (&r)[4], int q) {
-        const size_t off = slab_off(q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = *(const f32x4 *)(g_src[j] + off);
-    };
-    auto lstore = [&](const f32x4 (&r)[4], int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *(f32x4 *)&Xs[buf][lds_dst[j]] = r[j];
-    };
-    // B fragments of a whole slab: [kk][plane][activation block]
-    auto fread = [&](f16x8 (&xf)[2][2][2], int buf) {
+    auto dma = [&](int P, int j) { glds16_s(lane_off[j], phase_base(P), lds0 + (unsigned)((P & (GS_RING - 1)) * GS_PHASE * 2 + j * 1024)); };
+    // B fragments of one slab: [kk][plane][activation block]
+    auto fread = [&](f16x8 (&xf)[2][2][2], int slot, int sl) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    xf[kk][pl][ni] = *(const f16x8 *)&Xs[buf][pl * (128 * 32) + split_lds_off(wn * 64 + ni * 32 + l32, 2 * kk + lh)];
+                    xf[kk][pl][ni] = *(const f16x8 *)&Xs[slot][(sl * 2 + pl) * GS_PLANE + split_lds_off(ni * 32 + l32, 2 * kk + lh)];
     };
 
-    // Pipeline state at the top of slab q: LDS[q&1] = slab q and LDS[(q+1)&1] = slab q+1 visible, xa/xb = fragments of slab q
-    // (xa for even q), register set ra/rb = slabs q+2, q+3 in flight (ra holds even slabs).
-    f32x4 ra[4], rb[4];
+    // Pipeline state at the top of phase P: ring slot P&3 = phase P visible to every wave, phases P+1 and P+2 in flight,
+    // xa = fragments of phase P's first slab.
     f16x8 xa[2][2][2], xb[2][2][2];
-    gload(ra, 0);
-    gload(rb, 1);
-    lstore(ra, 0);
-    gload(ra, 2);
-    lstore(rb, 1);
-    gload(rb, 3);
+#pragma unroll
+    for (int P = 0; P < 3; ++P)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma(P, j);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __syncthreads();
-    fread(xa, 0);
+    fread(xa, 0, 0);
 
     f32x16 acc[2][2];   // [gate block mi][activation block ni]
     for (int it = 0; it < n_my; ++it) {
@@ -152,42 +154,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
         asm volatile("s_nop 1" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            // next slab's fragments first: their LDS latency hides behind this slab's 24 MFMAs
-            if (ks & 1) fread(xa, 0); else fread(xb, 1);
-            // 24 MFMAs: three product terms per k-step, small ones first; the four blocks alternate so consecutive MFMAs never
-            // chain.  The staging traffic rides in their shadows, one instruction per MFMA: slab q+2 -> the LDS buffer slab q
-            // has just left (every wave read it before the previous barrier), then slab q+4 -> the freed registers.
+        for (int ph = 0; ph < 4; ++ph) {
+            const int P = it * 4 + ph;
+            // ---- first slab of the phase; its partner's fragments first (LDS latency hides behind these 24 MFMAs)
+            fread(xb, ph, 1);
 #pragma unroll
             for (int m = 0; m < 24; ++m) {
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
-                mfma32_av(acc[mi][ni], Wr[mi][ks * 2 + kk][term == 0 ? 1 : 0],
-                          (ks & 1) ? xb[kk][term == 1 ? 1 : 0][ni] : xa[kk][term == 1 ? 1 : 0][ni]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (m >= 2 && m < 10 && (m & 1) == 0) {
-                    const int j = (m - 2) >> 1;
-                    if (ks & 1) *(f32x4 *)&Xs[1][lds_dst[j]] = rb[j]; else *(f32x4 *)&Xs[0][lds_dst[j]] = ra[j];
-                }
-                if (m >= 10 && m < 18 && (m & 1) == 0) {
-                    const int j = (m - 10) >> 1;
-                    if (ks & 1) rb[j] = *(const f32x4 *)(g_src[j] + slab_off(it * 8 + ks + 4));
-                    else ra[j] = *(const f32x4 *)(g_src[j] + slab_off(it * 8 + ks + 4));
-                }
+                // three product terms per k-step, small ones first; the four blocks alternate so consecutive MFMAs never chain
+                mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + kk][term == 0 ? 1 : 0], xa[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // Phase P+1 must have landed (this wave's four pieces; the barrier covers the other waves').  Vector-memory operations
+            // retire in issue order, so "at most N outstanding" with N = what was issued after those pieces: phase P+2's four, plus
+            // the sixteen stores of the previous tile's epilogue when it lies in between (first two phases of every tile but the first).
+            if (it > 0 && ph < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
+            // ---- second slab: the next phase's first fragments, then phase P+3 into the slot phase P-1 has left
+            fread(xa, (ph + 1) & 3, 0);
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
+                mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + 2 + kk][term == 0 ? 1 : 0], xb[kk][term == 1 ? 1 : 0][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m >= 4 && m < 12 && (m & 1) == 0) dma(P + 3, (m - 4) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // epilogue: each accumulator block is four contiguous 1 KiB pieces of the recurrent kernel's layout
-        // (12 wait states between the last MFMA and the first read of its result)
+        // (12 wait states between the last MFMA and the first read of its result).  Exactly sixteen stores per wave and tile
+        // (the vmcnt arithmetic above counts them); only the last tile of the whole launch can be ragged, and nothing waits after it.
         asm volatile("s_nop 11" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const int xblk = xt * 4 + wn * 2 + ni;      // = t * ntiles + tile
+            const int xblk = xt * 2 + ni;      // = t * ntiles + tile
             if (xblk * 32 >= p.m_rows) continue;
             const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
-                const int gblk = gtile * 4 + wm * 2 + mi;  // = (d*4 + w)*4 + b
+                const int gblk = slice * 2 + mi;  // = (d*4 + w)*4 + b
                 const int d = gblk >> 4, wb = gblk & 15;
                 float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4;
 #pragma unroll
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end still target this workgroup's LDS
 }
 
 }  // namespace clair

@@ -62,6 +62,30 @@ def port_forward(w, x, threads=0):
     return outs
 
 
+def usable_threads():
+    """Hardware threads this process may actually keep busy: the host's count capped by the cgroup CPU quota (cpu.max:
+    the GPU boxes expose 256 hardware threads under a quota of 16 CPUs -- 256 OpenMP threads then spend their time throttled)."""
+    n = max_threads()
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // p))
+        except (OSError, ValueError):
+            pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return n
+
+
 def max_threads():
     return int(lib().clair_oracle_max_threads())
 
