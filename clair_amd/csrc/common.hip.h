@@ -30,20 +30,20 @@ __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * fast_rcp
 // clair/selu.py:26-30 : scale * where(x >= 0, x, alpha * elu(x))
 // elu needs expm1, not exp - 1: near 0 the subtraction leaves 6e-8 ABSOLUTE, i.e. 1e-5 relative on an activation of
 // 0.01 -- visible as 1e-5 on the probabilities once a layer with small outputs feeds one with large weights
-// (tools/parity_sweep.py, cell "L4 kernel x0.01").  On (-0.25, 0] the degree-7 Taylor polynomial is exact to 5e-8
-// relative; below, exp - 1 is (<= 2e-7 relative).
-__device__ __forceinline__ float selu_f(float x) {
+// (tools/parity_sweep.py, cell "L4 kernel x0.01").  On (-0.125, 0] the degree-6 Taylor polynomial is exact to 9e-8
+// relative; below, exp - 1 is (<= 5e-7 relative).
+__device__ __forceinline__ float selu_scaled(float x, float k) {   // k * selu(x); k folds a following power-of-two activation scale
     constexpr float alpha = 1.6732632423543772848170429916717f;
     constexpr float scale = 1.0507009873554804934193349852946f;
-    float p = fmaf(x, 1.0f / 5040.0f, 1.0f / 720.0f);
-    p = fmaf(p, x, 1.0f / 120.0f);
+    float p = fmaf(x, 1.0f / 720.0f, 1.0f / 120.0f);
     p = fmaf(p, x, 1.0f / 24.0f);
     p = fmaf(p, x, 1.0f / 6.0f);
     p = fmaf(p, x, 0.5f);
     p = fmaf(p, x, 1.0f);
-    const float em1 = x > -0.25f ? p * x : fast_exp(x) - 1.0f;
-    return scale * (x >= 0.0f ? x : alpha * em1);
+    const float em1 = x > -0.125f ? p * x : fast_exp(x) - 1.0f;
+    return x >= 0.0f ? x * (scale * k) : em1 * (alpha * scale * k);
 }
+__device__ __forceinline__ float selu_f(float x) { return selu_scaled(x, 1.0f); }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
@@ -68,6 +68,21 @@ __device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo) {
     // residual then belong to different splits (found as 1e-5 instead of 2e-6 error on L4, tools/debug_taps.py).
     asm("" : "+v"(hi));
     lo = (_Float16)(x - (float)hi);
+}
+
+// The same split for four values at once, as packed pairs ready for an 8-byte LDS store: v_cvt_pk_f16_f32 rounds two values per
+// instruction (round to nearest even, like the scalar conversion), v_fma_mix_f32 forms x - float(hi) with the fp16 operand
+// converted on the fly (exact), a second packed conversion rounds the residuals: 8 instructions instead of ~20.
+__device__ __forceinline__ void split2_pk4(const float (&x)[4], uint2 &hi, uint2 &lo) {
+    float r[4];
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi.x) : "v"(x[0]), "v"(x[1]));
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi.y) : "v"(x[2]), "v"(x[3]));
+    asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r[0]) : "v"(x[0]), "v"(hi.x));
+    asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[1]) : "v"(x[1]), "v"(hi.x));
+    asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r[2]) : "v"(x[2]), "v"(hi.y));
+    asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[3]) : "v"(x[3]), "v"(hi.y));
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo.x) : "v"(r[0]), "v"(r[1]));
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo.y) : "v"(r[2]), "v"(r[3]));
 }
 
 __device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {

@@ -16,6 +16,10 @@ namespace clair {
 constexpr int L34_CAND = 32;
 constexpr int L34_ROW = 30 * 16 + 8;    // fp16 units per candidate row of one l3 plane: 976 B, 16-B aligned, rows 52 banks apart
 constexpr int L34_LDS_BYTES = 33 * 32 * 16 * 4;   // the a2 staging tile (67 584 B) is the larger of the buffer's two lives
+// l3 is multiplied by 2^4 before its 2-way fp16 split and the L4 reduction by 2^-4 (folded into TailArgs::l4_scale): a selu output
+// of 0.01 would otherwise have a subnormal low plane (3e-8 absolute = 3e-6 relative); 2^4 keeps 22 bits down to |y| ~ 0.008 and
+// overflows only beyond |y| = 4 094.
+constexpr float L34_ACT_SCALE = 16.0f;
 
 struct L3L4Args {
     const float *a2;    // [33][n_pad][256]
@@ -114,16 +118,13 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        f16x4 hi, lo;
+                        float y[4];
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                            _Float16 a, b;
-                            split2(selu_f(acc3[cc][mb][nbk][r] + bias[cc]), a, b);
-                            hi[cc] = a;
-                            lo[cc] = b;
-                        }
-                        *(f16x4 *)&l3h[0][mb * 16 + lq * 4 + r][u * 16 + w * 4] = hi;
-                        *(f16x4 *)&l3h[1][mb * 16 + lq * 4 + r][u * 16 + w * 4] = lo;
+                        for (int cc = 0; cc < 4; ++cc) y[cc] = selu_scaled(acc3[cc][mb][nbk][r] + bias[cc], L34_ACT_SCALE);
+                        uint2 hi, lo;
+                        split2_pk4(y, hi, lo);
+                        *(uint2 *)&l3h[0][mb * 16 + lq * 4 + r][u * 16 + w * 4] = hi;
+                        *(uint2 *)&l3h[1][mb * 16 + lq * 4 + r][u * 16 + w * 4] = lo;
                     }
             }
         }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
     if (p.dbg) {   // debug tap: this workgroup's 32 x (30 u x 16 channels) slice of l3
         for (int f = tid; f < L34_CAND * 480; f += 256) {
             const int row = f / 480, k = f - row * 480, u = k >> 4, ch = k & 15;
-            p.dbg[(size_t)(n0 + row) * L3_OUT + u * 256 + cg * 16 + ch] = (float)l3h[0][row][k] + (float)l3h[1][row][k];
+            p.dbg[(size_t)(n0 + row) * L3_OUT + u * 256 + cg * 16 + ch] = ((float)l3h[0][row][k] + (float)l3h[1][row][k]) * (1.0f / L34_ACT_SCALE);
         }
     }
 

@@ -247,7 +247,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
-        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift)};
+        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE};
         hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
@@ -637,7 +637,7 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
     if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);
     HIP_TRY(e, hipMemcpy(host, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     if (which == 3) {   // the partials are sums over the 2^w4_shift-scaled image
-        const float inv = std::ldexp(1.0f, -e->w4_shift);
+        const float inv = std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE;
         for (int64_t i = 0; i < count; ++i) host[i] *= inv;
     }
     return 0;
