@@ -27,7 +27,7 @@ struct L3L4Args {
     const float *b3;    // [256][30]
     const unsigned short *w4s;   // [16 cg][15 ks][12 nb][2 plane][64 lane][8] fp16 split of W4: row u*256 + cg*16 + ch with
                                  // u = 2*ks + (lq>>1), ch = 8*(lq&1) + j; column nb*16 + li
-    float *part;        // [16][n_pad][192]
+    float *part;        // [16 cg][n_pad/32][4 wave][6 mb*3+nb][64 lane][4 r]  split-K partial sums, in the accumulator layout
     int n_pad;
     float *dbg;         // parity tap (NULL in production): l3 as this kernel holds it, hi + lo, [n_pad][7680]
 };
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
 #pragma unroll
             for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma16h(a[mb][0], bq[ks % PF][nb][0], acc[mb][nb]);
     }
+    // split-K partials, fragment-major: [cg][block of 32][wave][mb*3 + nb][lane][4 r] -- a lane's accumulator quad is 16 contiguous
+    // bytes and a wave instruction one contiguous KiB (round 1: 24 dword stores per lane, four 64-byte segments each)
+    const int block = n0 / L34_CAND, nblocks = p.n_pad / L34_CAND;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
-            float *dst = p.part + ((size_t)cg * p.n_pad + n0 + mb * 16 + lq * 4) * L4_UNITS + w * 48 + nb * 16 + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[(size_t)r * L4_UNITS] = acc[mb][nb][r];
-        }
+        for (int nb = 0; nb < 3; ++nb)
+            *(f32x4 *)(p.part + ((((size_t)cg * nblocks + block) * 4 + w) * 6 + mb * 3 + nb) * 256 + lane * 4) = acc[mb][nb];
 }
 
 // ---- tail: L4 split-K reduce + selu, L5_1..4 + selu, heads + selu + softmax ---------------------
@@ -203,7 +203,7 @@ constexpr int L4S_ROW = L4_UNITS + 4;  // padded LDS rows (16 B aligned, conflic
 constexpr int L5S_ROW = L5_UNITS + 4;
 
 struct TailArgs {
-    const float *l4part;  // [L4_SPLITS][n_pad][192]
+    const float *l4part;  // [16 cg][n_pad/32][4 wave][6 mb*3+nb][64 lane][4 r]  (l3l4_kernel above)
     const float *b4;      // [192]
     const float *w5f;     // [4][12][6][64][4]  B fragments of L5_k: W5[k5][lq*48 + k4*4 + j][nb*16 + li]
     const float *b5;      // [4][96]
@@ -224,16 +224,22 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * TAIL_TILE;
 
-    // L4: fixed-order reduction of the split-K partials, bias, selu
-    for (int f = tid; f < TAIL_TILE * (L4_UNITS / 4); f += 256) {
-        const int m = f / (L4_UNITS / 4), j4 = f - m * (L4_UNITS / 4);
-        f32x4 s = *(const f32x4 *)(p.l4part + ((size_t)n0 + m) * L4_UNITS + j4 * 4);
+    // L4: fixed-order reduction of the split-K partials, bias, selu.  A thread takes accumulator quads of the producing kernel's
+    // layout -- 16-byte loads, a wave instruction one contiguous KiB -- i.e. rows 4*lq' .. +3 (r) of column 48w' + 16nb + li':
+    // this tile is half mb of candidate block n0 / 32; 12 (w', nb) pairs x 64 lanes = 768 quads over 256 threads.
+    {
+        const int blk = n0 / 32, mb = (n0 >> 4) & 1, nblocks = p.n_pad / 32;
+        for (int f = tid; f < 12 * 64; f += 256) {
+            const int wn = f >> 6, ln = f & 63, wq = wn / 3, nb = wn - wq * 3;
+            const size_t at = (((size_t)blk * 4 + wq) * 6 + mb * 3 + nb) * 256 + ln * 4;
+            f32x4 s = *(const f32x4 *)(p.l4part + at);
 #pragma unroll
-        for (int sp = 1; sp < L4_SPLITS; ++sp)
-            s += *(const f32x4 *)(p.l4part + ((size_t)sp * p.n_pad + n0 + m) * L4_UNITS + j4 * 4);
-        s = s * p.l4_scale + *(const f32x4 *)(p.b4 + j4 * 4);
-        f32x4 o = {selu_f(s[0]), selu_f(s[1]), selu_f(s[2]), selu_f(s[3])};
-        *(f32x4 *)&l4s[m][j4 * 4] = o;
+            for (int sp = 1; sp < L4_SPLITS; ++sp) s += *(const f32x4 *)(p.l4part + (size_t)sp * nblocks * (4 * 6 * 256) + at);
+            const int col = wq * 48 + nb * 16 + (ln & 15);
+            const float b4 = p.b4[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) l4s[(ln >> 4) * 4 + r][col] = selu_f(s[r] * p.l4_scale + b4);
+        }
     }
     __syncthreads();
 

@@ -631,15 +631,24 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
         case 2: src = s.a2; avail = (int64_t)T_POS * np * 256; break;
         case 4: if (!e->tap_l3) return fail(e, "clair_debug_read: tap 4 needs CLAIR_AMD_TAP_L3=1 at engine creation");
                 src = s.zx; avail = np * L3_OUT; break;
-        case 3: src = s.l4part; avail = (int64_t)L4_SPLITS * np * L4_UNITS; break;   // split-K partials of the 7680->192 product
+        case 3: {   // split-K partials live in the accumulator layout (dense.hip.h): hand them back as [16][n_pad][192] in W4's own units
+            avail = (int64_t)L4_SPLITS * np * L4_UNITS;
+            if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap 3 holds %lld", (long long)count, (long long)avail);
+            std::vector<float> raw((size_t)avail);
+            HIP_TRY(e, hipMemcpy(raw.data(), s.l4part, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const float inv = std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE;
+            const int64_t nblocks = np / 32;
+            for (int64_t i = 0; i < count; ++i) {
+                const int64_t cg = i / (np * L4_UNITS), n = (i / L4_UNITS) % np, col = i % L4_UNITS;
+                const int64_t block = n / 32, row = n % 32, w = col / 48, nb = (col % 48) / 16, li = col % 16, mb = row / 16, lq = (row % 16) / 4, r = row % 4;
+                host[i] = raw[(size_t)(((((cg * nblocks + block) * 4 + w) * 6 + mb * 3 + nb) * 64 + lq * 16 + li) * 4 + r)] * inv;
+            }
+            return 0;
+        }
         default: return fail(e, "clair_debug_read: unknown tap %d", which);
     }
     if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap %d holds %lld", (long long)count, which, (long long)avail);
     HIP_TRY(e, hipMemcpy(host, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
-    if (which == 3) {   // the partials are sums over the 2^w4_shift-scaled image
-        const float inv = std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE;
-        for (int64_t i = 0; i < count; ++i) host[i] *= inv;
-    }
     return 0;
 }
 
