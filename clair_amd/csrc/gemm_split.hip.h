@@ -128,6 +128,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     xf[kk][pl][ni] = *(const f16x8 *)&Xs[slot][(sl * 2 + pl) * GS_PLANE + split_lds_off(ni * 32 + l32, 2 * kk + lh)];
     };
 
+    auto fread1 = [&](f16x8 (&xf)[2][2][2], int slot, int sl, int i) {   // piece i = kk*4 + pl*2 + ni of the same
+        const int kk = i >> 2, pl = (i >> 1) & 1, ni = i & 1;
+        xf[kk][pl][ni] = *(const f16x8 *)&Xs[slot][(sl * 2 + pl) * GS_PLANE + split_lds_off(ni * 32 + l32, 2 * kk + lh)];
+    };
+
     // Pipeline state at the top of phase P: ring slot P&3 = phase P visible to every wave, phases P+1 and P+2 in flight,
     // xa = fragments of phase P's first slab.
     f16x8 xa[2][2][2], xb[2][2][2];
@@ -156,13 +161,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             const int P = it * 4 + ph;
-            // ---- first slab of the phase; its partner's fragments first (LDS latency hides behind these 24 MFMAs)
-            fread(xb, ph, 1);
+            // ---- first slab of the phase; its partner's eight fragments are read one per MFMA shadow (as a burst in front of the
+            //      MFMAs they held the wave's issue for ~130 cycles per slab: 12 % of the kernel, tools/gpu/gemm_ablate.sh)
 #pragma unroll
             for (int m = 0; m < 24; ++m) {
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
                 // three product terms per k-step, small ones first; the four blocks alternate so consecutive MFMAs never chain
                 mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + kk][term == 0 ? 1 : 0], xa[kk][term == 1 ? 1 : 0][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < 8) fread1(xb, ph, 1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // Phase P+1 must have landed (this wave's four pieces; the barrier covers the other waves').  Vector-memory operations
@@ -171,14 +178,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (it > 0 && ph < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
-            // ---- second slab: the next phase's first fragments, then phase P+3 into the slot phase P-1 has left
-            fread(xa, (ph + 1) & 3, 0);
+            // ---- second slab: the next phase's first fragments (one per shadow), then phase P+3 into the slot phase P-1 has left
 #pragma unroll
             for (int m = 0; m < 24; ++m) {
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
                 mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + 2 + kk][term == 0 ? 1 : 0], xb[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (m >= 4 && m < 12 && (m & 1) == 0) dma(P + 3, (m - 4) >> 1);
+                if (m < 8) fread1(xa, (ph + 1) & 3, 0, m);
+                if (m >= 10 && m < 18 && (m & 1) == 0) dma(P + 3, (m - 10) >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -302,3 +302,65 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert d["gt_concordance"]["gt_identical"] is True and d["parity_max_abs_err"] < 1e-5
+
+
+def test_whole_genome_share_of_one_gpu_config3(synth_weights):
+    """BASELINE.json configs[3]: ~5 M ONT candidates over 8 GPUs = 625 k per GPU.  One rank's share through the resident path
+    (clair_run_resident, batch 1024, three batches in flight), checked by properties at full size -- every row a distribution,
+    finite, and (candidates are independent) bit-identical to the same candidates run in other batch positions -- and against
+    the oracle on a 2 048-candidate subsample spread over the whole share."""
+    from clair_amd import _capi
+    from clair_amd import shard
+    total, world, batch = 5000000, 8, 1024
+    first, mine = shard.shard_batches(total, batch, 3, world)
+    assert abs(mine - total // world) < 2 * batch
+    uniq = 16 * batch                                        # distinct synthetic candidates, tiled over the share
+    x, _ = synth.synthetic_input(uniq, "ont", seed=20250928 + 3)
+    eng = _capi.Engine(device=0, max_batch=batch, n_slots=3)
+    try:
+        eng.load_weights(synth_weights)
+        n_batches = (mine + batch - 1) // batch
+        xd, od = eng.dataset_alloc(uniq * 2)                 # second half: the same candidates, rotated by 7 positions
+        try:
+            eng.dataset_upload(xd, 0, x)
+            eng.dataset_upload(xd, uniq, np.roll(x, 7, axis=0))
+            for b in range(n_batches):                       # the share: 611 batches cycling over the 32 resident ones
+                eng.run_resident(b % 3, xd, od, (b % 32) * batch, batch)
+            eng.sync()
+            out = eng.dataset_download(od, 0, uniq * 2)
+        finally:
+            eng.dataset_free(xd, od)
+        assert np.isfinite(out).all()
+        for a, b_ in ((0, 21), (21, 24), (24, 57), (57, 90)):
+            assert np.abs(out[:, a:b_].sum(axis=1) - 1).max() < 1e-5
+        assert np.array_equal(np.roll(out[:uniq], 7, axis=0), out[uniq:]), "outputs depend on the batch position of a candidate"
+        pick = np.linspace(0, uniq - 1, 2048).astype(np.int64)
+        want = _oracle(synth_weights, x[pick])
+        for g, w_ in zip(_capi.split_outputs(out[pick]), want):
+            assert np.abs(g - w_).max() <= PROB_TOL
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("platform", ["ont", "pacbio_ccs", "illumina"])
+def test_gt_concordance_65k_per_platform(synth_weights, platform):
+    """VCF GT concordance at scale (tools/gt_concordance.py runs 200 k per platform; numbers in DESIGN.md): decode of the HIP
+    probabilities vs decode of the float32 oracle's on 65 536 synthetic candidates.  The decode picks arg-max over float32 products
+    with exact-equality tests (clair/call_var.py:733-762), so two float32 evaluations of the same graph may break an exact tie
+    differently: at most 3 such rows per 65 536 are tolerated, and every one of them must be a tie at float32 resolution --
+    |dp| <= 1e-5 on that candidate -- not a numerical failure."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gt_concordance
+    from clair_amd import _capi
+    eng = _capi.Engine(device=0, max_batch=4096, n_slots=1)
+    try:
+        eng.load_weights(synth_weights)
+        r = gt_concordance.concordance(eng, synth_weights, platform, 65536, 777, log=lambda *a: None)
+    finally:
+        eng.close()
+    assert r["vcf_rows"] > 65000 and r["max_abs_dp"] <= PROB_TOL
+    assert r["gt_flips"] <= 3, r["flips"]
+    for f in r["flips"]:
+        assert f["max_abs_dp"] <= PROB_TOL

@@ -1,5 +1,8 @@
-run() { timeout 200 python bench.py --streams $1 2>/dev/null | python -c "
+#!/bin/sh
+# bench.py over slot counts and projection-GEMM launch geometries
+cd "$(dirname "$0")/../.."
+run() { CLAIR_AMD_PROJ2_GROUPS=$1 timeout 200 python bench.py --streams $2 --steps 400 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$2 streams $1', d['value'])"; }
-for g in 1 2; do for st in 3 5 6 7 9; do CLAIR_AMD_PROJ2_GROUPS=$g run $st "groups=$g"; done; done
+print('groups $1 streams $2', d['value'], {k:v['ms_mean'] for k,v in d['kernels_in_flight_ms'].items() if v['ms_mean']})"; }
+for g in 4 5; do for st in 3 4 5 6; do run $g $st; done; done

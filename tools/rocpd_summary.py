@@ -1,15 +1,34 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite result (--kernel-trace --stats) as a text table.
 
-usage: tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--skip-first N] [--phases W,K,I] > profiles/rNN_....txt
-Per kernel: calls, total / mean / min / max duration (us) and share of GPU kernel time;
-VGPR/AGPR/LDS as recorded by the tracer.  --skip-first drops the first N dispatches of each
+usage: tools/rocpd_summary.py gpurun_out/prof/bench_results.db [--skip-first N] [--phases W,K,I] [--resource-usage FILE] > profiles/rNN_....txt
+Per kernel: calls, total / mean / min / max duration (us) and share of GPU kernel time; grid, LDS and the register counts.
+The tracer's own register columns are NOT usable for kernels that pin operands in the accumulation half of the register file:
+rocprofv3 7.2 records arch_vgpr_count as the allocation granule (e.g. 244 for a 226-VGPR kernel) and accum_vgpr_count as 0 even
+when the kernel descriptor reserves 256 AGPRs.  --resource-usage takes the compiler's own -Rpass-analysis=kernel-resource-usage
+output (profiles/rNN_kernel_resource_usage.txt) and prints ITS VGPR / AGPR / SGPR / scratch numbers beside the tracer's.  --skip-first drops the first N dispatches of each
 kernel (warm-up launches) so the means line up with bench.py's timed region.  --phases W,K,I splits each kernel's dispatches the way bench.py issues
-them -- W warm-up launches, K timed steps (batches overlapped on the slots), K instrumented steps, I launches alone on one stream
--- and prints the mean of each phase: the K-step mean is `roofline.overlapped_kernel_ms`, the last-I mean is `roofline.kernel_ms`.
+them -- W warm-up launches, K timed steps (batches in flight on the slots), K steps with HIP events around the dominant kernel only
+(`roofline.kernel_ms` is the dominant kernel's mean there), K steps with events around every kernel, I launches alone on one stream
+(`roofline.alone_kernel_ms`) -- and prints the mean of each phase.
 """
 import sqlite3
 import sys
+
+
+def compiler_resources(path):
+    """mangled kernel name -> (vgprs, agprs, sgprs, scratch, occupancy) from a -Rpass-analysis=kernel-resource-usage log"""
+    import re
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
 
 
 def main():
@@ -31,24 +50,31 @@ def main():
         stats.append((sum(d), name, len(d), sum(d) / len(d), min(d), max(d), g))
     stats.sort(reverse=True)
     print("# source: %s   (durations in microseconds; first %d dispatches per kernel skipped)" % (path, skip))
-    print("%-58s %6s %12s %10s %10s %10s %6s  %s" % ("kernel", "calls", "total_us", "mean_us", "min_us", "max_us", "pct", "grid/wg vgpr+agpr sgpr lds"))
+    print("%-58s %6s %12s %10s %10s %10s %6s  %s" % ("kernel", "calls", "total_us", "mean_us", "min_us", "max_us", "pct", "grid/wg vgpr+agpr(tracer) sgpr lds"))
     for tot, name, n, mean, mn, mx, g in stats:
         short = name if len(name) <= 58 else name[:55] + "..."
         print("%-58s %6d %12.1f %10.2f %10.2f %10.2f %6.2f  %dx%dx%d/%d %d+%d %d %d"
               % (short, n, tot, mean, mn, mx, 100.0 * tot / total, g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10]))
     print("# total kernel time %.1f us over %d dispatches" % (total, sum(s[2] for s in stats)))
+    if "--resource-usage" in sys.argv:
+        res = compiler_resources(sys.argv[sys.argv.index("--resource-usage") + 1])
+        print("#\n# registers as the compiler allocated them (%s); the tracer's vgpr+agpr column above is the descriptor's granule and 0"
+              % sys.argv[sys.argv.index("--resource-usage") + 1])
+        for mangled, r in res.items():
+            print("#   %-62s VGPRs %3d  AGPRs %3d  SGPRs %3d  scratch %d  LDS %6d  waves/SIMD %d"
+                  % (mangled[:62], r.get("VGPRs", 0), r.get("AGPRs", 0), r.get("TotalSGPRs", 0), r.get("ScratchSize", 0), r.get("LDS", 0), r.get("Occupancy", 0)))
     if "--phases" in sys.argv:
         w, k, i = (int(v) for v in sys.argv[sys.argv.index("--phases") + 1].split(","))
-        print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches overlapped | %d instrumented steps | %d "
-              "launches alone on one stream" % (w, k, k, i))
-        print("%-58s %10s %10s %10s %10s" % ("kernel", "warm-up", "timed", "instrum.", "alone"))
+        print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches in flight | %d steps, events on the dominant kernel | "
+              "%d steps, events on every kernel | %d launches alone on one stream" % (w, k, k, k, i))
+        print("%-58s %10s %10s %10s %10s %10s" % ("kernel", "warm-up", "timed", "ev.dominant", "ev.all", "alone"))
         for name, rs in per.items():
             d = [(r[2] - r[1]) / 1e3 for r in rs]
-            if len(d) != w + 2 * k + i:
+            if len(d) != w + 3 * k + i:
                 continue
-            cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:]]
+            cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:w + 3 * k], d[w + 3 * k:]]
             short = name if len(name) <= 58 else name[:55] + "..."
-            print("%-58s %10.2f %10.2f %10.2f %10.2f" % ((short,) + tuple(sum(c) / max(len(c), 1) for c in cut)))
+            print("%-58s %10.2f %10.2f %10.2f %10.2f %10.2f" % ((short,) + tuple(sum(c) / max(len(c), 1) for c in cut)))
 
 
 if __name__ == "__main__":
