@@ -23,6 +23,7 @@
 #pragma once
 #include "common.hip.h"
 #include "lstm32.hip.h"
+#include <type_traits>
 
 namespace clair {
 
@@ -144,69 +145,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     fread(xa, 0, 0);
 
-    f32x16 acc[2][2];   // [gate block mi][activation block ni]
-    for (int it = 0; it < n_my; ++it) {
-        const int xt = x_first + it * x_step;
-        // the bias seeds the accumulators (plain VALU moves; two wait states before the first asm MFMA reads them)
+    // Two accumulator sets: tile i accumulates in set i & 1 while the sixteen 1 KiB stores of tile i-1 (the other set) ride in the
+    // MFMA shadows of its first two phases -- as a burst after the last MFMA they were 11 % of the kernel (tools/gpu/gemm_ablate.sh).
+    f32x16 accs[2][2][2];   // [set][gate block mi][activation block ni]
+    f32x16 bias16[2];       // the bias in accumulator layout: C operand of every accumulator's first MFMA (D != C there)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    acc[mi][ni][4 * a] = bq[mi][a][0]; acc[mi][ni][4 * a + 1] = bq[mi][a][1];
-                    acc[mi][ni][4 * a + 2] = bq[mi][a][2]; acc[mi][ni][4 * a + 3] = bq[mi][a][3];
-                }
-        asm volatile("s_nop 1" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        for (int a = 0; a < 4; ++a) {
+            bias16[mi][4 * a] = bq[mi][a][0]; bias16[mi][4 * a + 1] = bq[mi][a][1];
+            bias16[mi][4 * a + 2] = bq[mi][a][2]; bias16[mi][4 * a + 3] = bq[mi][a][3];
+        }
+    asm volatile("" : "+v"(bias16[0]), "+v"(bias16[1]));
+    // piece j = 0..15 of a tile's output: activation block ni = j >> 3, gate block mi = (j >> 2) & 1, quad a = j & 3; each accumulator
+    // block is four contiguous 1 KiB pieces of the recurrent kernel's layout
+    auto store_piece = [&](const f32x16 (&acc)[2][2], int xt, int j) {
+        const int ni = j >> 3, mi = (j >> 2) & 1, a = j & 3;
+        const int xblk = xt * 2 + ni;      // = t * ntiles + tile
+        const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
+        const int gblk = slice * 2 + mi;   // = (d*4 + w)*4 + b
+        const int d = gblk >> 4, wb = gblk & 15;
+        float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4 + a * 256;
+        __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)dst);
+    };
+    auto run_tile = [&](auto set_c, int it) {
+        constexpr int SET = decltype(set_c)::value;
+        f32x16 (&acc)[2][2] = accs[SET];
+        const int xt_prev = x_first + (it - 1) * x_step;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             const int P = it * 4 + ph;
             // ---- first slab of the phase; its partner's eight fragments are read one per MFMA shadow (as a burst in front of the
-            //      MFMAs they held the wave's issue for ~130 cycles per slab: 12 % of the kernel, tools/gpu/gemm_ablate.sh)
+            //      MFMAs they held the wave's issue for ~130 cycles per slab)
 #pragma unroll
             for (int m = 0; m < 24; ++m) {
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
                 // three product terms per k-step, small ones first; the four blocks alternate so consecutive MFMAs never chain
-                mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + kk][term == 0 ? 1 : 0], xa[kk][term == 1 ? 1 : 0][ni]);
+                if (ph == 0 && m < 4) mfma32_av_first(acc[mi][ni], Wr[mi][0][1], xa[0][0][ni], bias16[mi]);
+                else mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + kk][term == 0 ? 1 : 0], xa[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 8) fread1(xb, ph, 1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // Phase P+1 must have landed (this wave's four pieces; the barrier covers the other waves').  Vector-memory operations
-            // retire in issue order, so "at most N outstanding" with N = what was issued after those pieces: phase P+2's four, plus
-            // the sixteen stores of the previous tile's epilogue when it lies in between (first two phases of every tile but the first).
-            if (it > 0 && ph < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            // retire in issue order, so "at most N outstanding" with N = what was issued after those pieces, i.e. in the second slab of
+            // phase P-1: phase P+2's four pieces, preceded there by eight stores of the previous tile when P-1 is phase 0 or 1 of a tile
+            // that has a predecessor.
+            if (it > 0 && (ph == 1 || ph == 2)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
-            // ---- second slab: the next phase's first fragments (one per shadow), then phase P+3 into the slot phase P-1 has left
+            // ---- second slab: the next phase's first fragments (one per shadow), the previous tile's output (eight pieces in each of
+            //      the first two phases), then phase P+3 into the slot phase P-1 has left
 #pragma unroll
             for (int m = 0; m < 24; ++m) {
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
                 mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + 2 + kk][term == 0 ? 1 : 0], xb[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (m < 8) fread1(xa, (ph + 1) & 3, 0, m);
+                if (ph < 2 && m >= 1 && m <= 8 && it > 0) store_piece(accs[SET ^ 1], xt_prev, ph * 8 + m - 1);
                 if (m >= 10 && m < 18 && (m & 1) == 0) dma(P + 3, (m - 10) >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // epilogue: each accumulator block is four contiguous 1 KiB pieces of the recurrent kernel's layout
-        // (12 wait states between the last MFMA and the first read of its result).  Exactly sixteen stores per wave and tile
-        // (the vmcnt arithmetic above counts them); only the last tile of the whole launch can be ragged, and nothing waits after it.
-        asm volatile("s_nop 11" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+    };
+    for (int it = 0; it < n_my; it += 2) {
+        run_tile(std::integral_constant<int, 0>(), it);
+        if (it + 1 < n_my) run_tile(std::integral_constant<int, 1>(), it + 1);
+    }
+    // the last tile's output (12 wait states between the last MFMA and the first read of its result); only this one can be ragged
+    {
+        const int last = n_my - 1, xt = x_first + last * x_step;
+        asm volatile("s_nop 11" : "+v"(accs[0][0][0]), "+v"(accs[0][0][1]), "+v"(accs[0][1][0]), "+v"(accs[0][1][1]),
+                                  "+v"(accs[1][0][0]), "+v"(accs[1][0][1]), "+v"(accs[1][1][0]), "+v"(accs[1][1][1]));
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int xblk = xt * 2 + ni;      // = t * ntiles + tile
-            if (xblk * 32 >= p.m_rows) continue;
-            const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int gblk = slice * 2 + mi;  // = (d*4 + w)*4 + b
-                const int d = gblk >> 4, wb = gblk & 15;
-                float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)(dst + a * 256));
-            }
+        for (int j = 0; j < 16; ++j) {
+            if ((xt * 2 + (j >> 3)) * 32 >= p.m_rows) continue;
+            if (last & 1) store_piece(accs[1], xt, j); else store_piece(accs[0], xt, j);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end still target this workgroup's LDS
