@@ -18,6 +18,7 @@
 #include "dense.hip.h"
 #include "gemm_split.hip.h"
 #include "lstm32.hip.h"
+#include "lstm32_pair.hip.h"
 
 using namespace clair;
 
@@ -61,6 +62,8 @@ struct clair_engine {
     int max_pad = 0;
     bool weights_ready = false;
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
+    int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
+                               // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
     int proj2_groups = 8;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 4 gate tiles x groups workgroups (see clair_engine_create)
     int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
@@ -216,6 +219,8 @@ int drain_timers(clair_engine *e) {
     return 0;
 }
 
+bool use_lstm2_pair(const clair_engine *e, int ntiles) { return e->lstm2_pair < 0 ? ntiles >= 64 : e->lstm2_pair == 1; }
+
 // Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
 // zero or any finite value) writing packed outputs to out_dev ([n][90]).
 int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
@@ -237,8 +242,13 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1};
-        hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        if (use_lstm2_pair(e, ntiles)) {
+            Lstm32PairArgs a{s.zx, e->wh2s, s.a2, n_pad, ntiles};
+            hipLaunchKernelGGL(lstm32_pair_kernel, dim3(((ntiles + 1) / 2) * 2), dim3(256), 0, s.stream, a);
+        } else {
+            Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1};
+            hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        }
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
@@ -298,6 +308,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
     e->proj2_groups = n_slots > 1 ? 4 : 8;
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
+    { const char *t = getenv("CLAIR_AMD_LSTM2_PAIR"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_pair = t[0] - '0'; }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
     for (auto &s : e->slots) {
@@ -604,7 +615,8 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
     const int n_pad = (n + 31) & ~31, ntiles = n_pad / 32;
     const int x_tiles = (T_POS * n_pad + GS_ROWS - 1) / GS_ROWS;
     for (int k = 0; k < CLAIR_K_COUNT; ++k) workgroups[k] = 0;
-    workgroups[CLAIR_K_LSTM1] = workgroups[CLAIR_K_LSTM2] = ntiles * 2;
+    workgroups[CLAIR_K_LSTM1] = ntiles * 2;
+    workgroups[CLAIR_K_LSTM2] = use_lstm2_pair(e, ntiles) ? ((ntiles + 1) / 2) * 2 : ntiles * 2;
     workgroups[CLAIR_K_PROJ2] = 32 * std::min(e->proj2_groups, (x_tiles + 7) / 8);
     workgroups[CLAIR_K_L4] = (n_pad / L34_CAND) * L4_SPLITS;
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;

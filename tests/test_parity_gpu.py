@@ -74,6 +74,32 @@ def test_full_size_batches_by_properties(synth_weights, n, platform):
         eng.close()
 
 
+@pytest.mark.parametrize("n", [1, 33, 70, 100, 200])
+def test_two_tile_lstm2_kernel_forced_at_small_sizes(synth_weights, monkeypatch, n):
+    """lstm32_pair_kernel (two 32-candidate tiles per workgroup, steps alternating) is the default from 2048 candidates on; forced
+    here at sizes with 1, 2, 3, 4 and 7 tiles (odd counts: the last workgroup's second tile duplicates its first).  Outputs and the
+    LSTM2 tap must equal the one-tile kernel's BIT for bit (same arithmetic per candidate, only the schedule differs) and the oracle's
+    within tolerance."""
+    from clair_amd import _capi
+    x, _ = synth.synthetic_input(n, "ont", seed=700 + n)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLAIR_AMD_LSTM2_PAIR", mode)
+        eng = _capi.Engine(device=0, max_batch=256, n_slots=1)
+        try:
+            eng.load_weights(synth_weights)
+            outs = eng.predict(x)
+            n_pad = (n + 31) // 32 * 32
+            res[mode] = (outs, eng.debug_read(0, 2, (33, n_pad, 256))[:, :n])
+        finally:
+            eng.close()
+    assert np.array_equal(res["0"][1], res["1"][1])
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert np.array_equal(a, b)
+    for g, w_ in zip(res["1"][0], _oracle(synth_weights, x)):
+        assert np.abs(g - w_).max() <= PROB_TOL
+
+
 def _sweep_cells():
     import os
     import sys
