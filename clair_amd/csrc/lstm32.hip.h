@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
-    if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, (B) - 1)                                                     \
+    if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, ((B) > 0 ? (B) - 1 : 0))                                                     \
     if (!FIRST && (M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */ \
     if (FIRST && (B) > 0 && (M) == 8) load_seed(xacc[(B) - 1], 0, (B) - 1);   /* the gates above read their accumulators in gaps 1-7: block B-1's restarts from its bias */ \
     if ((B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p exp
 sed -e 's|^int enqueue_forward(|static bool ablated(int id) { static const unsigned m = getenv("CLAIR_ABLATE") ? (unsigned)strtoul(getenv("CLAIR_ABLATE"), nullptr, 0) : 0u; return (m >> id) \& 1u; }\nint enqueue_forward(|' \
-    -e 's|^\(        \)hipLaunchKernelGGL(|\1if (!ablated(kt.id)) hipLaunchKernelGGL(|' \
+    -e 's|^\(        *\)hipLaunchKernelGGL(\(.*s\.stream, a);\)|\1if (!ablated(kt.id)) hipLaunchKernelGGL(\2|' \
     -e 's|#include "\([a-z0-9_]*\.hip\.h\)"|#include "../clair_amd/csrc/\1"|' -e 's|#include "../../include/clair_amd.h"|#include "../include/clair_amd.h"|' \
     clair_amd/csrc/engine.hip > exp/engine_ablate.hip
 grep -c "ablated(kt.id)" exp/engine_ablate.hip
