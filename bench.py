@@ -191,13 +191,15 @@ def main():
 
     # The same loop again, same streams, with a HIP-event pair around the dominant kernel only (two marker packets per
     # forward pass): its duration in the configuration the timed region ran in -- what roofline.frac is computed from.
-    eng.timing_enable(only=[DOMINANT])
+    fused = eng.kernel_workgroups(batch)["proj2"] == 0      # layer 2 as one launch (CLAIR_AMD_LSTM2_FUSED=1): its events carry id "lstm2"
+    dominant = "lstm2" if fused else DOMINANT
+    eng.timing_enable(only=[dominant])
     eng.timing_reset()
     t1 = time.perf_counter()
     run(steps)
     eng.sync()
     elapsed_dom = time.perf_counter() - t1
-    dom_ms, dom_cnt = eng.kernel_times()[DOMINANT]
+    dom_ms, dom_cnt = eng.kernel_times()[dominant]
     # ... with every kernel bracketed (ten marker packets per pass): the per-kernel table
     eng.timing_enable(True)
     eng.timing_reset()
@@ -240,22 +242,23 @@ def main():
         wgs = eng.kernel_workgroups(batch)
         cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in times_iso}
         chip_time = {k: times_iso[k][0] / max(times_iso[k][1], 1) * cu_share[k] for k in times_iso}
-        dom = DOMINANT
+        dom = dominant
         dom_ms_mean = dom_ms / max(dom_cnt, 1)                        # in the multi-stream run
         alone_ms = times_iso[dom][0] / max(times_iso[dom][1], 1)
-        flop = KERNEL_FLOP[dom] * batch
+        flop_cand = KERNEL_FLOP["proj2"] + KERNEL_FLOP["lstm2"] if fused else KERNEL_FLOP[dom]
+        flop = flop_cand * batch
         tf = flop / (dom_ms_mean * 1e-3) / 1e12
         tf_alone = flop / (alone_ms * 1e-3) / 1e12
         pmc = PMC_TRAFFIC_BYTES.get(batch) or {k: (v * batch / 1024 if k != "source" else v + " (batch 1024, scaled by batch/1024)")
                                                  for k, v in PMC_TRAFFIC_BYTES[1024].items()}
-        traffic = pmc.get(dom)
+        traffic = pmc.get("layer2_fused" if fused else dom)
         roof = {
-            "bound": "mfma", "kernel": dom, "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "bound": "mfma", "kernel": "layer2_fused (proj2 + lstm2 in one launch)" if fused else dom, "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": round(traffic) if traffic else None,
             "traffic_source": pmc["source"],
             "definition": "SURVEY.md 8(d) algorithmic FLOP of the kernel per launch (%d per candidate x batch) / its mean HIP-event "
                           "duration with %d batches in flight (the timed loop repeated with events around this kernel only) / dense f16 MFMA peak"
-                          % (KERNEL_FLOP[dom], streams),
+                          % (flop_cand, streams),
             "kernel_ms": round(dom_ms_mean, 5), "launches": dom_cnt, "algorithmic_flop_per_launch": flop,
             "executed_frac": round(tf * SPLIT_TERMS / PEAK_F16_MFMA_TFLOPS, 4),
             "executed_note": "matmuls run as a 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
@@ -263,7 +266,7 @@ def main():
             "workgroups": wgs[dom], "cu_share": round(cu_share[dom], 4),
             "hbm_gbs_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9, 1) if traffic else None,
             "hbm_frac_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None,
-            "design_bytes_per_launch": DESIGN_BYTES[dom] * batch,
+            "design_bytes_per_launch": (33 * 256 * 4 + 33 * 1024 * 4 + 33 * 256 * 4 if fused else DESIGN_BYTES[dom]) * batch,
             "chip_time_share_alone": {k: round(v / max(sum(chip_time.values()), 1e-12), 3) for k, v in chip_time.items() if v},
             "value_with_events_on_this_kernel": round(steps * batch / elapsed_dom, 1),
         }

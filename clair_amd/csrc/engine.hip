@@ -19,6 +19,7 @@
 #include "gemm_split.hip.h"
 #include "lstm32.hip.h"
 #include "lstm32_pair.hip.h"
+#include "lstm2_fused.hip.h"
 
 using namespace clair;
 
@@ -42,6 +43,8 @@ struct Slot {
     unsigned short *a1 = nullptr;   // [2][33][max_pad][256] fp16: LSTM1 output as its 2-way split
     float *a2 = nullptr;      // [33][max_pad][256]
     float *l4part = nullptr;  // [16][max_pad][192]
+    unsigned *fuse_flags = nullptr;   // lstm2_fused.hip.h: [2][max_pad/32][33][8] ticket words, one error word, one claim word per workgroup
+    unsigned fuse_ticket = 0;         // ticket of the last fused forward pass on this slot
     float *d_out = nullptr;   // [max_pad][90]
     float *h_out = nullptr;   // pinned [max_batch][90]
     float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
@@ -64,6 +67,10 @@ struct clair_engine {
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
     int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
                                // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
+    int lstm2_fused = -1;      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one slot
+                               // from 512 candidates on, where it shortens a pass by 2-8 % (104 us instead of 47 + 78 at batch 1024;
+                               // profiles/r02_lstm2_fused.txt); with batches in flight on other slots the two launches pack as well.  CLAIR_AMD_LSTM2_FUSED=0/1 forces
+    int fused_groups = 4;      // projection workgroup groups per XCD inside the fused launch (CLAIR_AMD_FUSED_GROUPS)
     int proj2_groups = 8;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 4 gate tiles x groups workgroups (see clair_engine_create)
     int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
@@ -175,7 +182,7 @@ void free_slot(Slot &s) {
     for (auto &t : s.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto ev : s.free_events) (void)hipEventDestroy(ev);
     (void)hipFree(s.d_x); (void)hipFree(s.zx); (void)hipFree(s.a1); (void)hipFree(s.a2);
-    (void)hipFree(s.l4part); (void)hipFree(s.d_out);
+    (void)hipFree(s.l4part); (void)hipFree(s.d_out); (void)hipFree(s.fuse_flags);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_x) (void)hipHostFree(s.h_x);
     if (s.d_counts) (void)hipFree(s.d_counts);
@@ -219,6 +226,13 @@ int drain_timers(clair_engine *e) {
     return 0;
 }
 
+bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->slots.size() == 1); }
+bool use_lstm2_fused(const clair_engine *e, int ntiles) {   // pairs of tiles share a 64-row activation tile: even tile counts only
+    if ((ntiles & 1) || !fused_possible(e)) return false;
+    return e->lstm2_fused == 1 || ntiles >= 16;
+}
+size_t fuse_words(int max_pad) { return (size_t)2 * (max_pad / 32) * T_POS * 8; }                  // ticket words of the zx blocks
+size_t fuse_claims(const clair_engine *e) { return (size_t)32 * e->fused_groups + 32 * ((e->max_pad / 64 + 7) / 8); }   // one per workgroup of the largest launch
 bool use_lstm2_pair(const clair_engine *e, int ntiles) { return e->lstm2_pair < 0 ? ntiles >= 64 : e->lstm2_pair == 1; }
 
 // Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
@@ -233,21 +247,32 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         Lstm32Args a{x_dev, e->wx1s, e->bx1, nullptr, e->wh1s, s.a1, nullptr, n_pad, ntiles, -1};
         hipLaunchKernelGGL((lstm32_kernel<true>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
     }
-    {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split; weight-stationary persistent workgroups
-        KernelTimer kt(e, s, CLAIR_K_PROJ2);
-        const int x_tiles = (m_rows + GS_ROWS - 1) / GS_ROWS;
-        const int groups = std::min(e->proj2_groups, (x_tiles + 7) / 8);
-        GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows, groups};
-        hipLaunchKernelGGL(gemm_split_kernel, dim3(32 * groups), dim3(256), 0, s.stream, a);
-    }
-    {
+    if (use_lstm2_fused(e, ntiles)) {   // layer 2 in one launch: projection and recurrence side by side, zx through L2 (lstm2_fused.hip.h)
         KernelTimer kt(e, s, CLAIR_K_LSTM2);
-        if (use_lstm2_pair(e, ntiles)) {
-            Lstm32PairArgs a{s.zx, e->wh2s, s.a2, n_pad, ntiles};
-            hipLaunchKernelGGL(lstm32_pair_kernel, dim3(((ntiles + 1) / 2) * 2), dim3(256), 0, s.stream, a);
-        } else {
-            Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1};
-            hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+        const int groups = e->fused_groups;
+        if (++s.fuse_ticket == 0) s.fuse_ticket = 1;   // (a wrapped ticket could meet a 4-billion-passes-old word; the words are zero at most once)
+        Lstm2FusedArgs a{GemmSplitArgs{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows, groups},
+                         Lstm32Args{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1},
+                         FuseArgs{s.fuse_flags, s.fuse_ticket, s.fuse_flags + fuse_words(e->max_pad) + 1, s.fuse_flags + fuse_words(e->max_pad)}, 32 * groups};
+        const int consumers = 32 * ((ntiles / 2 + 7) / 8);
+        hipLaunchKernelGGL(lstm2_fused_kernel, dim3(32 * groups + consumers), dim3(256), 0, s.stream, a);
+    } else {
+        {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split; weight-stationary persistent workgroups
+            KernelTimer kt(e, s, CLAIR_K_PROJ2);
+            const int x_tiles = (m_rows + GS_ROWS - 1) / GS_ROWS;
+            const int groups = std::min(e->proj2_groups, (x_tiles + 7) / 8);
+            GemmSplitArgs a{s.a1, e->wx2s, e->bx2, s.zx, n_pad, ntiles, m_rows, groups};
+            hipLaunchKernelGGL(gemm_split_kernel, dim3(32 * groups), dim3(256), 0, s.stream, a);
+        }
+        {
+            KernelTimer kt(e, s, CLAIR_K_LSTM2);
+            if (use_lstm2_pair(e, ntiles)) {
+                Lstm32PairArgs a{s.zx, e->wh2s, s.a2, n_pad, ntiles};
+                hipLaunchKernelGGL(lstm32_pair_kernel, dim3(((ntiles + 1) / 2) * 2), dim3(256), 0, s.stream, a);
+            } else {
+                Lstm32Args a{nullptr, nullptr, nullptr, s.zx, e->wh2s, nullptr, s.a2, n_pad, ntiles, -1};
+                hipLaunchKernelGGL((lstm32_kernel<false>), dim3(ntiles * 2), dim3(256), 0, s.stream, a);
+            }
         }
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
@@ -261,6 +286,21 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
+    return 0;
+}
+
+// lstm2_fused.hip.h hands zx over through the L2 of the XCD its workgroups find themselves on; if the placement rule it relies on
+// did not hold (a logical id claimed twice, a wait that ran out) a workgroup raised the word behind the slot's tickets, and the
+// results of that pass cannot be trusted.
+const char *const FUSED_PLACEMENT_MSG = "fused layer-2 launch: its blocks did not go round the XCDs as assumed (a logical id claimed twice, or a wait "
+                                        "that ran out); results discarded -- set CLAIR_AMD_LSTM2_FUSED=0";
+int check_fused_placement(clair_engine *e) {
+    for (auto &s : e->slots) {
+        if (!s.fuse_flags) continue;
+        unsigned bad = 0;
+        HIP_TRY(e, hipMemcpy(&bad, s.fuse_flags + fuse_words(e->max_pad), sizeof bad, hipMemcpyDeviceToHost));
+        if (bad) return fail(e, "%s", FUSED_PLACEMENT_MSG);
+    }
     return 0;
 }
 
@@ -308,6 +348,8 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
     e->proj2_groups = n_slots > 1 ? 4 : 8;
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
+    { const char *t = getenv("CLAIR_AMD_LSTM2_FUSED"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_fused = t[0] - '0'; }
+    { const char *t = getenv("CLAIR_AMD_FUSED_GROUPS"); if (t && atoi(t) > 0 && atoi(t) <= 8) e->fused_groups = atoi(t); }
     { const char *t = getenv("CLAIR_AMD_LSTM2_PAIR"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_pair = t[0] - '0'; }
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
@@ -319,8 +361,13 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.a1, ((size_t)2 * T_POS * mp * 256 + 128 * 256) * sizeof(unsigned short));   // + slack rows read (never used) by gemm_split's ragged last tile
         if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
+        if (r == hipSuccess && fused_possible(e)) {
+            const size_t words = fuse_words(e->max_pad) + 1 + fuse_claims(e);   // tickets | error word | claims
+            r = hipMalloc((void **)&s.fuse_flags, words * sizeof(unsigned));
+            if (r == hipSuccess) r = hipMemset(s.fuse_flags, 0, words * sizeof(unsigned));
+        }
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
-        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, (size_t)max_batch * OUT_FLOATS * sizeof(float), hipHostMallocDefault);
+        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, ((size_t)max_batch * OUT_FLOATS + 1) * sizeof(float), hipHostMallocDefault);   // + the fused launch's error word
         if (r != hipSuccess) {
             fail(nullptr, "allocating slot workspaces for max_batch=%d failed: %s", max_batch, hipGetErrorString(r));
             clair_engine_destroy(e);
@@ -463,6 +510,8 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
         HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
     if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
     HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    if (s.fuse_flags)
+        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
     s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
     s.pending_n = n;
     return 0;
@@ -493,6 +542,8 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
         HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
     if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
     HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    if (s.fuse_flags)
+        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
     s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
     s.pending_n = n;
     return 0;
@@ -513,6 +564,11 @@ int clair_wait(clair_engine_t *e, int slot) {
     HIP_TRY(e, hipSetDevice(e->device));
     Slot &s = e->slots[slot];
     HIP_TRY(e, hipStreamSynchronize(s.stream));
+    if (s.fuse_flags) {
+        unsigned bad;
+        memcpy(&bad, s.h_out + (size_t)e->max_batch * OUT_FLOATS, sizeof bad);
+        if (bad) { s.pending_n = 0; return fail(e, "%s", FUSED_PLACEMENT_MSG); }
+    }
     const int n = s.pending_n;
     for (int i = 0; i < n; ++i) {
         const float *row = s.h_out + (size_t)i * OUT_FLOATS;
@@ -578,7 +634,7 @@ int clair_sync(clair_engine_t *e) {
     if (!e) return fail(nullptr, "engine is NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    return 0;
+    return check_fused_placement(e);
 }
 
 int clair_timing_enable(clair_engine_t *e, int on) {
@@ -618,6 +674,10 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
     workgroups[CLAIR_K_LSTM1] = ntiles * 2;
     workgroups[CLAIR_K_LSTM2] = use_lstm2_pair(e, ntiles) ? ((ntiles + 1) / 2) * 2 : ntiles * 2;
     workgroups[CLAIR_K_PROJ2] = 32 * std::min(e->proj2_groups, (x_tiles + 7) / 8);
+    if (use_lstm2_fused(e, ntiles)) {   // one launch: the projection workgroups first, then the recurrent ones
+        workgroups[CLAIR_K_LSTM2] = 32 * e->fused_groups + 32 * ((ntiles / 2 + 7) / 8);
+        workgroups[CLAIR_K_PROJ2] = 0;
+    }
     workgroups[CLAIR_K_L4] = (n_pad / L34_CAND) * L4_SPLITS;
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
     return 0;

@@ -54,21 +54,34 @@ __device__ __forceinline__ int split_lds_off(int row, int chunk) { return row * 
 
 constexpr int GS_RING = 4;                        // phases resident in LDS
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_split_kernel(GemmSplitArgs p) {
+// FUSED (lstm2_fused.hip.h): the workgroup's tiles are those of the candidate-tile pairs its XCD owns (pair q -> XCD q % 8,
+// whatever the batch size), in the TIME order of its direction (gate tiles 2, 3 walk t = 32..0), and every wave publishes a
+// ticket word per (direction, tile, t) block once its sixteen pieces of it are in L2.
+template <bool FUSED>
+__device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const int block, const FuseArgs &fz) {
     __shared__ __attribute__((aligned(16))) f16bits_t Xs[GS_RING][GS_PHASE];   // [ring slot][slab][plane][row][k]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, lh = lane >> 5;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int xcd = block & 7, local = block >> 3;
     const int gtile = local & 3, group = local >> 2;
     const int x_tiles = (p.m_rows + GS_ROWS - 1) / GS_ROWS;
     const int x_step = 8 * p.groups;
     const int x_first = xcd + 8 * group;
-    if (x_first >= x_tiles) return;
-    const int n_my = (x_tiles - x_first + x_step - 1) / x_step;   // activation tiles of this workgroup
+    // fused: items i = s * nq + k of this XCD (step s of this gate tile's direction, pair q = xcd + 8k); group g takes i = g, g + groups, ...
+    const int npairs = p.ntiles >> 1;
+    const int nq = FUSED ? (xcd < npairs ? (npairs - xcd + 7) >> 3 : 0) : 0;
+    const int n_items = T_POS * nq;
+    if (FUSED ? group >= n_items : x_first >= x_tiles) return;
+    const int n_my = FUSED ? (n_items - group + p.groups - 1) / p.groups : (x_tiles - x_first + x_step - 1) / x_step;   // activation tiles of this workgroup
     const int slice = gtile * 4 + wave;                           // this wave's 64 gate rows
+    auto xt_of = [&](int it) -> int {                             // activation tile (64 rows of a1) number it of this workgroup
+        if (!FUSED) return x_first + it * x_step;
+        const int i = group + it * p.groups, s_ = i / nq, k = i - s_ * nq;
+        return ((gtile >> 1) ? T_POS - 1 - s_ : s_) * npairs + xcd + 8 * k;
+    };
 
     // resident weights: Wr[mi][kk][plane]
     f16x8 Wr[2][16][2];
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n_phases = n_my * 4;
     auto phase_base = [&](int P) -> const f16bits_t * {
         const int q = P < n_phases ? P : n_phases - 1;   // the prefetch past the end re-reads the last phase
-        return my_base + ((size_t)(x_first + (q >> 2) * x_step) * GS_ROWS * 256) + (q & 3) * 64;
+        return my_base + ((size_t)xt_of(q >> 2) * GS_ROWS * 256) + (q & 3) * 64;
     };
     auto dma = [&](int P, int j) { glds16_s(lane_off[j], phase_base(P), lds0 + (unsigned)((P & (GS_RING - 1)) * GS_PHASE * 2 + j * 1024)); };
     // B fragments of one slab: [kk][plane][activation block]
@@ -168,10 +181,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4 + a * 256;
         __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)dst);
     };
+    // fused: this wave's ticket words of the two candidate tiles of activation tile xt
+    auto publish = [&](int xt) {
+        if (!FUSED) return;
+        const int t = xt / npairs, q = xt - t * npairs;
+        unsigned *fw = fz.flags + (((size_t)((gtile >> 1) * p.ntiles + 2 * q) * T_POS + t) * 8) + (gtile & 1) * 4 + wave;
+        if (lane == 0) {
+            __hip_atomic_store(fw, fz.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fw + T_POS * 8, fz.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     auto run_tile = [&](auto set_c, int it) {
         constexpr int SET = decltype(set_c)::value;
         f32x16 (&acc)[2][2] = accs[SET];
-        const int xt_prev = x_first + (it - 1) * x_step;
+        const int xt_prev = xt_of(it > 0 ? it - 1 : 0);
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             const int P = it * 4 + ph;
@@ -194,6 +217,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (it > 0 && (ph == 1 || ph == 2)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __syncthreads();
+            // fused: at most phase P+2's four pieces are outstanding here, so in phase 3 the previous tile's stores (issued in phases
+            // 0 and 1) have retired -- its blocks are in L2; the two ticket stores are older than this slab's DMA pieces, so the
+            // counts above hold
+            if (FUSED && ph == 3 && it > 0) publish(xt_prev);
             // ---- second slab: the next phase's first fragments (one per shadow), the previous tile's output (eight pieces in each of
             //      the first two phases), then phase P+3 into the slot phase P-1 has left
 #pragma unroll
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // the last tile's output (12 wait states between the last MFMA and the first read of its result); only this one can be ragged
     {
-        const int last = n_my - 1, xt = x_first + last * x_step;
+        const int last = n_my - 1, xt = xt_of(last);
         asm volatile("s_nop 11" : "+v"(accs[0][0][0]), "+v"(accs[0][0][1]), "+v"(accs[0][1][0]), "+v"(accs[0][1][1]),
                                   "+v"(accs[1][0][0]), "+v"(accs[1][0][1]), "+v"(accs[1][1][0]), "+v"(accs[1][1][1]));
 #pragma unroll
@@ -224,6 +251,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end still target this workgroup's LDS
+    if (FUSED) publish(xt_of(n_my - 1));
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_split_kernel(GemmSplitArgs p) {
+    gemm_split_body<false>(p, blockIdx.x, FuseArgs{nullptr, 0u, nullptr, nullptr});
 }
 
 }  // namespace clair

@@ -103,8 +103,17 @@ __device__ __forceinline__ void mfma32_vv_first(f32x16 &acc, const f16x8 &a, con
 
 constexpr float GATE_K2 = 2.0f * 1.44269504088896340736f;
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm32_kernel(Lstm32Args p) {
+// Hand-off words of the fused layer-2 kernel (lstm2_fused.hip.h): the projection workgroups publish "this (direction, tile, t)
+// block is written" per producing wave, the recurrent workgroups wait for them a step ahead of their seed loads.
+struct FuseArgs {
+    unsigned *flags;        // [2 dir][n_pad/32][33][8 producer waves]  = ticket of the forward pass that wrote the block
+    unsigned ticket;        // this forward pass (never 0; the words start zeroed)
+    unsigned *claims;       // [workgroups of the launch]  ticket of the pass whose workgroup took this logical id
+    unsigned *error;        // raised when a logical id is claimed twice or a wait runs out: the pass's results are not to be used
+};
+
+template <bool FIRST, bool FUSED>
+__device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, const int tile, const FuseArgs &fz) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[FIRST ? L32_LDS_FIRST : L32_LDS_SECOND];
     _Float16 (*hbuf)[2][L32_TILE][HP_ROW] = (_Float16 (*)[2][L32_TILE][HP_ROW])lds_raw;   // [step parity][plane][cand][unit]
     _Float16 *wxl = (_Float16 *)(lds_raw + L32_HBUF_BYTES);             // FIRST: [wave][b][kk][plane][lane][8]
@@ -115,8 +124,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cand = lane & 31, hq = lane >> 5;
-    const int d = p.dir_only < 0 ? (blockIdx.x & 1) : p.dir_only;
-    const int tile = p.dir_only < 0 ? (blockIdx.x >> 1) : blockIdx.x;
 
     // resident weights: Aw[b][kk][plane] = 8 fp16 of gate row (b, lane%32), k = 16*kk + 8*(lane/32) + j
     f16x8 Aw[4][8][2];
@@ -208,6 +215,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
     };
+    // ---- fused layer 2: wave w's seeds of step s come from producer waves 2w and 2w+1 of the projection workgroup that owns this
+    //      direction's gate rows 128 (w >> 1) .. +127 (gemm_split.hip.h: slice = gtile*4 + wave).  Their two ticket words are read
+    //      one step before they are needed (the words are written through to memory, ~2 us away) and polled only if still behind.
+    const unsigned long long *fl_base = FUSED ? (const unsigned long long *)fz.flags + ((size_t)(d * p.ntiles + tile) * T_POS) * 4 + w : nullptr;
+    unsigned long long fl_next = 0;
+    auto flag_fetch = [&](int s) {
+        if (!FUSED || s >= T_POS) return;
+        fl_next = __hip_atomic_load(fl_base + (size_t)(d ? T_POS - 1 - s : s) * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto flag_wait = [&](int s) {
+        if (!FUSED || s >= T_POS) return;
+        const unsigned long long want = ((unsigned long long)fz.ticket << 32) | fz.ticket;
+        const unsigned long long *fp = fl_base + (size_t)(d ? T_POS - 1 - s : s) * 4;
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)fl_next), hi = __builtin_amdgcn_readfirstlane((unsigned)(fl_next >> 32));
+        if ((((unsigned long long)hi << 32) | lo) == want) return;
+        const long long deadline = wall_clock64() + 5000000;   // 100 MHz: 50 ms, three orders of magnitude beyond any honest wait
+        while ((((unsigned long long)hi << 32) | lo) != want) {
+            __builtin_amdgcn_s_sleep(2);
+            const unsigned long long v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = __builtin_amdgcn_readfirstlane((unsigned)v); hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            if (wall_clock64() > deadline) { if (lane == 0) *fz.error = 1u; break; }
+        }
+    };
     // ---- h_s (both planes complete in LDS) -> HBM, as four pieces per thread laid out so that every wave-level store is one
     //      contiguous run per row (a thread-per-row-chunk map made each store touch 64 quarter-filled 64-byte segments and cost
     //      ~200 issue cycles; this way a store covers two whole 512-byte fp32 rows / four 256-byte fp16 rows).  Split into an LDS
@@ -275,6 +305,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         xreg = load_x(2);
     } else {
+        flag_fetch(0);
+        flag_wait(0);
+        flag_fetch(1);
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_seed(zq[b], 0, b);
     }
@@ -347,6 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), and in block 0 the copy-out of h_{s-1}.
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (FUSED && (B) == 0 && (M) == 2) { flag_wait(s + 1); flag_fetch(s + 2); }                                   \
     if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
     if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, ((B) > 0 ? (B) - 1 : 0))                                                     \
     if (!FIRST && (M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */ \
@@ -468,6 +502,13 @@ _Pragma("unroll")                                                               
     for (int i = 0; i < 8; ++i) copy_cvt(i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) copy_write(T_POS - 1, j);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm32_kernel(Lstm32Args p) {
+    const int d = p.dir_only < 0 ? (blockIdx.x & 1) : p.dir_only;
+    const int tile = p.dir_only < 0 ? (blockIdx.x >> 1) : blockIdx.x;
+    lstm32_body<FIRST, false>(p, d, tile, FuseArgs{nullptr, 0u, nullptr, nullptr});
 }
 
 }  // namespace clair

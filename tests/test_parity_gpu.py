@@ -100,6 +100,64 @@ def test_two_tile_lstm2_kernel_forced_at_small_sizes(synth_weights, monkeypatch,
         assert np.abs(g - w_).max() <= PROB_TOL
 
 
+@pytest.mark.parametrize("n", [64, 500, 1024, 2048])
+def test_fused_layer2_launch_equals_the_two_launches_bit_for_bit(synth_weights, monkeypatch, n):
+    """lstm2_fused_kernel (projection and recurrence of layer 2 in ONE launch, the recurrent workgroups waiting on per-block ticket
+    words; default on one-slot handles from 512 candidates on) against the two-launch path: same arithmetic per candidate, so the
+    outputs and the LSTM2 tap must be equal bit for bit -- also on a second pass over the same slot, when every ticket word still
+    holds the previous pass's value."""
+    from clair_amd import _capi
+    x, _ = synth.synthetic_input(n, "ont", seed=800 + n)
+    res = {}
+    monkeypatch.setenv("CLAIR_AMD_LSTM2_PAIR", "0")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", mode)
+        eng = _capi.Engine(device=0, max_batch=2048, n_slots=1)
+        try:
+            eng.load_weights(synth_weights)
+            first = eng.predict(x)
+            outs = eng.predict(x)
+            n_pad = (n + 31) // 32 * 32
+            wgs = eng.kernel_workgroups(n)
+            assert (wgs["proj2"] == 0) == (mode == "1"), wgs          # the fused launch really is the one that ran
+            res[mode] = (first, outs, eng.debug_read(0, 2, (33, n_pad, 256))[:, :n])
+        finally:
+            eng.close()
+    assert np.array_equal(res["0"][2], res["1"][2])
+    for a, b, c in zip(res["0"][0], res["1"][0], res["1"][1]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for g, w_ in zip(res["1"][1], _oracle(synth_weights, x[:256])):
+        assert np.abs(g[:256] - w_).max() <= PROB_TOL
+
+
+def test_fused_layer2_launch_with_batches_in_flight(synth_weights, monkeypatch):
+    """The fused launch takes its place from the XCD each workgroup finds itself on (a queue's launches go round the XCDs with a
+    rotation that depends on what else is being dispatched); forced on a three-slot handle, 24 batches in flight three at a time
+    must give what the two-launch path gives, and the engine's placement check (clair_sync) must stay quiet."""
+    from clair_amd import _capi
+    n, batch = 24 * 1024, 1024
+    x, _ = synth.synthetic_input(n, "ont", seed=77)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", mode)
+        eng = _capi.Engine(device=0, max_batch=batch, n_slots=3)
+        try:
+            eng.load_weights(synth_weights)
+            xd, od = eng.dataset_alloc(n)
+            try:
+                eng.dataset_upload(xd, 0, x)
+                for rep in range(3):
+                    for b in range(n // batch):
+                        eng.run_resident(b % 3, xd, od, b * batch, batch)
+                eng.sync()
+                out[mode] = eng.dataset_download(od, 0, n)
+            finally:
+                eng.dataset_free(xd, od)
+        finally:
+            eng.close()
+    assert np.array_equal(out["0"], out["1"])
+
+
 def _sweep_cells():
     import os
     import sys

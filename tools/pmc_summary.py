@@ -15,7 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-SHORT = (("gemm_split", "proj2"), ("l3l4", "l4"), ("tail", "tail"), ("lstm32_pair_kernel", "lstm2"), ("lstm32_kernel<false>", "lstm2"), ("lstm32_kernel<true>", "lstm1"))
+SHORT = (("lstm2_fused", "layer2_fused"), ("gemm_split", "proj2"), ("l3l4", "l4"), ("tail", "tail"), ("lstm32_pair_kernel", "lstm2"), ("lstm32_kernel<false>", "lstm2"), ("lstm32_kernel<true>", "lstm1"))
 
 
 def per_kernel(path, counter, skip):
@@ -51,7 +51,7 @@ def traffic():
         if s is None:
             continue
         f, w = 2 * fetch[name] * 1024 / 1e6, write.get(name, 0.0) * 1024 / 1e6
-        a = bench.DESIGN_BYTES[s] * batch / 1e6
+        a = (33 * 256 * 4 + 33 * 1024 * 4 + 33 * 256 * 4 if s == "layer2_fused" else bench.DESIGN_BYTES[s]) * batch / 1e6   # fused: a1 in, zx out (its reads stay in L2), a2 out
         total += f + w
         table[s] = (f + w) * 1e6
         print("%-54s %14.1f %14.1f %14.1f %14.1f %8.2f" % (name[:54], f, w, f + w, a, (f + w) / a if a else 0))
