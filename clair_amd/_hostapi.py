@@ -7,6 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_crc32c", "clair_host_parse_tensors",
+           "clair_host_counts_to_input_i16", "clair_host_counts_to_input_i32",
            "clair_host_decode_rows", "clair_host_decode_rows_ex",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
@@ -54,8 +55,10 @@ def load():
         lib.clair_host_evc_reads.restype = i64
         lib.clair_host_evc_take.argtypes = [vp, i64, vp, ctypes.POINTER(i64)]
         lib.clair_host_evc_take_text.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
-        if lib.clair_host_abi_version() != 3:
-            raise RuntimeError("libclair_host.so has ABI version %d, expected 3: run `python -m clair_amd.build`"
+        lib.clair_host_counts_to_input_i16.argtypes = [vp, i64, vp]
+        lib.clair_host_counts_to_input_i32.argtypes = [vp, i64, vp]
+        if lib.clair_host_abi_version() != 4:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 4: run `python -m clair_amd.build`"
                                % lib.clair_host_abi_version())
         _lib = lib
     return _lib
@@ -64,6 +67,19 @@ def load():
 def crc32c(data):
     """CRC32C (Castagnoli) of a bytes object."""
     return int(load().clair_host_crc32c(data, len(data)))
+
+
+def counts_to_input(counts):
+    """Raw pileup counts [n,33,8,4] (int16 or int32) -> float32 network input with channels 1..3 -= channel 0 (utils.py:96-98)."""
+    lib = load()
+    c = np.ascontiguousarray(counts)
+    if c.dtype not in (np.int16, np.int32):
+        c = c.astype(np.int32)
+    x = np.empty(c.shape, dtype=np.float32)
+    fn = lib.clair_host_counts_to_input_i16 if c.dtype == np.int16 else lib.clair_host_counts_to_input_i32
+    if fn(c.ctypes.data, c.size // 4, x.ctypes.data) != 0:
+        raise ValueError("counts_to_input: " + lib.clair_host_last_error().decode())
+    return x
 
 
 def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):
@@ -96,13 +112,16 @@ def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitiv
         return ([], np.zeros(0, np.uint8)) if with_status else []
     x = np.ascontiguousarray(X, dtype=np.float32).reshape(n, N_VALUES)
     gt21, genotype, len1, len2 = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
-    parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
-    lens = np.fromiter(map(len, parts), dtype=np.int32, count=3 * n)
-    tok = np.empty((n, 6), dtype=np.int32)
-    tok[:, 1::2] = lens.reshape(n, 3)
-    starts = np.cumsum(lens, dtype=np.int64) - lens
-    tok[:, 0::2] = starts.reshape(n, 3)
-    meta = "".join(parts).encode("ascii")
+    if hasattr(infos, "native_meta"):          # tensor_binary.InfoTable: the record columns as they are
+        meta, tok = infos.native_meta()
+    else:
+        parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
+        lens = np.fromiter(map(len, parts), dtype=np.int32, count=3 * n)
+        tok = np.empty((n, 6), dtype=np.int32)
+        tok[:, 1::2] = lens.reshape(n, 3)
+        starts = np.cumsum(lens, dtype=np.int64) - lens
+        tok[:, 0::2] = starts.reshape(n, 3)
+        meta = "".join(parts).encode("ascii")
     cap = 4096 + 256 * n + 2 * len(meta)
     out = ctypes.create_string_buffer(cap)
     out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)

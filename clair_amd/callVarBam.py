@@ -127,8 +127,7 @@ def tensor_batches(args, positions, batch_size):
         nonlocal total
         total += len(infos)
         print("Processed %d tensors" % total, file=sys.stderr)
-        x = counts.astype(np.float32)                     # the decode reads depth and allele support from the tensor
-        x[:, :, :, 1:] -= x[:, :, :, 0:1]
+        x = _hostapi.counts_to_input(counts)              # the decode reads depth and allele support from the tensor
         # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
         small = counts.astype(np.int16) if int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
         return x, infos, small

@@ -208,6 +208,34 @@ int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_ro
 
 }  // extern "C"
 
+namespace {
+template <typename T>
+int counts_to_input(const T *counts, int64_t n_quads, float *x) {
+    if (!counts || !x || n_quads < 0) return fail("clair_host_counts_to_input: bad arguments");
+    const int nthreads = clair_host_threads((int)std::min<int64_t>(n_quads / (CLAIR_HOST_VALUES / 4), 1 << 30));
+    auto work = [&](int t) {
+        const int64_t lo = n_quads * t / nthreads, hi = n_quads * (t + 1) / nthreads;
+        for (int64_t q = lo; q < hi; ++q) {   // float32 first, then the subtraction, as the reference does (exact for counts below 2^24 either way)
+            const float c0 = (float)counts[4 * q];
+            x[4 * q] = c0;
+            x[4 * q + 1] = (float)counts[4 * q + 1] - c0;
+            x[4 * q + 2] = (float)counts[4 * q + 2] - c0;
+            x[4 * q + 3] = (float)counts[4 * q + 3] - c0;
+        }
+    };
+    if (nthreads <= 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int clair_host_counts_to_input_i16(const int16_t *counts, int64_t n_quads, float *x) { return counts_to_input(counts, n_quads, x); }
+extern "C" int clair_host_counts_to_input_i32(const int32_t *counts, int64_t n_quads, float *x) { return counts_to_input(counts, n_quads, x); }
+
 // CRC32C (Castagnoli, reflected polynomial 0x82F63B78) of a byte range, slicing-by-8: what the TensorFlow bundle format
 // protects its index blocks and tensor data with (clair_amd/tf_bundle.py masks it the LevelDB way).  Known answer:
 // "123456789" -> 0xE3069283.

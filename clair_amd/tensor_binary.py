@@ -39,40 +39,111 @@ def pack_records(ctg_name, centres, seqs, counts):
     return rec.tobytes()
 
 
+class InfoTable(object):
+    """The [[ctg, pos, seq], ...] list of one batch, kept as the record columns it came from.  Behaves like that list (len,
+    iteration, integer and slice indexing give the same lists of three strings) and lets the native decoder take the columns as
+    they are (`native_meta`) instead of 12 000 Python strings per batch that it would only join again."""
+
+    def __init__(self, ctg, ctg_len, pos, seq, seq_len):
+        self.ctg, self.ctg_len, self.pos, self.seq, self.seq_len = ctg, ctg_len, pos, seq, seq_len
+        self._rows = None
+
+    def __len__(self):
+        return len(self.pos)
+
+    def rows(self):
+        if self._rows is None:
+            self._rows = [[c[:cl].decode(), str(p), s[:sl].decode()] for c, cl, p, s, sl in
+                          zip(self.ctg.tolist(), self.ctg_len.tolist(), self.pos.tolist(), self.seq.tolist(), self.seq_len.tolist())]
+        return self._rows
+
+    def __getitem__(self, i):
+        return self.rows()[i]
+
+    def __iter__(self):
+        return iter(self.rows())
+
+    def __eq__(self, other):
+        return self.rows() == (other.rows() if isinstance(other, InfoTable) else other)
+
+    def native_meta(self):
+        """-> (meta bytes, tok int32 [n,6]) in the form clair_host_decode_rows takes: per candidate (offset, length) of contig,
+        decimal position and reference sequence inside `meta`, here fixed-width rows of 37 + 20 + 33 bytes."""
+        n = len(self)
+        width = MAX_CTG + 20 + 33
+        meta = np.zeros((n, width), dtype=np.uint8)
+        pos = self.pos.astype(np.int64)
+        if n and int(pos.min()) < 0:                  # never produced by this package; formatted the slow way
+            ptxt = np.char.encode(pos.astype("U20"), "ascii").astype("S20")
+            meta[:, MAX_CTG:MAX_CTG + 20] = np.frombuffer(ptxt.tobytes(), dtype=np.uint8).reshape(n, 20)
+            plen, pstart = np.char.str_len(ptxt), np.zeros(n, dtype=np.int64)
+        else:                                         # decimal digits right-aligned in the 20-byte field, 19 divisions for the whole batch
+            rest, digits = pos.copy(), meta[:, MAX_CTG:MAX_CTG + 20]
+            for k in range(19, -1, -1):
+                rest, d = np.divmod(rest, 10)
+                digits[:, k] = d + 48
+            plen = np.maximum(1, 20 - (digits != 48).argmax(axis=1)) if n else np.zeros(0, np.int64)
+            plen = np.where(pos == 0, 1, plen)
+            pstart = 20 - plen
+        meta[:, :MAX_CTG] = np.frombuffer(np.ascontiguousarray(self.ctg).tobytes(), dtype=np.uint8).reshape(n, MAX_CTG)
+        meta[:, MAX_CTG + 20:] = np.frombuffer(np.ascontiguousarray(self.seq).tobytes(), dtype=np.uint8).reshape(n, 33)
+        tok = np.empty((n, 6), dtype=np.int32)
+        base = np.arange(n, dtype=np.int64) * width
+        tok[:, 0] = base
+        tok[:, 1] = self.ctg_len
+        tok[:, 2] = base + MAX_CTG + pstart
+        tok[:, 3] = plen
+        tok[:, 4] = base + MAX_CTG + 20
+        tok[:, 5] = self.seq_len
+        return meta.tobytes(), tok
+
+
+_IUPAC_TABLE = np.zeros(256, dtype=bool)
+_IUPAC_TABLE[list(IUPAC)] = True
+
+
 def read_batches(stream, batch_size, first=b""):
     """Yield (X float32 [n,33,8,4], infos, counts int16 [n,33,8,4]) from a binary record stream positioned after MAGIC.
     Batching follows clair/utils.py:72-109: batch_size records are TAKEN per batch, those whose centre base is not an IUPAC
-    code are dropped from it, empty batches are skipped, progress goes to stderr."""
+    code are dropped from it, empty batches are skipped, progress goes to stderr.  infos is an InfoTable (list-like)."""
     processed = 0
-    pending = first
     want = batch_size * RECORD.itemsize
+    carry = first
     eof = False
-    while not eof or pending:
-        while not eof and len(pending) < want:
-            more = stream.read(want - len(pending))
+    while not eof or carry:
+        pieces, have = [carry] if carry else [], len(carry)
+        carry = b""
+        while not eof and have < want:
+            more = stream.read(want - have)
             if more:
-                pending += more
+                pieces.append(more)
+                have += len(more)
             else:
                 eof = True
-        take = min(len(pending), want) // RECORD.itemsize * RECORD.itemsize
+        pending = pieces[0] if len(pieces) == 1 else b"".join(pieces)
+        if len(pending) > want:                      # only a caller-supplied `first` can be longer than one batch
+            pending, carry = pending[:want], pending[want:]
+        take = len(pending) // RECORD.itemsize * RECORD.itemsize
         if take == 0:
             if pending:
                 raise ValueError("truncated binary tensor record (%d trailing bytes)" % len(pending))
             break
-        rec = np.frombuffer(pending[:take], dtype=RECORD)
-        pending = pending[take:]
-        seq = rec["seq"]
-        keep = np.fromiter((rec["seq_len"][i] > 16 and len(s) > 16 and s[16] in IUPAC for i, s in enumerate(seq)), dtype=bool,
-                           count=len(rec))
-        rec = rec[keep] if not keep.all() else rec
+        if take < len(pending):
+            if eof and not carry:
+                raise ValueError("truncated binary tensor record (%d trailing bytes)" % (len(pending) - take))
+            carry = pending[take:] + carry
+        rec = np.frombuffer(pending, dtype=RECORD, count=take // RECORD.itemsize)
+        seq_bytes = np.frombuffer(np.ascontiguousarray(rec["seq"]).tobytes(), dtype=np.uint8).reshape(len(rec), 33)
+        # a stored sequence shorter than 17 characters has no centre base (S33 fields are NUL padded: NUL is not an IUPAC code)
+        keep = (rec["seq_len"] > 16) & _IUPAC_TABLE[seq_bytes[:, 16]]
+        if not keep.all():
+            rec = rec[keep]
         n = len(rec)
         processed += n
         print("Processed %d tensors" % processed, file=sys.stderr)
         if n == 0:
             continue
         counts = np.ascontiguousarray(rec["counts"])
-        x = counts.astype(np.float32)
-        x[:, :, :, 1:] -= x[:, :, :, 0:1]
-        infos = [[c[:cl].decode(), str(p), s[:sl].decode()] for c, cl, p, s, sl in
-                 zip(rec["ctg"].tolist(), rec["ctg_len"].tolist(), rec["pos"].tolist(), rec["seq"].tolist(), rec["seq_len"].tolist())]
-        yield x, infos, counts
+        from clair_amd import _hostapi
+        x = _hostapi.counts_to_input(counts)
+        yield x, InfoTable(rec["ctg"].copy(), rec["ctg_len"].copy(), rec["pos"].copy(), rec["seq"].copy(), rec["seq_len"].copy()), counts

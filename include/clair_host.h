@@ -14,7 +14,7 @@
 extern "C" {
 #endif
 
-#define CLAIR_HOST_ABI_VERSION 3
+#define CLAIR_HOST_ABI_VERSION 4
 #define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
 
 int clair_host_abi_version(void);
@@ -24,6 +24,11 @@ const char *clair_host_last_error(void);
 int clair_host_threads(int work_items);
 /* CRC32C (Castagnoli) of a byte range -- the checksum of TensorFlow's bundle format (clair_amd/tf_bundle.py); "123456789" -> 0xE3069283 */
 uint32_t clair_host_crc32c(const uint8_t *data, int64_t n);
+
+/* raw pileup counts -> network input (clair/utils.py:96-98: X[:,:,:,1:] -= X[:,:,:,0:1] after the float32 conversion of :81-83):
+ * n_quads groups of four channels (33 x 8 per candidate); x[4q] = c[4q], x[4q+k] = c[4q+k] - c[4q].  int16 and int32 counts. */
+int clair_host_counts_to_input_i16(const int16_t *counts, int64_t n_quads, float *x);
+int clair_host_counts_to_input_i32(const int32_t *counts, int64_t n_quads, float *x);
 
 /* -- ingest: the parsing work of clair/utils.py:72-109 (tensor_generator_from) for one chunk of text ---------------
  * Record format (dataPrepScripts/CreateTensor.py:60-65): "ctg pos refseq33 v0 ... v1055", whitespace separated.

@@ -21,7 +21,7 @@ def test_host_header_symbols_are_exported():
     assert declared and sorted(_hostapi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.clair_host_abi_version() == 3
+    assert lib.clair_host_abi_version() == 4
 
 
 def _collect(gen, path, batch):
@@ -138,3 +138,73 @@ def test_native_decode_is_bypassed_where_it_does_not_apply():
     ens = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, True, None))
     assert ens.decode_batch(x, infos, Y) == ens.decode_batch_py(x, infos, Y)
     assert cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None)).decode_batch(x[:0], [], [y[:0] for y in Y]) == []
+
+
+class _Dribble(io.RawIOBase):
+    """A pipe-like stream: read(n) hands out at most `step` bytes."""
+
+    def __init__(self, data, step):
+        self.data, self.at, self.step = data, 0, step
+
+    def read(self, n=-1):
+        n = self.step if n < 0 else min(n, self.step)
+        out = self.data[self.at:self.at + n]
+        self.at += len(out)
+        return out
+
+
+def test_binary_record_reader_batches_like_the_text_reader_and_feeds_the_native_decoder_its_columns():
+    """tensor_binary.read_batches: batch_size records TAKEN per batch, non-IUPAC / missing centre bases dropped from it, ragged
+    last batch, short reads, a caller-supplied prefix, truncated tails rejected -- and the InfoTable it yields is the same list of
+    [ctg, pos, seq] the text reader builds, whose columns the native decoder takes as they are (byte-identical rows)."""
+    from clair_amd import call_var as cvar, tensor_binary
+    n = 1000
+    raw, infos = synth.synthetic_candidates(n, "ont", seed=5)
+    infos = [list(i) for i in infos]
+    for k in range(0, n, 37):
+        infos[k][2] = infos[k][2][:16] + "Z" + infos[k][2][17:]      # not an IUPAC code: dropped
+    for k in range(3, n, 101):
+        infos[k][2] = infos[k][2][:12]                               # no centre base at all: dropped
+    for k in range(7, n, 53):
+        infos[k][2] = infos[k][2][:16] + "N" + infos[k][2][17:]      # kept by the reader (IUPAC), skipped by the decoder
+    infos[11][1] = "123456789012"                                    # a long position
+    blob = b"".join(tensor_binary.pack_records("chr%d" % (k % 3), [int(infos[k][1])], [infos[k][2]], raw[k:k + 1]) for k in range(n))
+    kept = [k for k in range(n) if len(infos[k][2]) > 16 and infos[k][2][16] in "ACGTURYSWKMBDHVN"]
+    want_infos = [["chr%d" % (k % 3), infos[k][1], infos[k][2]] for k in kept]
+    for batch, step, first in ((64, 1 << 30, b""), (64, 999, b""), (300, 7000, blob[:5000]), (2000, 1 << 30, b"")):
+        with redirect_stderr(io.StringIO()):
+            got = list(tensor_binary.read_batches(_Dribble(blob[len(first):], step), batch, first=first))
+        taken = 0
+        for x, inf, counts in got:
+            lo = sum(1 for k in kept if k < taken)
+            taken += batch
+            hi = sum(1 for k in kept if k < taken)
+            assert len(inf) == hi - lo and list(inf) == want_infos[lo:hi] and inf[0] == want_infos[lo] and inf[1:3] == want_infos[lo + 1:lo + 3]
+            assert counts.dtype == np.int16 and np.array_equal(counts, raw[kept[lo:hi]])
+            assert np.array_equal(x, synth.to_model_input(raw[kept[lo:hi]]))
+        assert sum(len(g[1]) for g in got) == len(kept)
+    with pytest.raises(ValueError), redirect_stderr(io.StringIO()):
+        list(tensor_binary.read_batches(io.BytesIO(blob + b"tail"), 64))
+    # the native decoder over the record columns == over the list of strings
+    with redirect_stderr(io.StringIO()):
+        x, table, _ = next(tensor_binary.read_batches(io.BytesIO(blob), n))
+    rng = np.random.default_rng(3)
+    Y = [_random_probs(rng, len(table), k, 4.0) for k in (21, 3, 33, 33)]
+    dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
+    rows = dec.decode_batch(x, table, Y)
+    assert rows == dec.decode_batch(x, [list(i) for i in table], Y) and len(rows) > 800
+    assert rows == cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None), native=False).decode_batch(x, table, Y)
+
+
+def test_native_counts_to_input_equals_the_reference_arithmetic():
+    """clair_host_counts_to_input_*: float32 conversion, then channels 1..3 -= channel 0 (clair/utils.py:81-83, 96-98), for int16
+    and int32 counts including the extremes of the range."""
+    rng = np.random.default_rng(4)
+    for dtype, lo, hi in ((np.int16, -32768, 32767), (np.int32, -100000, 100000)):
+        c = rng.integers(lo, hi, size=(300, 33, 8, 4), endpoint=True).astype(dtype)
+        c[0] = hi
+        c[1] = lo
+        want = c.astype(np.float32)
+        want[:, :, :, 1:] -= want[:, :, :, 0:1]
+        assert np.array_equal(_hostapi.counts_to_input(c), want)
+    assert _hostapi.counts_to_input(np.zeros((0, 33, 8, 4), np.int16)).shape == (0, 33, 8, 4)
