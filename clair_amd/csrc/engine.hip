@@ -49,6 +49,7 @@ struct Slot {
     float *h_out = nullptr;   // pinned [max_batch][90]
     float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
     short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first clair_submit_counts
+    short *h_counts = nullptr;   // pinned [max_batch][1056]: staging of a caller's pageable count buffer (as h_x is for float input)
     // pending host outputs of a submit
     float *o_gt21 = nullptr, *o_gt = nullptr, *o_l1 = nullptr, *o_l2 = nullptr;
     int pending_n = 0;
@@ -186,6 +187,7 @@ void free_slot(Slot &s) {
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_x) (void)hipHostFree(s.h_x);
     if (s.d_counts) (void)hipFree(s.d_counts);
+    if (s.h_counts) (void)hipHostFree(s.h_counts);
     if (s.stream) (void)hipStreamDestroy(s.stream);
 }
 
@@ -505,7 +507,13 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
     Slot &s = e->slots[slot];
     if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
     const int n_pad = (n + 31) & ~31;
-    HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+    // A caller's pageable buffer goes through the slot's page-locked one: hipMemcpyAsync straight from pageable memory stages the
+    // copy itself and blocks the caller for milliseconds at these sizes (4.5 ms per 2 MB batch measured; tools/gpu/e2e_profile.sh)
+    if (x != s.h_x) {
+        if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+        memcpy(s.h_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float));
+    }
+    HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
     if (n_pad > n)
         HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
     if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
@@ -535,7 +543,9 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
     if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
     if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
     const int n_pad = (n + 31) & ~31;
-    HIP_TRY(e, hipMemcpyAsync(s.d_counts, counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
+    if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
+    memcpy(s.h_counts, counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short));   // page-locked staging, as in clair_submit
+    HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
     const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
     hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
     if (n_pad > n)
