@@ -14,6 +14,7 @@ Behaviour kept identical to the reference (pinned by tests/golden/ingest_* minte
     (possibly empty) chunk; empty chunks are not yielded                         utils.py:100-104
   * a partial last batch is yielded as X[:n]                                     utils.py:105
 """
+import os
 import shlex
 import sys
 from subprocess import PIPE, Popen
@@ -38,6 +39,14 @@ def setup_environment():
 def _open_source(tensor_file_path, binary=False):
     if tensor_file_path == "PIPE":
         return None, (sys.stdin.buffer if binary else sys.stdin)
+    if binary and os.path.isfile(tensor_file_path):
+        # `gzip -fdc` hands a file that is in none of the formats it knows through unchanged -- at ~400 MB/s of pipe, which bounds
+        # an uncompressed tensor file at 160 k candidates/s.  Such a file (not starting with gzip's 0x1f lead byte of the gzip /
+        # compress / pack / lzh formats, nor with pkzip's "PK") is opened directly: the same bytes.
+        with open(tensor_file_path, "rb") as f:
+            lead = f.read(2)
+        if lead and lead[:1] != b"\x1f" and lead != b"PK":
+            return None, open(tensor_file_path, "rb", buffering=8388608)
     proc = Popen(shlex.split("gzip -fdc %s" % tensor_file_path), stdout=PIPE,
                  bufsize=8388608, universal_newlines=not binary)
     return proc, proc.stdout
@@ -59,6 +68,8 @@ def tensor_generator_from(tensor_file_path, batch_size):
         if proc is not None:
             stream.close()
             proc.wait()
+        elif tensor_file_path != "PIPE":
+            stream.close()
         return
     chunks = queue.Queue(maxsize=4)
     if head:
@@ -104,6 +115,8 @@ def tensor_generator_from(tensor_file_path, batch_size):
     if proc is not None:
         stream.close()
         proc.wait()
+    elif tensor_file_path != "PIPE":
+        stream.close()
 
 
 def tensor_generator_from_py(tensor_file_path, batch_size):

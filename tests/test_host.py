@@ -58,6 +58,14 @@ def test_native_ingest_equals_python_ingest(tmp_path, n, batch):
     for (xg, ig), (xw, iw) in zip(got, want):
         assert xg.dtype == np.float32 and xg.tobytes() == xw.tobytes()
         assert ig == iw
+    # the same records as an uncompressed file (read directly instead of through `gzip -fdc`'s pass-through): the same batches
+    plain = str(tmp_path / "t.txt")
+    with open(plain, "w") as f:
+        f.write("\n".join(l.rstrip("\n") for l in lines))
+    got_plain, err_p = _collect(utils.tensor_generator_from, plain, batch)
+    assert err_p == err_w and len(got_plain) == len(want)
+    for (xg, ig), (xw, iw) in zip(got_plain, want):
+        assert xg.tobytes() == xw.tobytes() and ig == iw
 
 
 @pytest.mark.parametrize("mutation", ["short", "extra_head", "two_head", "bad_value", "short_seq", "blank"])
