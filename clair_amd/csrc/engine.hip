@@ -68,9 +68,10 @@ struct clair_engine {
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
     int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
                                // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
-    int lstm2_fused = -1;      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one slot
-                               // from 512 candidates on, where it shortens a pass by 2-8 % (104 us instead of 47 + 78 at batch 1024;
-                               // profiles/r02_lstm2_fused.txt); with batches in flight on other slots the two launches pack as well.  CLAIR_AMD_LSTM2_FUSED=0/1 forces
+    int lstm2_fused = -1;      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one or
+                               // two slots from 512 candidates on (one slot: 104 us instead of 47 + 78 at batch 1024, +8 % per pass; two slots:
+                               // 6.86 against 6.4 M/s; profiles/r02_lstm2_fused.txt); with three batches in flight the two launches pack
+                               // better (7.5 against 7.4 M/s).  CLAIR_AMD_LSTM2_FUSED=0/1 forces
     int fused_groups = 4;      // projection workgroup groups per XCD inside the fused launch (CLAIR_AMD_FUSED_GROUPS)
     int proj2_groups = 8;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 4 gate tiles x groups workgroups (see clair_engine_create)
     int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
@@ -228,7 +229,7 @@ int drain_timers(clair_engine *e) {
     return 0;
 }
 
-bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->slots.size() == 1); }
+bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->slots.size() <= 2); }
 bool use_lstm2_fused(const clair_engine *e, int ntiles) {   // pairs of tiles share a 64-row activation tile: even tile counts only
     if ((ntiles & 1) || !fused_possible(e)) return false;
     return e->lstm2_fused == 1 || ntiles >= 16;
