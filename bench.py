@@ -61,9 +61,9 @@ DESIGN_BYTES = {
 # MI355X_MICROARCH.md prescribes for gfx950), per batch size: profiles/*_pmc_hbm_traffic*.txt.  Not collected live: a counter
 # pass serialises kernels and cannot share a process with the timed run.
 PMC_TRAFFIC_BYTES = {
-    1024: {"source": "profiles/r02_ont_b1024_pmc_hbm_traffic.txt", "proj2": 181.5e6, "l4": 54.7e6, "tail": 16.1e6, "lstm2": 178.3e6, "lstm1": 46.0e6},
-    4096: {"source": "profiles/r02_ccs_b4096_pmc_hbm_traffic.txt", "proj2": 700.7e6, "l4": 213.1e6, "tail": 55.0e6, "lstm2": 702.4e6, "lstm1": 175.8e6},
-    8192: {"source": "profiles/r02_illumina_b8192_pmc_hbm_traffic.txt", "proj2": 1392.7e6, "l4": 399.9e6, "tail": 106.8e6, "lstm2": 1403.5e6, "lstm1": 351.4e6},
+    1024: {"source": "profiles/r02_ont_b1024_pmc_hbm_traffic.txt", "proj2": 181.6e6, "l4": 54.7e6, "tail": 16.1e6, "lstm2": 178.3e6, "lstm1": 46.0e6, "layer2_fused": 382.0e6},
+    4096: {"source": "profiles/r02_ccs_b4096_pmc_hbm_traffic.txt", "proj2": 700.7e6, "l4": 213.3e6, "tail": 55.0e6, "lstm2": 702.5e6, "lstm1": 175.8e6},
+    8192: {"source": "profiles/r02_illumina_b8192_pmc_hbm_traffic.txt", "proj2": 1392.8e6, "l4": 396.7e6, "tail": 106.8e6, "lstm2": 1403.3e6, "lstm1": 351.4e6},
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
 PEAK_F16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: f16/bf16 MFMA dense (AMD's 5 PF headline includes 2:1 sparsity)

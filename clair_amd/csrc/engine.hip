@@ -69,7 +69,7 @@ struct clair_engine {
     int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
                                // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
     int lstm2_fused = -1;      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one or
-                               // two slots from 512 candidates on (one slot: 104 us instead of 47 + 78 at batch 1024, +8 % per pass; two slots:
+                               // two slots for 512 .. 2048 candidates (one slot: 104 us instead of 47 + 78 at batch 1024, +8 % per pass; two slots:
                                // 6.86 against 6.4 M/s; profiles/r02_lstm2_fused.txt); with three batches in flight the two launches pack
                                // better (7.5 against 7.4 M/s).  CLAIR_AMD_LSTM2_FUSED=0/1 forces
     int fused_groups = 4;      // projection workgroup groups per XCD inside the fused launch (CLAIR_AMD_FUSED_GROUPS)
@@ -232,7 +232,8 @@ int drain_timers(clair_engine *e) {
 bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->slots.size() <= 2); }
 bool use_lstm2_fused(const clair_engine *e, int ntiles) {   // pairs of tiles share a 64-row activation tile: even tile counts only
     if ((ntiles & 1) || !fused_possible(e)) return false;
-    return e->lstm2_fused == 1 || ntiles >= 16;
+    return e->lstm2_fused == 1 || (ntiles >= 16 && ntiles <= 64);   // 512 .. 2048 candidates: beyond, every kernel fills the chip by itself and
+                                                                    // 128 projection workgroups are too few (batch 4096, one slot: 6.6 against 7.2 M/s)
 }
 size_t fuse_words(int max_pad) { return (size_t)2 * (max_pad / 32) * T_POS * 8; }                  // ticket words of the zx blocks
 size_t fuse_claims(const clair_engine *e) { return (size_t)32 * e->fused_groups + 32 * ((e->max_pad / 64 + 7) / 8); }   // one per workgroup of the largest launch

@@ -1,7 +1,9 @@
 #!/bin/sh
 # Round-2 profile of one benchmark configuration.  usage: profile_r02.sh <tag> <steps> <bench.py arguments ...>
 #   -> gpurun_out/r02_<tag>_{bench.json, kernel_stats.txt, pmc_hbm_traffic.txt, pmc_mfma_util.txt}   (copied into profiles/ afterwards)
-# Counter passes are separate rocprofv3 runs with --kernel-trace only (never with the hip/hsa trace domains).
+# Counter passes are separate rocprofv3 runs with --kernel-trace only (never with the hip/hsa trace domains).  The matrix-pipe pass runs one
+# slot so that every kernel has the chip to itself; it keeps the two layer-2 launches apart (CLAIR_AMD_LSTM2_FUSED=0), the kernels the
+# three-slot pipeline runs.
 TAG=$1; STEPS=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -18,7 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_summary.py traffic $O/pmc_r02_${TAG}_FETCH_SIZE/bench_results.db $O/pmc_r02_${TAG}_WRITE_SIZE/bench_results.db --batch $BATCH > $O/r02_${TAG}_pmc_hbm_traffic.txt 2>&1
 rm -rf $O/pmc_r02_${TAG}_sq
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/pmc_r02_${TAG}_sq -o bench -- env BENCH_WARM_STEPS=0 python $R/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline "$@" > $O/pmc_r02_${TAG}_sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/pmc_r02_${TAG}_sq -o bench -- env BENCH_WARM_STEPS=0 CLAIR_AMD_LSTM2_FUSED=0 python $R/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline "$@" > $O/pmc_r02_${TAG}_sq.log 2>&1
 python $R/tools/pmc_summary.py mfma $O/pmc_r02_${TAG}_sq/bench_results.db --batch $BATCH --groups 8 > $O/r02_${TAG}_pmc_mfma_util.txt 2>&1
 cd $R
 head -c 600 $O/r02_${TAG}_bench.json; echo; tail -12 $O/r02_${TAG}_kernel_stats.txt; cat $O/r02_${TAG}_pmc_hbm_traffic.txt $O/r02_${TAG}_pmc_mfma_util.txt
