@@ -40,7 +40,7 @@ def main():
     ck = weights.save_weights(os.path.join(tmp, "model"), weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1))[:-4]
     print("inputs: %.1f MB SAM, %d reads (%.0f s to generate)" % (len(body) / 1e6, body.count("\n"), time.time() - t0))
     out = os.path.join(tmp, "out.vcf")
-    for batch in (1024,):
+    for batch in (1024, 4096):
         t0 = time.time()
         r = subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--bam_fn", sam, "--ref_fn", fa, "--ctgName",
                             case["ctg"], "--samtools", fake, "--call_fn", out, "--batch_size", str(batch)], cwd=ROOT, capture_output=True, text=True)
