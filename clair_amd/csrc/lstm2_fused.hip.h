@@ -1,6 +1,9 @@
 // BiLSTM layer 2 as ONE launch: the input-projection GEMM (gemm_split.hip.h) and the recurrence (lstm32.hip.h) of a batch run side
-// by side, the projection handing its zx blocks to the recurrent workgroups through the XCD's L2 instead of a 138 MB round trip
-// through HBM (clair/model.py:443-450).
+// by side, the recurrent workgroups consuming each zx block as soon as the projection has written it (clair/model.py:443-450).
+// What it buys is TIME on handles with one or two slots (104 us instead of 47 + 78 at batch 1024); the bytes still make the trip:
+// the L2 does not allocate a full-line store that misses, so the block goes to memory and the reader's first touch brings it back
+// (fetch 208 MB + write 174 MB per 1024-batch against 186 + 173 for the two launches; DESIGN.md section 6,
+// profiles/r02_lstm2_fused.txt).
 //
 //   * workgroups [0, P) are projection workgroups, [P, P + C) recurrent ones.  Workgroups reach the CUs in id order and the
 //     projection never waits for anyone, so every block a recurrent workgroup waits for comes from a workgroup that is running or
@@ -10,9 +13,9 @@
 //     nothing).  So a workgroup takes its place from where it IS: XCD x = HW_REG_XCC_ID and its row blockIdx / 8 give the logical
 //     id 8 * (blockIdx / 8) + x -- the eight blocks of a row land on eight different XCDs and rows arrive in order on each.  Pair q
 //     of candidate tiles belongs to XCD q % 8: its projection items and its four recurrent workgroups (2 tiles x 2 directions) all
-//     carry logical ids = q mod 8, so the zx block written by a projection wave (non-temporal stores: the line stays in that
-//     XCD's L2) is read by a recurrent wave of the same XCD (non-temporal loads: L1 bypassed, L2 served) a few microseconds
-//     later.  zx still has its full-size buffer, so the bytes also leave L2 towards memory; what is saved is the read side.
+//     carry logical ids = q mod 8, so the zx block written by a projection wave is read by a recurrent wave of the same XCD
+//     (non-temporal loads: L1 bypassed), i.e. through the SAME L2 its stores went through: that L2 is what orders the block's
+//     stores (retired before the ticket is written) against the reader's loads (issued after the ticket is seen).
 //     Every workgroup CLAIMS its logical id (atomic exchange of the pass's ticket): a second claimant means the placement rule
 //     does not hold, *error is raised and the engine refuses the result; every wait is bounded (a block whose producer never
 //     came raises the same word after ~50 ms instead of hanging the GPU).
