@@ -30,7 +30,7 @@ from . import param
 IUPAC = frozenset("ACGTURYSWKMBDHVN")
 
 
-def candidate_positions(args):
+def candidate_positions(args, quiet=False):
     """Stage 1.  -> int64 positions (1-based, ascending for sorted alignments)."""
     from . import _hostapi
     if args.vcf_fn is not None:
@@ -67,7 +67,7 @@ def candidate_positions(args):
     view.wait()
     if view.returncode != 0:
         sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
-    if finder.reads == 0:
+    if finder.reads == 0 and not quiet:
         print("No read has been process, either the genome region you specified has no read cover, or please check the correctness of your BAM input (%s)."
               % args.bam_fn, file=sys.stderr)
     return np.concatenate(chunks) if chunks else np.zeros(0, np.int64)
@@ -104,9 +104,10 @@ def positions_from_vcf(vcf_fn, ctg_name, ctg_start, ctg_end):
     return np.array(out, dtype=np.int64)
 
 
-def tensor_batches(args, positions, batch_size):
+def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True):
     """Stage 2 as a generator of (X float32 [n,33,8,4], [[ctg, pos, refseq], ...]) -- what clair_amd.utils.tensor_generator_from
-    yields for the text records of the same windows."""
+    yields for the text records of the same windows.  read_flank = (left, right) widens the region the ALIGNMENTS are taken from
+    (not the candidates): a sub-range of a larger run needs the reads that touch only the flanks of its outermost windows."""
     from . import _hostapi
     seq, ref_start = ct.reference_sequence_from(args.samtools, args.ref_fn, args.ctgName, args.ctgStart, args.ctgEnd)
     if not seq:
@@ -117,7 +118,7 @@ def tensor_batches(args, positions, batch_size):
         positions = positions[(positions >= args.ctgStart) & (positions <= args.ctgEnd)]
     builder = _hostapi.PileupBuilder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1, positions,
                                      consider_left_edge=not args.stop_consider_left_edge, dcov=args.dcov)
-    region = "%s:%d-%d" % (args.ctgName, args.ctgStart, args.ctgEnd) if have_range else args.ctgName
+    region = "%s:%d-%d" % (args.ctgName, max(1, args.ctgStart - read_flank[0]), args.ctgEnd + read_flank[1]) if have_range else args.ctgName
     view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
                                text=False)
     total = 0
@@ -126,7 +127,8 @@ def tensor_batches(args, positions, batch_size):
     def emit(counts, infos):
         nonlocal total
         total += len(infos)
-        print("Processed %d tensors" % total, file=sys.stderr)
+        if progress:
+            print("Processed %d tensors" % total, file=sys.stderr)
         x = _hostapi.counts_to_input(counts)              # the decode reads depth and allele support from the tensor
         # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
         small = counts.astype(np.int16) if int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
@@ -174,6 +176,108 @@ def tensor_batches(args, positions, batch_size):
         sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
 
 
+WINDOW_FLANK = 33          # reads that touch only the flank of a sub-range's outermost windows (16 positions) must still be seen
+MIN_SPAN_PER_WORKER = 50000
+
+
+def contig_length(ref_fn, ctg_name):
+    with open(ref_fn + ".fai") as f:
+        for row in f:
+            col = row.split("\t")
+            if col[0] == ctg_name:
+                return int(col[1])
+    return None
+
+
+def front_end_workers(args):
+    """How many sub-ranges the two host stages are split into (--front_end_workers; default: by the CPUs this process may use)."""
+    if args.vcf_fn is not None:
+        return 1, None, None
+    have_range = args.ctgStart is not None and args.ctgEnd is not None
+    lo, hi = (args.ctgStart, args.ctgEnd) if have_range else (1, contig_length(args.ref_fn, args.ctgName) if os.path.isfile(args.ref_fn + ".fai") else None)
+    if hi is None:
+        return 1, None, None
+    want = args.front_end_workers
+    if want is None or want == 1:
+        return 1, None, None        # the default is the single pass: see --front_end_workers for when the split run can differ from it
+    if want <= 0:                   # 0 = by the CPUs this process may use
+        want = max(1, min(8, ingest_cpus() // 2))
+    want = max(1, min(want, (hi - lo + 1) // MIN_SPAN_PER_WORKER))
+    return want, lo, hi
+
+
+def ingest_cpus():
+    """CPUs this process may use: affinity mask, capped by a cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def parallel_front_end(args, batch_size, workers, lo, hi):
+    """Both host stages (candidate search, pileup windows) over `workers` consecutive sub-ranges of [lo, hi] at once, each on its
+    own thread with its own `samtools view` streams (the native cores release the GIL) -- the reference's process-per-chunk
+    fan-out (clair/callVarBamParallel.py:90-119) inside one process feeding one GPU.  Batches come out in position order: a
+    sub-range's batches are consumed when every earlier sub-range is done (bounded queues hold the others back).  Candidates
+    and windows are those of the unsplit run (a sub-range takes its alignments from WINDOW_FLANK positions beyond its INNER ends) as
+    long as CreateTensor's tuple budget does not run out: each sub-range has its own, like each chunk of callVarBamParallel."""
+    import copy
+    import queue
+    import threading
+    edges = [lo + (hi - lo + 1) * k // workers for k in range(workers)] + [hi + 1]
+    queues = [queue.Queue(maxsize=6) for _ in range(workers)]
+    counts = [0] * workers
+    stop = threading.Event()
+
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work(k):
+        sub = copy.copy(args)
+        sub.ctgStart, sub.ctgEnd = edges[k], edges[k + 1] - 1
+        try:
+            positions = candidate_positions(sub, quiet=True)
+            counts[k] = len(positions)
+            # the run's own outer ends keep the reference's region semantics (alignments of exactly ctgStart-ctgEnd, CreateTensor.py);
+            # on a whole contig they are the contig's ends
+            flank = (WINDOW_FLANK if k > 0 else 0, WINDOW_FLANK if k + 1 < workers else 0)
+            for batch in tensor_batches(sub, positions, batch_size, read_flank=flank, progress=False):
+                if not put(queues[k], batch):
+                    return
+            put(queues[k], None)
+        except BaseException:                       # sys.exit of a failing samtools included: handed to the consumer
+            put(queues[k], sys.exc_info())
+
+    threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(workers)]
+    for t in threads:
+        t.start()
+    total = 0
+    try:
+        for k in range(workers):
+            while True:
+                item = queues[k].get()
+                if item is None:
+                    break
+                if isinstance(item, tuple) and len(item) == 3 and isinstance(item[1], BaseException):
+                    raise item[1].with_traceback(item[2])
+                total += len(item[1])
+                print("Processed %d tensors" % total, file=sys.stderr)
+                yield item
+        logging.info("%d candidate sites" % sum(counts))
+    finally:
+        stop.set()
+
+
 def Run(args):
     if args.ctgName is None:
         sys.exit("--ctgName must be specified. You can call variants on multiple chromosomes simultaneously.")
@@ -187,8 +291,16 @@ def Run(args):
     logging.basicConfig(format="%(message)s", level=logging.INFO)
     cv.ingest.setup_environment()
 
-    positions = candidate_positions(args)
-    logging.info("%d candidate sites" % len(positions))
+    workers, lo, hi = front_end_workers(args)
+    if workers > 1:
+        def source(batch):
+            return parallel_front_end(args, batch, workers, lo, hi)
+    else:
+        positions = candidate_positions(args)
+        logging.info("%d candidate sites" % len(positions))
+
+        def source(batch):
+            return tensor_batches(args, positions, batch)
 
     config = cv.OutputConfig(
         is_show_reference=False, is_debug=args.debug,
@@ -210,7 +322,7 @@ def Run(args):
         except Exception as exc:
             sys.exit("[ERROR] %s" % exc)
         try:
-            cv.call_variants(args, m, decoder, writer, batch, generator=tensor_batches(args, positions, batch))
+            cv.call_variants(args, m, decoder, writer, batch, generator=source(batch))
         finally:
             m.close()
     finally:
@@ -254,6 +366,11 @@ def build_parser():
     add('--output_for_ensemble', action='store_true', help="write probabilities for ensembling instead of a VCF")
     # additions of this implementation
     add('--batch_size', type=int, default=None, help="candidates per forward pass, default: %d" % param.predictBatchSize)
+    add('--front_end_workers', type=int, default=None,
+        help="run the candidate search and the pileup over this many consecutive sub-ranges at once (threads, one pair of samtools streams each; "
+             "0 = half the usable CPUs, at most 8; at least 50 kb per sub-range).  Default 1: the single pass.  The split run yields the single "
+             "pass's candidates and windows EXCEPT where CreateTensor's 5 M-tuple budget runs out (candidates every few bases at high depth): every "
+             "sub-range has its own budget, as every chunk of callVarBamParallel has")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
     add('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
         help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")

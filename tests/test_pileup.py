@@ -304,6 +304,35 @@ def test_in_process_tensor_batches_equal_the_text_pipeline(region):
         assert [list(map(str, i)) for i in ig] == [list(map(str, i)) for i in iw]
 
 
+@pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
+@pytest.mark.parametrize("workers", [2, 5])
+def test_parallel_front_end_gives_the_windows_of_the_unsplit_run(region, workers, capfd):
+    """callVarBam's host stages over consecutive sub-ranges on threads (each with its own samtools streams, alignments taken from
+    33 positions beyond the sub-range) yield the candidates and windows of the single pass, in the same order -- also when a
+    worker's samtools dies (the failure reaches the consumer instead of reading as end of input)."""
+    from clair_amd import callVarBam
+    with tempfile.TemporaryDirectory() as tmp:
+        case, fa, sam = _bam_case(tmp, seed=307)
+        common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS] + region
+        args = callVarBam.build_parser().parse_args(common + ["--threshold", "0.15", "--minCoverage", "5", "--chkpnt_fn", "x", "--call_fn", "y"])
+        pos = callVarBam.candidate_positions(args)
+        want = list(callVarBam.tensor_batches(args, pos, 64))
+        lo, hi = (args.ctgStart, args.ctgEnd) if region else (1, callVarBam.contig_length(fa, case["ctg"]))
+        assert hi == (2500 if region else case["ref_len"])
+        capfd.readouterr()
+        got = list(callVarBam.parallel_front_end(args, 64, workers, lo, hi))
+        progress = [l for l in capfd.readouterr().err.splitlines() if l.startswith("Processed")]
+        bad = callVarBam.build_parser().parse_args(common + ["--chkpnt_fn", "x", "--call_fn", "y"])
+        bad.samtools = "%s %s" % (sys.executable, os.path.join(HERE, "no_such_tool.py"))
+        with pytest.raises(SystemExit):
+            list(callVarBam.parallel_front_end(bad, 64, workers, lo, hi))
+    cat = lambda batches, k: np.concatenate([b[k] for b in batches])  # noqa: E731
+    assert len(pos) > 100 and sum(len(b[1]) for b in got) == sum(len(b[1]) for b in want)
+    assert np.array_equal(cat(got, 0), cat(want, 0)) and np.array_equal(cat(got, 2), cat(want, 2))
+    assert [list(map(str, i)) for b in got for i in b[1]] == [list(map(str, i)) for b in want for i in b[1]]
+    assert progress[-1] == "Processed %d tensors" % sum(len(b[1]) for b in want)
+
+
 def test_vcf_sites_as_candidates():
     """--vcf_fn: the candidate stream = column 2 of what the reference's GetTruth prints (tests/golden/get_truth.json, minted by
     running dataPrepScripts/GetTruth.py here): '*' alternates add the base before, equal positions collapse, order as printed."""

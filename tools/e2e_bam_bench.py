@@ -40,10 +40,11 @@ def main():
     ck = weights.save_weights(os.path.join(tmp, "model"), weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1))[:-4]
     print("inputs: %.1f MB SAM, %d reads (%.0f s to generate)" % (len(body) / 1e6, body.count("\n"), time.time() - t0))
     out = os.path.join(tmp, "out.vcf")
-    for batch in (1024, 4096):
+    for batch, workers in ((1024, 1), (4096, 1), (4096, 4)):
         t0 = time.time()
         r = subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--bam_fn", sam, "--ref_fn", fa, "--ctgName",
-                            case["ctg"], "--samtools", fake, "--call_fn", out, "--batch_size", str(batch)], cwd=ROOT, capture_output=True, text=True)
+                            case["ctg"], "--samtools", fake, "--call_fn", out, "--batch_size", str(batch), "--front_end_workers", str(workers)],
+                           cwd=ROOT, capture_output=True, text=True)
         dt = time.time() - t0
         if r.returncode != 0:
             print(r.stderr[-2000:])
@@ -51,8 +52,8 @@ def main():
         tensors = [l for l in r.stderr.splitlines() if l.startswith("Processed")]
         n = int(tensors[-1].split()[1]) if tensors else 0
         rows = sum(1 for l in open(out) if not l.startswith("#"))
-        print("callVarBam, batch %d: %.2f s wall for %d candidate windows -> %d VCF rows: %.0f candidates/s end to end (one process, one GPU)"
-              % (batch, dt, n, rows, n / dt))
+        print("callVarBam, batch %d, %d front-end worker(s): %.2f s wall for %d candidate windows -> %d VCF rows: %.0f candidates/s end to end (one process, one GPU)"
+              % (batch, workers, dt, n, rows, n / dt))
         for l in r.stderr.splitlines():
             if "candidate sites" in l or "Total time" in l:
                 print("   ", l)
