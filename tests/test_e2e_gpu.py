@@ -157,3 +157,21 @@ def test_call_var_vcf_does_not_depend_on_the_kernel_selection(tmp_path):
     assert len(outs["default"].splitlines()) > 4000
     for name in ("unfused", "pair", "plain", "binary"):
         assert outs[name] == outs["default"], name
+
+
+def test_callVarBam_front_end_workers_write_the_single_pass_vcf(tmp_path, monkeypatch):
+    """callVarBam --front_end_workers 3 (both host stages over three sub-ranges on threads, batches consumed in position order)
+    writes the VCF of the single pass, whole contig and region."""
+    from clair_amd import callVarBam
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp, seed=97)
+    ck = _model(tmp)
+    monkeypatch.setattr(callVarBam, "MIN_SPAN_PER_WORKER", 300)       # the test contig is 3 kb; the CLI asks for 50 kb per sub-range
+    for region in ([], ["--ctgStart", "300", "--ctgEnd", "2500"]):
+        outs = []
+        for workers in ("1", "3"):
+            out = os.path.join(tmp, "w%s.vcf" % workers)
+            callVarBam.main(["--chkpnt_fn", ck, "--call_fn", out, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--bam_fn", sam,
+                             "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS, "--front_end_workers", workers] + region)
+            outs.append(open(out).read())
+        assert len(outs[0].splitlines()) > 30 and outs[0] == outs[1]
