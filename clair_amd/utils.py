@@ -36,6 +36,70 @@ def setup_environment():
     return None
 
 
+class _InflateReader(object):
+    """read(n) over a gzip file, inflated in-process (zlib, which releases the GIL): 340 MB/s of text where the `gzip -dc` child
+    delivers 180.  Members are concatenated and bytes behind the last member passed through as `gzip -fdc` does; a truncated file ends the stream
+    with gzip's complaint on stderr."""
+
+    def __init__(self, path):
+        import zlib
+        self._zlib = zlib
+        self._f = open(path, "rb", buffering=0)
+        self._d = zlib.decompressobj(16 + zlib.MAX_WBITS)
+        self._path = path
+        self._fresh = True          # no byte of the current member seen yet
+        self._done = False
+        self._raw = False           # past the last member: the rest of the file is passed through
+
+    def read(self, n=-1):
+        want = n if n is not None and n > 0 else 1 << 23
+        out = []
+        have = 0
+        while have < want and not self._done:
+            if self._raw:                                     # bytes behind the last member that are not a member: `gzip -f` copies them through
+                more = self._f.read(1 << 20)
+                if not more:
+                    self._done = True
+                    break
+                out.append(more)
+                have += len(more)
+                continue
+            if self._d.eof:                                   # the next member, if the bytes behind this one are one
+                rest = self._d.unused_data
+                if len(rest) < 2:
+                    rest += self._f.read(2 - len(rest))
+                self._d = self._zlib.decompressobj(16 + self._zlib.MAX_WBITS)
+                self._fresh = True
+                if rest:
+                    if rest[:2] != b"\x1f\x8b":
+                        self._raw = True
+                        out.append(rest)
+                        have += len(rest)
+                        continue
+                    chunk = self._d.decompress(rest, want - have)
+                    self._fresh = False
+                    if chunk:
+                        out.append(chunk)
+                        have += len(chunk)
+                    continue
+            pending = self._d.unconsumed_tail
+            raw = pending if pending else self._f.read(1 << 20)
+            if not raw:
+                if not self._fresh and not self._d.eof:
+                    sys.stderr.write("gzip: %s: unexpected end of file\n" % self._path)
+                self._done = True
+                break
+            self._fresh = False
+            chunk = self._d.decompress(raw, want - have)
+            if chunk:
+                out.append(chunk)
+                have += len(chunk)
+        return b"".join(out)
+
+    def close(self):
+        self._f.close()
+
+
 def _open_source(tensor_file_path, binary=False):
     if tensor_file_path == "PIPE":
         return None, (sys.stdin.buffer if binary else sys.stdin)
@@ -47,6 +111,8 @@ def _open_source(tensor_file_path, binary=False):
             lead = f.read(2)
         if lead and lead[:1] != b"\x1f" and lead != b"PK":
             return None, open(tensor_file_path, "rb", buffering=8388608)
+        if lead == b"\x1f\x8b":
+            return None, _InflateReader(tensor_file_path)
     proc = Popen(shlex.split("gzip -fdc %s" % tensor_file_path), stdout=PIPE,
                  bufsize=8388608, universal_newlines=not binary)
     return proc, proc.stdout

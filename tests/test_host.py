@@ -216,3 +216,31 @@ def test_native_counts_to_input_equals_the_reference_arithmetic():
         want[:, :, :, 1:] -= want[:, :, :, 0:1]
         assert np.array_equal(_hostapi.counts_to_input(c), want)
     assert _hostapi.counts_to_input(np.zeros((0, 33, 8, 4), np.int16)).shape == (0, 33, 8, 4)
+
+
+def test_in_process_inflate_reads_what_gzip_fdc_writes(tmp_path):
+    """utils._InflateReader (gz tensor files are inflated in-process) against the `gzip -fdc` child it replaces: one member, several
+    members (an empty one among them), bytes behind the last member (passed through by -f), an empty member alone; odd read sizes."""
+    import subprocess
+    rng = np.random.default_rng(0)
+    base = "".join("line %d %s\n" % (i, "x" * int(rng.integers(0, 200))) for i in range(20000)).encode()
+    cases = {"single": gzip.compress(base),
+             "multi": gzip.compress(base[:100000]) + gzip.compress(base[100000:300000]) + gzip.compress(b"") + gzip.compress(base[300000:]),
+             "trailing": gzip.compress(base[:5000]) + b"\0\0\0\0garbage", "trailing1": gzip.compress(base[:5000]) + b"x",
+             "trailing_big": gzip.compress(base[:5000]) + base[:1500000], "empty_member": gzip.compress(b"")}
+    for name, blob in cases.items():
+        path = str(tmp_path / (name + ".gz"))
+        with open(path, "wb") as f:
+            f.write(blob)
+        want = subprocess.run(["gzip", "-fdc", path], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        for n in (7, 1000, 1 << 23):
+            r = utils._InflateReader(path)
+            got = b""
+            while True:
+                c = r.read(n)
+                if not c:
+                    break
+                assert len(c) <= max(n, 2) or name.startswith("trailing")      # pass-through pieces come as read from the file
+                got += c
+            r.close()
+            assert got == want, (name, n)
