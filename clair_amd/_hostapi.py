@@ -82,9 +82,70 @@ def counts_to_input(counts):
     return x
 
 
+class MetaInfoTable(object):
+    """The [[ctg, pos, seq], ...] list of a batch of text records, kept as the bytes the parser found them in: `meta` holds the
+    three fields of every candidate back to back, tok[i] = (offset, length) x 3 into it -- the form clair_host_decode_rows takes, so
+    a batch reaches the native decoder without a Python string per field.  List-like: len, iteration, indexing and comparison give
+    the lists of three strings."""
+
+    def __init__(self, meta, tok):
+        self.meta, self.tok = meta, tok
+        self._rows = None
+
+    @classmethod
+    def from_chunk(cls, chunk, tok):
+        """Compact the fields tok points at inside `chunk` (a parse buffer of megabytes) into their own small buffer."""
+        k = len(tok)
+        lens = tok[:, 1::2].astype(np.int64).ravel()
+        starts = tok[:, 0::2].astype(np.int64).ravel()
+        before = np.cumsum(lens) - lens
+        index = np.repeat(starts - before, lens) + np.arange(int(lens.sum()), dtype=np.int64)
+        meta = np.frombuffer(chunk, dtype=np.uint8)[index].tobytes()
+        out = np.empty((k, 6), dtype=np.int32)
+        out[:, 0::2] = before.reshape(k, 3)
+        out[:, 1::2] = lens.reshape(k, 3)
+        return cls(meta, out)
+
+    @classmethod
+    def concat(cls, tables):
+        tables = [t for t in tables if len(t)]
+        if len(tables) == 1:
+            return tables[0]
+        if not tables:
+            return cls(b"", np.zeros((0, 6), dtype=np.int32))
+        shift, toks = 0, []
+        for t in tables:
+            tk = t.tok.copy()
+            tk[:, 0::2] += shift
+            toks.append(tk)
+            shift += len(t.meta)
+        return cls(b"".join(t.meta for t in tables), np.concatenate(toks))
+
+    def __len__(self):
+        return len(self.tok)
+
+    def rows(self):
+        if self._rows is None:
+            m = self.meta
+            self._rows = [[m[o[0]:o[0] + o[1]].decode(), m[o[2]:o[2] + o[3]].decode(), m[o[4]:o[4] + o[5]].decode()] for o in self.tok.tolist()]
+        return self._rows
+
+    def __getitem__(self, i):
+        return self.rows()[i]
+
+    def __iter__(self):
+        return iter(self.rows())
+
+    def __eq__(self, other):
+        return self.rows() == (other.rows() if hasattr(other, "rows") else other)
+
+    def native_meta(self):
+        return self.meta, self.tok
+
+
 def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):
     """Parse up to max_rows lines of `chunk` (bytes), starting at byte `offset`, into x_out[row0:] (float32 [*,1056],
-    C-contiguous).  -> (rows_taken, infos of the kept rows as [[ctg, pos, seq], ...], bytes_consumed)"""
+    C-contiguous).  -> (rows_taken, infos of the kept rows as a MetaInfoTable ([[ctg, pos, seq], ...]), bytes_consumed)"""
     lib = load()
     tok = np.empty((max(max_rows, 1), 6), dtype=np.int32)
     taken, kept, used = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
@@ -94,12 +155,9 @@ def parse_tensors(chunk, final, max_rows, x_out, row0, offset=0):
                                       ctypes.byref(taken), ctypes.byref(kept), ctypes.byref(used))
     if rc != 0:
         raise ValueError("malformed tensor record: " + lib.clair_host_last_error().decode())
-    infos = []
-    if kept.value:
-        t = (tok[:kept.value].astype(np.int64) + np.array([offset, 0, offset, 0, offset, 0], dtype=np.int64)).tolist()
-        for o in t:
-            infos.append([chunk[o[0]:o[0] + o[1]].decode(), chunk[o[2]:o[2] + o[3]].decode(), chunk[o[4]:o[4] + o[5]].decode()])
-    return taken.value, infos, used.value
+    t = tok[:kept.value].astype(np.int64)
+    t[:, 0::2] += offset
+    return taken.value, MetaInfoTable.from_chunk(chunk, t), used.value
 
 
 def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2, with_status=False):

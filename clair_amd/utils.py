@@ -154,7 +154,7 @@ def tensor_generator_from(tensor_file_path, batch_size):
     eof = exhausted = False
     while not exhausted:
         flat = np.empty((batch_size, N_VALUES), dtype=np.float32)
-        infos = []
+        pieces, kept = [], 0                     # MetaInfoTable pieces of this batch: the fields stay bytes until someone asks for strings
         taken = 0
         while taken < batch_size:
             need = batch_size - taken
@@ -168,16 +168,17 @@ def tensor_generator_from(tensor_file_path, batch_size):
             if off >= len(buf):                  # the reference's readline() returned '' (utils.py:75-77)
                 exhausted = True
                 break
-            t, inf, used = _hostapi.parse_tensors(buf, eof, need, flat, len(infos), off)
+            t, inf, used = _hostapi.parse_tensors(buf, eof, need, flat, kept, off)
             taken += t
-            infos.extend(inf)
+            pieces.append(inf)
+            kept += len(inf)
             off += used
             lines_ahead -= t
-        n = len(infos)
+        n = kept
         processed += n
         print("Processed %d tensors" % processed, file=sys.stderr)
         if n > 0:
-            yield flat.reshape(batch_size, N_POS, N_ROW, N_CH)[:n], infos
+            yield flat.reshape(batch_size, N_POS, N_ROW, N_CH)[:n], _hostapi.MetaInfoTable.concat(pieces)
     if proc is not None:
         stream.close()
         proc.wait()

@@ -244,3 +244,33 @@ def test_in_process_inflate_reads_what_gzip_fdc_writes(tmp_path):
                 got += c
             r.close()
             assert got == want, (name, n)
+
+
+def test_text_reader_hands_the_native_decoder_the_parsed_fields_as_bytes(tmp_path):
+    """utils.tensor_generator_from yields a MetaInfoTable (the ctg / pos / seq fields as the parser found them): list-like, and the
+    native decoder gives the same rows over it as over the list of strings -- across parse-buffer boundaries (batches spanning two
+    reads of the file) and with dropped rows."""
+    from clair_amd import call_var as cvar
+    n = 3000
+    raw, infos = synth.synthetic_candidates(n, "pacbio_ccs", seed=12)
+    lines = list(synth.tensor_records(raw, infos))
+    for k in range(0, n, 13):
+        cols = lines[k].split()
+        cols[2] = cols[2][:16] + "Z" + cols[2][17:]
+        lines[k] = " ".join(cols)
+    path = str(tmp_path / "t.txt")
+    with open(path, "w") as f:
+        f.write("\n".join(l.rstrip("\n") for l in lines) + "\n")
+    rng = np.random.default_rng(8)
+    dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
+    total = 0
+    with redirect_stderr(io.StringIO()):
+        for x, table in utils.tensor_generator_from(path, 700):
+            assert isinstance(table, _hostapi.MetaInfoTable) and len(table) == len(x)
+            as_list = [list(i) for i in table]
+            assert table == as_list and table[0] == as_list[0] and table[2:5] == as_list[2:5]
+            Y = [_random_probs(rng, len(x), k, 3.0) for k in (21, 3, 33, 33)]
+            rows = dec.decode_batch(x, table, Y)
+            assert rows == dec.decode_batch(x, as_list, Y) and len(rows) > 0.9 * len(x)
+            total += len(x)
+    assert total == n - len(range(0, n, 13))
