@@ -33,7 +33,7 @@ import os
 import sys
 from argparse import ArgumentParser
 from collections import namedtuple
-from threading import Thread
+from threading import Event, Thread
 from time import time
 
 import numpy as np
@@ -598,10 +598,15 @@ class VcfWriter(object):
 # drivers
 # =============================================================================================
 def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
-    """call_var.py:1312-1367.  Software pipeline per iteration: decode+write batch k-1, forward pass
-    of batch k (asynchronous on the GPU), parse batch k+1; rows appear in input order.  `generator` replaces the
-    --tensor_fn reader with another source of (X, infos) batches (clair_amd.callVarBam hands pileup arrays over); a third
-    element, the raw int16 counts of the same batch, is sent to the GPU instead of X when the model can take it."""
+    """call_var.py:1312-1367.  The reference runs three threads per iteration (parse batch k+1, forward pass of batch k, decode +
+    write batch k-1) and joins them every iteration; here the three stages are three long-lived threads joined by bounded queues --
+    the batch source on one, the GPU (as many batches in flight as the model has slots) on the caller's, decode + write on a
+    third -- so a stage never waits for the slowest of the other two to finish ITS current batch.  Rows appear in input order
+    (one decoder, first in first out).  `generator` replaces the --tensor_fn reader with another source of (X, infos) batches
+    (clair_amd.callVarBam hands pileup arrays over); a third element, the raw int16 counts of the same batch, is sent to the GPU
+    instead of X when the model can take it.  A failure on either helper thread (sys.exit of a failing upstream stage included)
+    stops the pipeline and is raised here: the reference's callVarBam checks its stages' exit codes (callVarBam.py:218-233)."""
+    import queue
     writer.write_header()
     batch_size = batch_size or param.predictBatchSize
     if generator is None:
@@ -609,58 +614,99 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     logging.info("Calling variants ...")
     t0 = time()
     use_async = hasattr(m, "submit") and hasattr(m, "wait")
-    loaded = []
+    n_slots = max(1, int(getattr(m, "n_slots", 2))) if use_async else 1
+    loaded = queue.Queue(maxsize=n_slots + 2)      # batches parsed ahead
+    finished = queue.Queue(maxsize=n_slots + 2)    # (batch, prediction) waiting to be decoded and written
+    failures = []                                  # exc_info of a stage that died on its helper thread
+    stop = Event()
+    END = object()
 
-    failures = []            # exc_info of a stage that died on its helper thread
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def get(q):
+        while True:
+            try:
+                return q.get(timeout=0.1)
+            except queue.Empty:
+                if stop.is_set():
+                    return END
 
     def load():
         try:
-            loaded.append(next(generator))
-        except StopIteration:
-            loaded.append(None)
-        except BaseException:          # sys.exit of a failing upstream stage (samtools, a malformed record) included:
-            failures.append(sys.exc_info())   # a thread would swallow it and the loop would read "end of input"
-            loaded.append(None)
+            for batch in generator:
+                if not put(loaded, batch):
+                    return
+        except BaseException:                      # a thread would swallow it and the consumer would read "end of input"
+            failures.append(sys.exc_info())
+            stop.set()
+        put(loaded, END)
 
-    def emit(batch, prediction):
+    def emit():
         try:
-            writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
+            while True:
+                item = get(finished)
+                if item is END:
+                    return
+                batch, prediction = item
+                writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
         except BaseException:
             failures.append(sys.exc_info())
+            stop.set()
 
     def reraise():
         if failures:
             _, exc, tb = failures[0]
             raise exc.with_traceback(tb)
 
-    load()
-    reraise()
-    current = loaded.pop()
-    finished = None          # (batch, prediction) waiting to be written
-    k = 0
-    while current is not None or finished is not None:
-        threads = []
-        slot = k % 2
-        if current is not None:
-            if use_async and len(current) > 2 and current[2] is not None and hasattr(m, "submit_counts"):
+    loader, emitter = Thread(target=load, daemon=True), Thread(target=emit, daemon=True)
+    loader.start()
+    emitter.start()
+    inflight = []                                  # (slot, batch) submitted to the GPU, oldest first
+
+    def retire():
+        slot, batch = inflight.pop(0)
+        prediction = m.wait(slot)
+        m.prediction = prediction
+        put(finished, (batch, prediction))
+
+    try:
+        k = 0
+        while not stop.is_set():
+            current = get(loaded)
+            if current is END:
+                break
+            if not use_async:
+                prediction = m.predict(current[0])
+                m.prediction = prediction
+                put(finished, (current, prediction))
+                continue
+            if len(inflight) == n_slots:
+                retire()
+            slot = k % n_slots
+            if len(current) > 2 and current[2] is not None and hasattr(m, "submit_counts"):
                 m.submit_counts(slot, current[2])
-            elif use_async:
+            else:
                 m.submit(slot, current[0])
-            threads.append(Thread(target=load))
-        if finished is not None:
-            threads.append(Thread(target=emit, args=finished))
-        for t in threads:
-            t.start()
-        prediction = None
-        if current is not None:
-            prediction = m.wait(slot) if use_async else m.predict(current[0])
-            m.prediction = prediction
-        for t in threads:
-            t.join()
-        reraise()            # the reference's callVarBam checks its stages' exit codes (callVarBam.py:218-233); here they are threads
-        finished = (current, prediction) if current is not None else None
-        current = loaded.pop() if loaded else None
-        k += 1
+            inflight.append((slot, current))
+            k += 1
+        while inflight and not stop.is_set():
+            retire()
+    except BaseException:
+        stop.set()
+        raise
+    finally:
+        put(finished, END)
+        emitter.join()
+        stop.set()
+        loader.join(timeout=5.0)
+    reraise()
     logging.info("Total time elapsed: %.2f s" % (time() - t0))
 
 
