@@ -249,6 +249,18 @@ class PileupBuilder(object):
         raw = seqs.tobytes()
         return centres, [raw[i * 34:i * 34 + 34].split(b"\0", 1)[0].decode("latin-1") for i in range(n)], counts
 
+    def take_columns(self, max_rows=None):
+        """take_arrays without a Python string per window: -> (centres int64 [n], refseq bytes uint8 [n,34] NUL-terminated,
+        counts int32 [n,33,8,4])"""
+        n = self.pending() if max_rows is None else min(self.pending(), int(max_rows))
+        centres = np.empty(n, dtype=np.int64)
+        seqs = np.zeros((n, 34), dtype=np.uint8)
+        counts = np.empty((n, 33, 8, 4), dtype=np.int32)
+        taken = ctypes.c_int64(0)
+        if n:
+            self._lib.clair_host_pileup_take(self._h, n, centres.ctypes.data, seqs.ctypes.data, counts.ctypes.data, ctypes.byref(taken))
+        return centres, seqs, counts
+
     def take(self):
         centres, seqs, counts = self.take_arrays()
         return [(int(c), s, counts[i]) for i, (c, s) in enumerate(zip(centres, seqs))]

@@ -121,41 +121,50 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
     region = "%s:%d-%d" % (args.ctgName, max(1, args.ctgStart - read_flank[0]), args.ctgEnd + read_flank[1]) if have_range else args.ctgName
     view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
                                text=False)
+    from .tensor_binary import MAX_CTG, InfoTable, _IUPAC_TABLE
     total = 0
-    held_c, held_info, held = [], [], 0
+    ctg_bytes = args.ctgName.encode()
+    use_table = len(ctg_bytes) <= MAX_CTG           # the column form of [[ctg, pos, refseq], ...] (no Python string per window)
+    held = [[], [], []]                             # centres, refseq bytes [n,34], counts of windows not yet handed out
+    held_n = 0
 
-    def emit(counts, infos):
+    def emit(centres, seqs, counts):
         nonlocal total
-        total += len(infos)
+        n = len(centres)
+        total += n
         if progress:
             print("Processed %d tensors" % total, file=sys.stderr)
+        if use_table:
+            seq_col = np.ascontiguousarray(seqs[:, :33]).view("S33").ravel()
+            infos = InfoTable(np.full(n, ctg_bytes, dtype="S%d" % MAX_CTG), np.full(n, len(ctg_bytes), dtype=np.uint8), centres, seq_col,
+                              (seqs[:, :33] != 0).sum(axis=1).astype(np.uint8))
+        else:
+            raw = seqs.tobytes()
+            infos = [[args.ctgName, str(c), raw[i * 34:i * 34 + 34].split(b"\0", 1)[0].decode("latin-1")] for i, c in enumerate(centres.tolist())]
         x = _hostapi.counts_to_input(counts)              # the decode reads depth and allele support from the tensor
         # the GPU takes the raw counts (half the bytes on the host link) when they fit int16
         small = counts.astype(np.int16) if int(counts.max()) <= 32767 and int(counts.min()) >= -32768 else None
         return x, infos, small
 
     def drain(final):
-        nonlocal held_c, held_info, held
+        nonlocal held, held_n
         while builder.pending():
-            centres, seqs, counts = builder.take_arrays(batch_size)     # at most one batch per take: every copy below is O(batch)
-            keep = np.fromiter((len(s) > 16 and s[16] in IUPAC for s in seqs), dtype=bool, count=len(seqs))
+            centres, seqs, counts = builder.take_columns(batch_size)    # at most one batch per take: every copy below is O(batch)
+            keep = _IUPAC_TABLE[seqs[:, 16]]                             # a refseq shorter than 17 has NUL there: not an IUPAC code
             if not keep.all():
-                counts = counts[keep]
-                held_info.extend([args.ctgName, str(int(c)), s] for c, s, k in zip(centres, seqs, keep) if k)
-            else:
-                held_info.extend([args.ctgName, str(c), s] for c, s in zip(centres.tolist(), seqs))
-            held_c.append(counts)
-            held += len(counts)
-            if held >= batch_size:
-                c = np.concatenate(held_c) if len(held_c) > 1 else held_c[0]
-                rest = c[batch_size:]
-                infos, held_info = held_info[:batch_size], held_info[batch_size:]
-                held_c, held = ([rest] if len(rest) else []), len(rest)
-                yield emit(c[:batch_size], infos)
-        if final and held > 0:
-            c = np.concatenate(held_c) if len(held_c) > 1 else held_c[0]
-            infos, held_info, held_c, held = held_info, [], [], 0
-            yield emit(c, infos)
+                centres, seqs, counts = centres[keep], seqs[keep], counts[keep]
+            for col, piece in zip(held, (centres, seqs, counts)):
+                col.append(piece)
+            held_n += len(centres)
+            if held_n >= batch_size:
+                cols = [np.concatenate(c) if len(c) > 1 else c[0] for c in held]
+                held = [[c[batch_size:]] if held_n > batch_size else [] for c in cols]
+                held_n -= batch_size
+                yield emit(*(c[:batch_size] for c in cols))
+        if final and held_n > 0:
+            cols = [np.concatenate(c) if len(c) > 1 else c[0] for c in held]
+            held, held_n = [[], [], []], 0
+            yield emit(*cols)
 
     tail = None
     while True:
