@@ -40,7 +40,18 @@ def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print):
             for g, o in zip(got, eng.predict(x[i:i + batch])):
                 g[i:i + o.shape[0]] = o
         want = c_oracle.forward(w, x)
-        worst = max(worst, max(float(np.abs(g - t).max()) for g, t in zip(got, want)))
+        chunk_worst = max(float(np.abs(g - t).max()) for g, t in zip(got, want))
+        if chunk_worst > 1e-5:      # beyond the tolerance: which side moved?  (re-run the candidate's batch, re-evaluate the oracle on it alone)
+            k = int(np.argmax([float(np.abs(g - t).max()) for g, t in zip(got, want)]))
+            i = int(np.argmax(np.abs(got[k] - want[k]).max(axis=1)))
+            b0 = i // batch * batch
+            again = eng.predict(x[b0:b0 + batch])
+            alone32 = c_oracle.forward(w, x[i:i + 1])
+            alone64 = c_oracle.forward(w, x[i:i + 1], dtype=np.float64)
+            log("  !! %s chunk at %d: candidate %d output %d: |hip - oracle| %.2e;  hip again: |again - first| %.2e;  oracle alone: |alone32 - chunk32| %.2e, "
+                "|hip - alone32| %.2e, |hip - alone64| %.2e" % (platform, c0, i, k, chunk_worst, float(np.abs(again[k][i - b0] - got[k][i]).max()),
+                float(np.abs(alone32[k][0] - want[k][i]).max()), float(np.abs(got[k][i] - alone32[k][0]).max()), float(np.abs(got[k][i] - alone64[k][0]).max())))
+        worst = max(worst, chunk_worst)
         rows_g = dec.decode_batch(x, infos, got)
         rows_w = dec.decode_batch(x, infos, want)
         assert len(rows_g) == len(rows_w)
