@@ -158,6 +158,38 @@ def test_fused_layer2_launch_with_batches_in_flight(synth_weights, monkeypatch):
     assert np.array_equal(out["0"], out["1"])
 
 
+def test_outputs_do_not_depend_on_the_execution_mode(synth_weights):
+    """The same 16 384 candidates through every slots x batch-size combination (which selects the kernels: two launches or the fused
+    one, one- or two-tile LSTM2, 128 or 256 projection workgroups), three passes each: every output must equal the first pass of
+    the first mode BIT for bit -- a candidate's arithmetic does not depend on the batch it sits in (tools/gpu/cross_mode_stress.py
+    is the long form: 315 M candidate evaluations without a difference)."""
+    from clair_amd import _capi
+    n = 16384
+    x, _ = synth.synthetic_input(n, "ont", seed=4242)
+    ref = None
+    for slots, batch in ((3, 1024), (3, 4096), (1, 1024), (2, 2048), (1, 4096), (3, 8192), (2, 1024), (3, 512)):
+        eng = _capi.Engine(device=0, max_batch=batch, n_slots=slots)
+        try:
+            eng.load_weights(synth_weights)
+            xd, od = eng.dataset_alloc(n)
+            try:
+                eng.dataset_upload(xd, 0, x)
+                for rep in range(3):
+                    for b in range(n // batch):
+                        eng.run_resident(b % slots, xd, od, b * batch, batch)
+                    eng.sync()
+                    out = eng.dataset_download(od, 0, n)
+                    if ref is None:
+                        ref = out.copy()
+                    assert np.array_equal(out, ref), (slots, batch, rep)
+            finally:
+                eng.dataset_free(xd, od)
+        finally:
+            eng.close()
+    for g, w_ in zip(_capi.split_outputs(ref[:512]), _oracle(synth_weights, x[:512])):
+        assert np.abs(g - w_).max() <= PROB_TOL
+
+
 def _sweep_cells():
     import os
     import sys
