@@ -15,10 +15,13 @@ runs --steps batches.  `--scaling strong --candidates M`: a fixed set of M candi
 whole-genome configs[3]) is dealt in contiguous blocks of whole batches; --steps is then derived.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- the dominant kernel (most chip time: the LSTM2 input projection, gemm_split_kernel): SURVEY.md 8(d)
-                  algorithmic FLOP per launch / its mean HIP-event duration IN the multi-stream configuration of the
-                  timed loop / the 2.5 PFLOP/s dense f16 MFMA peak.  `executed_frac` counts the three fp16 MFMAs the
-                  2-way split issues per product; `alone_*` is the same kernel with nothing else on the chip.
+  roofline     -- the dominant kernel = the one with the most chip time (stand-alone duration x share of the 256 CUs its grid
+                  occupies) in THIS run's own per-kernel table: SURVEY.md 8(d) algorithmic FLOP per launch / its mean
+                  HIP-event duration IN the multi-stream configuration of the timed loop / the 2.5 PFLOP/s dense f16 MFMA
+                  peak.  `executed_frac` counts the three fp16 MFMAs the 2-way split issues per product; `alone_*` is the
+                  same kernel with nothing else on the chip; `kernels` carries the same fractions for every kernel of the
+                  pass; `traffic` comes from profiles/pmc_traffic.json and is null unless that table was measured on exactly
+                  the kernel sources this run executes (clair_amd/build.py: csrc_digest).
   cpu_baseline -- the blocked CPU port of the same forward pass (oracle/clair_cpu_port.c when present, else
                   oracle/clair_oracle.c) timed on the host cores of this box on a bounded sample (N=1 only).
 """
@@ -57,21 +60,42 @@ DESIGN_BYTES = {
     "l4": 33 * 256 * 4 + 16 * 192 * 4,
     "tail": 16 * 192 * 4 + 90 * 4,
 }
-# HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
-# MI355X_MICROARCH.md prescribes for gfx950), per batch size: profiles/*_pmc_hbm_traffic*.txt.  Not collected live: a counter
-# pass serialises kernels and cannot share a process with the timed run.
-PMC_TRAFFIC_BYTES = {
-    1024: {"source": "profiles/r02_ont_b1024_pmc_hbm_traffic.txt", "proj2": 181.6e6, "l4": 54.7e6, "tail": 16.1e6, "lstm2": 178.3e6, "lstm1": 46.0e6, "layer2_fused": 382.0e6},
-    4096: {"source": "profiles/r02_ccs_b4096_pmc_hbm_traffic.txt", "proj2": 700.7e6, "l4": 213.3e6, "tail": 55.0e6, "lstm2": 702.5e6, "lstm1": 175.8e6},
-    8192: {"source": "profiles/r02_illumina_b8192_pmc_hbm_traffic.txt", "proj2": 1392.8e6, "l4": 396.7e6, "tail": 106.8e6, "lstm2": 1403.3e6, "lstm1": 351.4e6},
-}
+# HBM bytes per launch come from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+# MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py traffic --json writes profiles/pmc_traffic.json).  Not collected
+# live: a counter pass serialises kernels and cannot share a process with the timed run.  Every entry is stamped with the digest of
+# the kernel sources it was measured on; an entry measured on other sources is NOT reported (traffic: null).
+PMC_TABLE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def load_pmc(batch, fused):
+    """({kernel: bytes per launch}, provenance string) for this batch size, or (None, why not)."""
+    from clair_amd import build
+    try:
+        doc = json.load(open(PMC_TABLE))
+    except (OSError, ValueError) as e:
+        return None, "no PMC table (%s)" % e
+    entry = doc.get("entries", {}).get(str(batch))
+    if entry is None:
+        return None, "profiles/pmc_traffic.json has no entry for batch %d" % batch
+    here = build.csrc_digest()
+    if entry.get("csrc_digest") != here:
+        return None, "profiles/pmc_traffic.json batch %d was measured on kernel sources %s (git %s); this run executes %s: not reported" % (
+            batch, entry.get("csrc_digest"), entry.get("git"), here)
+    table = dict(entry.get("kernels", {}))
+    if fused:
+        if "layer2_fused" not in entry.get("fused", {}):
+            return None, "profiles/pmc_traffic.json batch %d has no entry for the fused layer-2 launch" % batch
+        table.pop("proj2", None)
+        table["lstm2"] = entry["fused"]["layer2_fused"]
+    return table, "%s (kernel sources %s)" % (entry.get("source"), here)
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
 PEAK_F16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: f16/bf16 MFMA dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 WARM_STEPS = int(os.environ.get("BENCH_WARM_STEPS", "256"))   # untimed device warm-up before the contract's W warm-up steps
 SPLIT_TERMS = 3                         # fp16 MFMAs executed per algorithmic fp32 product (2-way split, common.hip.h)
 PLATFORM = {"ont": "ONT 122HD34", "pacbio_ccs": "PacBio CCS 15", "illumina": "Illumina 12345"}
-DOMINANT = "proj2"                      # most chip time (duration x CU share); checked against the measured table below
 
 
 def parse_args(argv=None):
@@ -91,10 +115,23 @@ def parse_args(argv=None):
 
 
 def spawn_and_relay(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU), relay rank 0's JSON line."""
-    procs = shard.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU), relay rank 0's JSON line; every rank's
+    stderr comes through line by line with a "[rank r]" prefix."""
+    import threading
+    procs = shard.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, stderr_pipe=True)
+
+    def relay(r, pipe):
+        for line in iter(pipe.readline, b""):
+            sys.stderr.write("[rank %d] %s" % (r, line.decode(errors="replace")))
+            sys.stderr.flush()
+
+    threads = [threading.Thread(target=relay, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
     out = procs[0].stdout.read().decode()
     rcs = [p.wait() for p in procs]
+    for t in threads:
+        t.join(timeout=5)
     sys.stdout.write(out)
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
@@ -145,6 +182,16 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     group = shard.NodeGroup()          # RCCL through the C ABI when WORLD_SIZE > 1
+    try:
+        rc = run_ranked(args, group, json_fd)
+    except BaseException:
+        group.close(barrier=False)     # unwinding: the peers may be gone, do not wait for them
+        raise
+    group.close()
+    return rc
+
+
+def run_ranked(args, group, json_fd):
     rank, world, local_rank = group.rank, group.world, group.local_rank
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d\n" % (args.gpus, world, world))
@@ -157,18 +204,20 @@ def main():
     eng.load_weights(w)
 
     steps = args.steps
+    mine_candidates = args.steps * batch
     if args.scaling == "strong":
-        _, mine = shard.shard_batches(args.candidates, batch, rank, world)
-        steps = (mine + batch - 1) // batch
+        _, mine_candidates = shard.shard_batches(args.candidates, batch, rank, world)
+        steps = (mine_candidates + batch - 1) // batch
     steps_max = int(round(group.max_float(steps)))
     nuniq = max(1, min(args.unique_batches, steps_max + args.warmup))
     x, infos = synth.synthetic_input(nuniq * batch, args.platform, seed=20250928 + rank)
     xd, od = eng.dataset_alloc(nuniq * batch)
     eng.dataset_upload(xd, 0, x)
+    last_n = mine_candidates - (steps - 1) * batch if steps else 0       # strong scaling: the set's ragged last batch is run ragged
 
-    def run(k):
+    def run(k, ragged_last=False):
         for i in range(k):
-            eng.run_resident(i % streams, xd, od, (i % nuniq) * batch, batch)
+            eng.run_resident(i % streams, xd, od, (i % nuniq) * batch, last_n if ragged_last and i == k - 1 else batch)
 
     # device warm-up outside the contract's W warm-up steps: first-touch of the workspaces, clock ramp, code upload
     device_warm = max(0, WARM_STEPS - args.warmup)
@@ -181,18 +230,38 @@ def main():
     group.barrier()
     eng.sync()
     t0 = time.perf_counter()
-    run(steps)
+    run(steps, ragged_last=True)
     eng.sync()
     mine_s = time.perf_counter() - t0
     group.barrier()
     elapsed = group.max_float(mine_s)          # the slowest rank defines the job time
     per_rank_s = group.gather_floats(mine_s)
     per_rank_steps = [int(round(v)) for v in group.gather_floats(steps)]
+    per_rank_candidates = [int(round(v)) for v in group.gather_floats(mine_candidates)]
+    rccl_ranks = int(round(sum(group.gather_floats(1.0 if group.transport == "rccl" else 0.0))))
 
-    # The same loop again, same streams, with a HIP-event pair around the dominant kernel only (two marker packets per
-    # forward pass): its duration in the configuration the timed region ran in -- what roofline.frac is computed from.
-    fused = eng.kernel_workgroups(batch)["proj2"] == 0      # layer 2 as one launch (CLAIR_AMD_LSTM2_FUSED=1): its events carry id "lstm2"
-    dominant = "lstm2" if fused else DOMINANT
+    # Per-kernel tables, outside the timed region.  (a) the same loop, same streams, every kernel bracketed by HIP events (ten marker
+    # packets per pass); (b) the same on ONE stream, so that a kernel's HIP-event duration is its own ("alone").
+    fused = eng.kernel_workgroups(batch)["proj2"] == 0      # layer 2 as one launch: its events carry id "lstm2"
+    eng.timing_enable(True)
+    eng.timing_reset()
+    run(steps)
+    eng.sync()
+    times = eng.kernel_times()
+    iso_steps = min(steps, 32)
+    eng.timing_reset()
+    for i in range(iso_steps):
+        eng.run_resident(0, xd, od, (i % nuniq) * batch, batch)
+    eng.sync()
+    times_iso = eng.kernel_times()
+    wgs = eng.kernel_workgroups(batch)
+    active = [k for k in _capi.KERNEL_NAMES if times_iso[k][1]]
+    cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in active}
+    alone_ms = {k: times_iso[k][0] / times_iso[k][1] for k in active}
+    chip_time = {k: alone_ms[k] * cu_share[k] for k in active}
+    # (c) the dominant kernel = most chip time in table (b), MEASURED in this run; the loop again with a HIP-event pair around that
+    # kernel only (two marker packets per pass): its duration in the configuration the timed region ran in = roofline.frac
+    dominant = max(chip_time, key=chip_time.get)
     eng.timing_enable(only=[dominant])
     eng.timing_reset()
     t1 = time.perf_counter()
@@ -200,19 +269,6 @@ def main():
     eng.sync()
     elapsed_dom = time.perf_counter() - t1
     dom_ms, dom_cnt = eng.kernel_times()[dominant]
-    # ... with every kernel bracketed (ten marker packets per pass): the per-kernel table
-    eng.timing_enable(True)
-    eng.timing_reset()
-    run(steps)
-    eng.sync()
-    times = eng.kernel_times()
-    # ... and on ONE stream, so that a kernel's HIP-event duration is its own ("alone")
-    iso_steps = min(steps, 32)
-    eng.timing_reset()
-    for i in range(iso_steps):
-        eng.run_resident(0, xd, od, (i % nuniq) * batch, batch)
-    eng.sync()
-    times_iso = eng.kernel_times()
     eng.timing_enable(False)
 
     # parity spot check of one resident batch against the oracle (outside the timed region)
@@ -221,6 +277,9 @@ def main():
         from clair_amd import call_var as cvar
         from oracle import c_oracle
         ns = min(1024, batch * nuniq)
+        eng.run_resident(0, xd, od, 0, min(ns, batch))
+        eng.sync()
+        ns = min(ns, batch)
         got = _capi.split_outputs(eng.dataset_download(od, 0, ns))
         want = c_oracle.forward(w, x[:ns])
         parity = max(float(np.abs(g - t_).max()) for g, t_ in zip(got, want))
@@ -235,47 +294,67 @@ def main():
 
     rc = 0
     if rank == 0:
-        total = sum(per_rank_steps) * batch
+        total = sum(per_rank_candidates)          # real candidates: a shard's ragged last batch counts what it holds
         value = total / elapsed
+        kflop = dict(KERNEL_FLOP)
+        if fused:
+            kflop["lstm2"] = KERNEL_FLOP["proj2"] + KERNEL_FLOP["lstm2"]
+        design = dict(DESIGN_BYTES)
+        if fused:
+            design["lstm2"] = 33 * 256 * 4 + 33 * 1024 * 4 + 33 * 256 * 4
+        pmc, pmc_note = load_pmc(batch, fused)
         kern = {k: {"ms_mean": (round(ms / cnt, 5) if cnt else None), "launches": cnt} for k, (ms, cnt) in times.items()}
-        kern_iso = {k: round(ms / cnt, 5) if cnt else None for k, (ms, cnt) in times_iso.items()}
-        wgs = eng.kernel_workgroups(batch)
-        cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in times_iso}
-        chip_time = {k: times_iso[k][0] / max(times_iso[k][1], 1) * cu_share[k] for k in times_iso}
+        kern_iso = {k: round(alone_ms[k], 5) if k in alone_ms else None for k in times_iso}
+
+        def frac(flop, ms):
+            return flop / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if ms else None
+
+        per_kernel = {}
+        for k in active:
+            in_ms = times[k][0] / times[k][1] if times[k][1] else None
+            fl = kflop[k] * batch
+            per_kernel[k] = {"algorithmic_flop_per_launch": fl, "in_flight_ms": round(in_ms, 5) if in_ms else None, "alone_ms": round(alone_ms[k], 5),
+                             "frac": round(frac(fl, in_ms), 4) if in_ms else None, "alone_frac": round(frac(fl, alone_ms[k]), 4),
+                             "workgroups": wgs[k], "cu_share": round(cu_share[k], 4),
+                             "chip_time_share_alone": round(chip_time[k] / max(sum(chip_time.values()), 1e-12), 3),
+                             "traffic": round(pmc[k]) if pmc and k in pmc else None, "design_bytes_per_launch": design[k] * batch}
         dom = dominant
-        dom_ms_mean = dom_ms / max(dom_cnt, 1)                        # in the multi-stream run
-        alone_ms = times_iso[dom][0] / max(times_iso[dom][1], 1)
-        flop_cand = KERNEL_FLOP["proj2"] + KERNEL_FLOP["lstm2"] if fused else KERNEL_FLOP[dom]
-        flop = flop_cand * batch
+        dom_ms_mean = dom_ms / max(dom_cnt, 1)                        # in the multi-stream run, events on this kernel only
+        flop = kflop[dom] * batch
         tf = flop / (dom_ms_mean * 1e-3) / 1e12
-        tf_alone = flop / (alone_ms * 1e-3) / 1e12
-        pmc = PMC_TRAFFIC_BYTES.get(batch) or {k: (v * batch / 1024 if k != "source" else v + " (batch 1024, scaled by batch/1024)")
-                                                 for k, v in PMC_TRAFFIC_BYTES[1024].items()}
-        traffic = pmc.get("layer2_fused" if fused else dom)
+        tf_alone = flop / (alone_ms[dom] * 1e-3) / 1e12
+        traffic = pmc.get(dom) if pmc else None
+        names = {"lstm1": "lstm32_kernel<true>", "proj2": "gemm_split_kernel", "lstm2": "lstm2_fused_kernel (proj2 + lstm2 in one launch)" if fused else "lstm32_kernel<false> / lstm32_pair_kernel",
+                 "l4": "l3l4_kernel", "tail": "tail_kernel"}
         roof = {
-            "bound": "mfma", "kernel": "layer2_fused (proj2 + lstm2 in one launch)" if fused else dom, "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "bound": "mfma", "kernel": "%s (%s)" % (dom, names.get(dom, dom)), "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": round(traffic) if traffic else None,
-            "traffic_source": pmc["source"],
-            "definition": "SURVEY.md 8(d) algorithmic FLOP of the kernel per launch (%d per candidate x batch) / its mean HIP-event "
-                          "duration with %d batches in flight (the timed loop repeated with events around this kernel only) / dense f16 MFMA peak"
-                          % (flop_cand, streams),
+            "traffic_source": pmc_note,
+            "definition": "dominant kernel = most chip time (stand-alone HIP-event duration x share of the 256 CUs its grid occupies) in this run's own "
+                          "table (`kernels`); frac = SURVEY.md 8(d) algorithmic FLOP of that kernel per launch (%d per candidate x batch) / its mean "
+                          "HIP-event duration with %d batches in flight (the timed loop repeated with events around this kernel only) / dense f16 MFMA peak"
+                          % (kflop[dom], streams),
             "kernel_ms": round(dom_ms_mean, 5), "launches": dom_cnt, "algorithmic_flop_per_launch": flop,
             "executed_frac": round(tf * SPLIT_TERMS / PEAK_F16_MFMA_TFLOPS, 4),
             "executed_note": "matmuls run as a 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
-            "alone_kernel_ms": round(alone_ms, 5), "alone_frac": round(tf_alone / PEAK_F16_MFMA_TFLOPS, 4),
+            "alone_kernel_ms": round(alone_ms[dom], 5), "alone_frac": round(tf_alone / PEAK_F16_MFMA_TFLOPS, 4),
             "workgroups": wgs[dom], "cu_share": round(cu_share[dom], 4),
             "hbm_gbs_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9, 1) if traffic else None,
             "hbm_frac_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None,
-            "design_bytes_per_launch": (33 * 256 * 4 + 33 * 1024 * 4 + 33 * 256 * 4 if fused else DESIGN_BYTES[dom]) * batch,
-            "chip_time_share_alone": {k: round(v / max(sum(chip_time.values()), 1e-12), 3) for k, v in chip_time.items() if v},
+            "design_bytes_per_launch": design[dom] * batch,
+            "kernels": per_kernel,
             "value_with_events_on_this_kernel": round(steps * batch / elapsed_dom, 1),
         }
         path_tf = value / world * FLOP_PER_CANDIDATE / 1e12
+        n_gpus = rccl_ranks if world > 1 else 1
+        if world > 1 and rccl_ranks != world:
+            sys.stderr.write("bench.py: %d of %d ranks hold an RCCL communicator; reporting n_gpus=%d\n" % (rccl_ranks, world, rccl_ranks))
+            rc = 1
         out = {
             "metric": "candidate sites/sec (whole node)",
             "value": round(value, 1),
             "unit": "candidates/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": steps_max,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(steps_max, 1) * 1e3, 4),
@@ -291,9 +370,9 @@ def main():
                        "device_warm_steps": device_warm,
                        "device_warm_note": "untimed steps before the contract's --warmup (clock ramp, first touch); BENCH_WARM_STEPS=0 removes them",
                        "collective": "none on the data path; RCCL (clair_comm_*) for the weight broadcast, barrier and timers" if world > 1 else "none (1 rank)",
-                       "transport": group.transport},
-            "per_rank": [{"rank": r, "steps": s_, "seconds": round(t_, 6), "candidates_per_s": round(s_ * batch / t_, 1) if t_ > 0 else None}
-                         for r, (s_, t_) in enumerate(zip(per_rank_steps, per_rank_s))],
+                       "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None},
+            "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None}
+                         for r, (s_, c_, t_) in enumerate(zip(per_rank_steps, per_rank_candidates, per_rank_s))],
             "roofline": roof,
             "roofline_path": {"achieved": round(path_tf, 2), "unit": "TFLOP/s per GPU (algorithmic, 40 386 432 FLOP / candidate)",
                               "frac_of_f16_mfma": round(path_tf / PEAK_F16_MFMA_TFLOPS, 4),
@@ -301,7 +380,7 @@ def main():
                               "frac_of_fp32_mfma": round(path_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                               "algorithmic_hbm_gbs": round(value / world * BYTES_PER_CANDIDATE / 1e9, 2),
                               "algorithmic_hbm_frac": round(value / world * BYTES_PER_CANDIDATE / 1e9 / PEAK_HBM_GBS, 6),
-                              "measured_traffic_bytes_per_candidate": round(sum(v for k, v in pmc.items() if k != "source") / batch)},
+                              "measured_traffic_bytes_per_candidate": round(sum(pmc[k] for k in active if k in pmc) / batch) if pmc else None},
             "kernels_in_flight_ms": kern,
             "kernels_alone_ms": kern_iso,
             "parity_max_abs_err": parity,
@@ -313,7 +392,6 @@ def main():
 
     eng.dataset_free(xd, od)
     eng.close()
-    group.close()
     return rc
 
 

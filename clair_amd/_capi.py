@@ -20,30 +20,35 @@ SYMBOLS = (
     "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
-    "clair_debug_read",
-    "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_last_error", "clair_comm_barrier",
+    "clair_debug_read", "clair_engine_counter",
+    "clair_comm_preflight", "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_last_error", "clair_comm_barrier",
     "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail")
 
 _lib = None
+_libs = {}
 
 
 class EngineError(RuntimeError):
     pass
 
 
-def load():
+def load(path=None):
     """Load libclair_amd.so (CDLL: calls release the GIL, as TF's session.run does for the
-    reference's predict thread, clair/call_var.py:1343)."""
+    reference's predict thread, clair/call_var.py:1343).  `path` names another BUILD of the same sources (the wait-all check
+    build of tools/gpu/waitall_compare.py); it never names a different implementation."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
+    if path is not None and path in _libs:
+        return _libs[path]
+    lib_path = path or LIB_PATH
+    if not os.path.isfile(lib_path):
         raise EngineError(
             "%s not found: build the HIP extension first (python -m clair_amd.build, or "
-            "__graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "__graft_entry__.build()). There is no CPU fallback." % lib_path)
+    lib = ctypes.CDLL(lib_path)
     c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     lib.clair_abi_version.restype = c_int
     lib.clair_device_count.restype = c_int
@@ -70,6 +75,8 @@ def load():
     lib.clair_timing_reset.argtypes = [c_vp]
     lib.clair_kernel_workgroups.argtypes = [c_vp, c_int, c_vp]
     lib.clair_debug_read.argtypes = [c_vp, c_int, c_int, c_vp, c_i64]
+    lib.clair_engine_counter.argtypes = [c_vp, c_int, ctypes.POINTER(c_i64)]
+    lib.clair_comm_preflight.argtypes = [c_int]
     lib.clair_comm_unique_id.argtypes = [c_vp]
     lib.clair_comm_create.argtypes = [c_int, c_int, c_int, c_vp, ctypes.POINTER(c_vp)]
     lib.clair_comm_destroy.argtypes = [c_vp]
@@ -85,7 +92,10 @@ def load():
         fn = getattr(lib, name)
         if name not in ("clair_last_error", "clair_engine_destroy", "clair_comm_last_error", "clair_comm_destroy"):
             fn.restype = c_int
-    _lib = lib
+    if path is None:
+        _lib = lib
+    else:
+        _libs[path] = lib
     return lib
 
 
@@ -96,8 +106,8 @@ def _ptr(a):
 class Engine(object):
     """Thin object wrapper over one clair_engine_t."""
 
-    def __init__(self, device=0, max_batch=1024, n_slots=1):
-        self._lib = load()
+    def __init__(self, device=0, max_batch=1024, n_slots=1, lib_path=None):
+        self._lib = load(lib_path)
         self._h = ctypes.c_void_p()
         self.max_batch = int(max_batch)
         self.n_slots = int(n_slots)
@@ -227,6 +237,12 @@ class Engine(object):
         wg = np.zeros(len(KERNEL_NAMES), dtype=np.int32)
         self._check(self._lib.clair_kernel_workgroups(self._h, int(n), _ptr(wg)), "clair_kernel_workgroups")
         return {k: int(wg[i]) for i, k in enumerate(KERNEL_NAMES)}
+
+    def counter(self, name):
+        """Event counters of the handle: "fused_launches", "fused_recoveries" (include/clair_amd.h: clair_engine_counter)."""
+        v = ctypes.c_int64()
+        self._check(self._lib.clair_engine_counter(self._h, ("fused_launches", "fused_recoveries").index(name), ctypes.byref(v)), "clair_engine_counter")
+        return int(v.value)
 
     def debug_read(self, slot, which, shape):
         out = np.empty(shape, dtype=np.float32)

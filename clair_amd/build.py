@@ -13,6 +13,18 @@ OUT = os.path.join(HERE, "libclair_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+def csrc_digest(root=None):
+    """sha256 over the kernel sources and the launch code (csrc/*.hip.h + engine.hip; names and bytes, sorted): what a
+    measurement of "this build" is stamped with (profiles/pmc_traffic.json, bench.py)."""
+    import hashlib
+    root = root or os.path.join(HERE, "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith(".hip.h") or f == "engine.hip":
+            h.update(f.encode() + b"\0" + open(os.path.join(root, f), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.isfile(OUT):
         return True
@@ -48,5 +60,19 @@ def build(force=False, verbose=False):
     return OUT
 
 
+WAITALL_OUT = os.path.join(HERE, "libclair_amd_waitall.so")
+
+
+def build_waitall():
+    """The CHECK build of the same sources (-DCLAIR_WAIT_ALL, csrc/common.hip.h): every hand-counted wait becomes a full one and the
+    memory, LDS and matrix pipes are drained after every hand-placed MFMA.  Only tools/gpu/waitall_compare.py loads it."""
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-DCLAIR_WAIT_ALL"]
+                          + SRCS + ["-o", WAITALL_OUT, "-ldl"])
+    return WAITALL_OUT
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--waitall" in sys.argv:
+        print(build_waitall())
+    else:
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -115,6 +115,20 @@ int clair_comm_unique_id(uint8_t *id) {
     return 0;
 }
 
+int clair_comm_preflight(int device) {
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0)
+        return cfail(nullptr, "no HIP device available (hipGetDeviceCount: %s); RCCL needs one GPU per rank", hipGetErrorString(err));
+    if (device < 0 || device >= ndev) return cfail(nullptr, "device %d out of range [0,%d)", device, ndev);
+    if (!rccl().error.empty()) return cfail(nullptr, "%s", rccl().error.c_str());
+    COMM_HIP(nullptr, hipSetDevice(device));
+    void *probe = nullptr;
+    COMM_HIP(nullptr, hipMalloc(&probe, 256));
+    COMM_HIP(nullptr, hipFree(probe));
+    return 0;
+}
+
 int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_comm_t **out) {
     if (!out) return cfail(nullptr, "out is NULL");
     *out = nullptr;

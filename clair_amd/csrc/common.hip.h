@@ -92,6 +92,21 @@ __device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
 
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// Hand-counted waits.  The production build waits for exactly the vector-memory operations a point depends on (CLAIR_VMWAIT(n):
+// "at most n still outstanding").  The CHECK build (-DCLAIR_WAIT_ALL, clair_amd/build.py: build_waitall -> libclair_amd_waitall.so)
+// waits for everything at every such point AND drains memory, LDS and the matrix pipe after every hand-placed MFMA
+// (CLAIR_DBG_FENCE: 48 wait states cover the 8-pass MFMA plus every documented read-after-MFMA hazard), so that none of the
+// timing arguments in gemm_split.hip.h / lstm32*.hip.h is load-bearing in it.  tools/gpu/waitall_compare.py runs both builds on
+// the same candidates and compares their outputs bit for bit: a latent ordering hazard in the production build shows up as a
+// difference.  This is a test instrument, not a second code path: nothing ships or runs it outside that tool.
+#ifdef CLAIR_WAIT_ALL
+#define CLAIR_VMWAIT(n) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define CLAIR_DBG_FENCE() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+#else
+#define CLAIR_VMWAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define CLAIR_DBG_FENCE()
+#endif
+
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).
 // Inline asm on purpose: hipcc then neither counts it nor fences later ds_reads of the same __shared__
 // array behind it with vmcnt(0).  M0 carries the LDS base and is compiler-reserved, so it is

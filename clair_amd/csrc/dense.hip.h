@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
             const float *src = p.a2 + ((size_t)t * p.n_pad + n0 + cand) * 256 + cg * 16 + (lane & 3) * 4;
             glds16((const f32x4 *)src, lds0 + piece * 1024);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CLAIR_VMWAIT(0);
         __syncthreads();
         // A operands: candidate li (of block mb), positions t = lq*9 + kk, this wave's four channels per float4
         f32x4 av[2][9];

@@ -109,7 +109,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int a = 0; a < 4; ++a) asm volatile("" : "+v"(bq[mi][a]));   // hipcc waits for its own loads HERE, not after the DMA prologue
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on this kernel counts its vector-memory operations itself
+    CLAIR_VMWAIT(0);   // from here on this kernel counts its vector-memory operations itself
 
     // Staging.  A phase is 2 slabs x 2 planes x 64 rows x 64 B = 16 one-KiB DMA pieces; wave w moves the four pieces of
     // plane-slab w (slab w>>1, plane w&1): piece j = rows 16j .. 16j+15, lane l -> LDS row 16j + l/4, 16-byte slot l%4, which
@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
     for (int P = 0; P < 3; ++P)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma(P, j);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    CLAIR_VMWAIT(8);
     __syncthreads();
     fread(xa, 0, 0);
 
@@ -207,6 +207,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
                 if (ph == 0 && m < 4) mfma32_av_first(acc[mi][ni], Wr[mi][0][1], xa[0][0][ni], bias16[mi]);
                 else mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + kk][term == 0 ? 1 : 0], xa[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
+                CLAIR_DBG_FENCE();
                 if (m < 8) fread1(xb, ph, 1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -215,7 +216,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
             // the previous tile, THEN phase P+2's four pieces.  "At most four outstanding" therefore covers the pieces and the
             // stores before them; it does not lean on how stores and loads retire relative to each other ("at most twelve" in the
             // phases that carry stores would), and costs nothing measurable (tools/gpu/ab_libs.sh: 7.57-7.60 against 7.54-7.61 M/s).
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            CLAIR_VMWAIT(4);
             __syncthreads();
             // fused: at most phase P+2's four pieces are outstanding here, so in phase 3 the previous tile's stores (issued in phases
             // 0 and 1) have retired -- its blocks are in L2; the two ticket stores are older than this slab's DMA pieces, so the
@@ -228,6 +229,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
                 const int kk = m / 12, term = (m % 12) / 4, mi = (m >> 1) & 1, ni = m & 1;
                 mfma32_av(acc[mi][ni], Wr[mi][ph * 4 + 2 + kk][term == 0 ? 1 : 0], xb[kk][term == 1 ? 1 : 0][ni]);
                 __builtin_amdgcn_sched_barrier(0);
+                CLAIR_DBG_FENCE();
                 if (m < 8) fread1(xa, (ph + 1) & 3, 0, m);
                 if (ph < 2 && m >= 1 && m <= 8 && it > 0) store_piece(accs[SET ^ 1], xt_prev, ph * 8 + m - 1);
                 if (m >= 10 && m < 18 && (m & 1) == 0) dma(P + 3, (m - 10) >> 1);
@@ -250,7 +252,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
             if (last & 1) store_piece(accs[1], xt, j); else store_piece(accs[0], xt, j);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the end still target this workgroup's LDS
+    CLAIR_VMWAIT(0);   // the clamped prefetches past the end still target this workgroup's LDS
     if (FUSED) publish(xt_of(n_my - 1));
 }
 

@@ -229,14 +229,24 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
         const unsigned long long want = ((unsigned long long)fz.ticket << 32) | fz.ticket;
         const unsigned long long *fp = fl_base + (size_t)(d ? T_POS - 1 - s : s) * 4;
         unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)fl_next), hi = __builtin_amdgcn_readfirstlane((unsigned)(fl_next >> 32));
-        if ((((unsigned long long)hi << 32) | lo) == want) return;
-        const long long deadline = wall_clock64() + 5000000;   // 100 MHz: 50 ms, three orders of magnitude beyond any honest wait
-        while ((((unsigned long long)hi << 32) | lo) != want) {
-            __builtin_amdgcn_s_sleep(2);
-            const unsigned long long v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lo = __builtin_amdgcn_readfirstlane((unsigned)v); hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-            if (wall_clock64() > deadline) { if (lane == 0) *fz.error = 1u; break; }
+        if ((((unsigned long long)hi << 32) | lo) != want) {
+            // Bounded: 50 ms at 100 MHz is three orders of magnitude beyond any honest wait.  A queue that was descheduled for longer
+            // (several processes on one GPU) runs it out; the engine then re-runs the pass on the two-launch path (engine.hip:
+            // recover_fused), it does not fail.
+            const long long deadline = wall_clock64() + 5000000;
+            while ((((unsigned long long)hi << 32) | lo) != want) {
+                __builtin_amdgcn_s_sleep(2);
+                const unsigned long long v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = __builtin_amdgcn_readfirstlane((unsigned)v); hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+                if (wall_clock64() > deadline) { if (lane == 0) *fz.error = 1u; break; }
+            }
         }
+        // acquire side of the hand-off: nothing this CU may hold of the block (vector L1) survives the sighting of its ticket.  Free
+        // here: the only vector-memory operations in flight are older than a step.  The release side is the producer's in-order
+        // retirement of its stores into the L2 this wave reads through, then its ticket (gemm_split.hip.h: publish); an agent-scope
+        // release there would write back the XCD's whole L2 per ticket (measured: 29 -> 68 us), which is why the hand-off is
+        // confined to ONE L2 and the placement that guarantees it is checked per launch (lstm2_fused.hip.h: claims).
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
     // ---- h_s (both planes complete in LDS) -> HBM, as four pieces per thread laid out so that every wave-level store is one
     //      contiguous run per row (a thread-per-row-chunk map made each store touch 64 quarter-filled 64-byte segments and cost
@@ -380,6 +390,7 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
     // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), and in block 0 the copy-out of h_{s-1}.
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
+    CLAIR_DBG_FENCE();                                                                                            \
     if (FUSED && (B) == 0 && (M) == 2) { flag_wait(s + 1); flag_fetch(s + 2); }                                   \
     if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
     if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, ((B) > 0 ? (B) - 1 : 0))                                                     \
@@ -424,6 +435,7 @@ _Pragma("unroll")                                                               
         const int xb = q / 6, kk = (q % 6) / 3, term = q % 3;                                                     \
         mfma32_vv(xacc[xb], wxa[xb & 1][kk][term == 0 ? 1 : 0], term == 1 ? xl[kk] : xh[kk]);                     \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
+        CLAIR_DBG_FENCE();                                                                                        \
         if ((GATES) && q >= 1) L32_GAP(q, 3)                                                                      \
         if ((GATES) && q == 8) load_seed(xacc[3], 0, 3);                                                          \
         if (q == 5) load_wx(wxa[0], 2);                                                                           \

@@ -180,6 +180,7 @@ _Pragma("unroll")                                                               
             if (m == 0) mfma32_av_first(acc[(b) & 1], Aw[b][kk][1], hf[kk][0], zold);                             \
             else mfma32_av(acc[(b) & 1], Aw[b][kk][term == 0 ? 1 : 0], hf[kk][term == 1 ? 1 : 0]);                \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
+            CLAIR_DBG_FENCE();                                                                                    \
             if (m == 3) load_seed(zq[b], Y, sy, b);   /* after the keep-alive below: the refill can land in the registers it replaces */ \
             if ((b) == 0 && m >= 1) P2_GAP(m, Y, 3, ypar)                                                         \
             if ((b) > 0 && m >= 1) P2_GAP(m, X, (b) - 1, s & 1)                                                   \

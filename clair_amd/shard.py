@@ -22,7 +22,6 @@ share the launcher as parent and MASTER_PORT itself is taken by the launcher's s
 No torch anywhere in this module.
 """
 import os
-import pickle
 import socket
 import struct
 import tempfile
@@ -54,9 +53,89 @@ def rendezvous_path():
     return os.path.join(tempfile.gettempdir(), "clair_amd_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
 
 
+# -- wire format of the bootstrap / CPU transport ------------------------------------------------------------------------------------
+# Fixed framing, no pickle: a peer on 127.0.0.1 can make a rank parse bytes, never run code.  frame = b"CLSH" | kind u8 | 3 pad |
+# payload length u64 | payload.  kinds: 0 None, 1 int64, 2 bytes, 3 utf-8 string, 4 ndarray (dtype code u8, ndim u8, 6 pad, dims
+# int64 x ndim, raw C-order bytes), 5 list / 6 tuple (count u32, then that many frames).  Before any frame a connecting rank
+# presents the 32-character token rank 0 wrote next to its port in the (0600, owner-checked) rendezvous file.
+_MAGIC = b"CLSH"
+_DTYPES = {0: np.dtype("<f4"), 1: np.dtype("<f8"), 2: np.dtype("<i8"), 3: np.dtype("u1"), 4: np.dtype("<i4")}
+_DTYPE_CODES = {v: k for k, v in _DTYPES.items()}
+_MAX_PAYLOAD = 1 << 36
+_TOKEN_BYTES = 32
+
+
+def _encode(obj):
+    if obj is None:
+        kind, payload = 0, b""
+    elif isinstance(obj, (bool, int, np.integer)):
+        kind, payload = 1, struct.pack("<q", int(obj))
+    elif isinstance(obj, (bytes, bytearray)):
+        kind, payload = 2, bytes(obj)
+    elif isinstance(obj, str):
+        kind, payload = 3, obj.encode("utf-8")
+    elif isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        dt = a.dtype.newbyteorder("<") if a.dtype.byteorder == ">" else a.dtype
+        if np.dtype(dt) not in _DTYPE_CODES:
+            raise TypeError("shard transport carries float32/float64/int64/int32/uint8 arrays, not %s" % a.dtype)
+        a = a.astype(dt, copy=False)
+        kind = 4
+        payload = struct.pack("<BB6x", _DTYPE_CODES[np.dtype(dt)], a.ndim) + struct.pack("<%dq" % a.ndim, *a.shape) + a.tobytes()
+    elif isinstance(obj, (list, tuple)):
+        kind = 5 if isinstance(obj, list) else 6
+        payload = struct.pack("<I", len(obj)) + b"".join(_encode(o) for o in obj)
+    else:
+        raise TypeError("shard transport cannot carry %r" % type(obj))
+    return _MAGIC + struct.pack("<B3xQ", kind, len(payload)) + payload
+
+
+def _decode(buf, at=0):
+    """One frame of `buf` starting at `at` -> (object, next offset).  Raises ValueError on anything malformed."""
+    if len(buf) - at < 16 or bytes(buf[at:at + 4]) != _MAGIC:
+        raise ValueError("bootstrap: bad frame header")
+    kind, n = struct.unpack_from("<B3xQ", buf, at + 4)
+    at += 16
+    if n > len(buf) - at:
+        raise ValueError("bootstrap: truncated frame")
+    body, nxt = memoryview(buf)[at:at + n], at + n
+    if kind == 0 and n == 0:
+        return None, nxt
+    if kind == 1 and n == 8:
+        return struct.unpack("<q", body)[0], nxt
+    if kind == 2:
+        return bytes(body), nxt
+    if kind == 3:
+        return bytes(body).decode("utf-8"), nxt
+    if kind == 4 and n >= 8:
+        code, ndim = struct.unpack_from("<BB6x", body, 0)
+        if code not in _DTYPES or ndim > 8 or n < 8 + 8 * ndim:
+            raise ValueError("bootstrap: bad array header")
+        dims = struct.unpack_from("<%dq" % ndim, body, 8)
+        count = 1
+        for d_ in dims:
+            if d_ < 0:
+                raise ValueError("bootstrap: negative dimension")
+            count *= d_
+        if count * _DTYPES[code].itemsize != n - 8 - 8 * ndim:
+            raise ValueError("bootstrap: array size does not match its shape")
+        return np.frombuffer(bytes(body[8 + 8 * ndim:]), dtype=_DTYPES[code]).reshape(dims).copy(), nxt
+    if kind in (5, 6) and n >= 4:
+        (count,) = struct.unpack_from("<I", body, 0)
+        items, pos = [], at + 4
+        for _ in range(count):
+            item, pos = _decode(buf, pos)
+            if pos > nxt:
+                raise ValueError("bootstrap: nested frame overruns its container")
+            items.append(item)
+        if pos != nxt:
+            raise ValueError("bootstrap: container length mismatch")
+        return (items if kind == 5 else tuple(items)), nxt
+    raise ValueError("bootstrap: unknown frame kind %d" % kind)
+
+
 def _send_msg(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-    sock.sendall(struct.pack("<Q", len(data)) + data)
+    sock.sendall(_encode(obj))
 
 
 def _recv_exact(sock, n):
@@ -70,8 +149,46 @@ def _recv_exact(sock, n):
 
 
 def _recv_msg(sock):
-    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    head = _recv_exact(sock, 16)
+    if head[:4] != _MAGIC:
+        raise ValueError("bootstrap: bad frame header")
+    (n,) = struct.unpack_from("<Q", head, 8)
+    if n > _MAX_PAYLOAD:
+        raise ValueError("bootstrap: frame of %d bytes refused" % n)
+    obj, _ = _decode(head + _recv_exact(sock, n))
+    return obj
+
+
+def _publish(path, port, token):
+    """Rank 0's port and token, visible atomically under `path`, readable by this user only (mkstemp: 0600, fresh name, no symlink
+    is followed; os.replace swaps the directory entry)."""
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", dir=os.path.dirname(path) or ".")
+    try:
+        os.write(fd, ("%d %s\n" % (port, token)).encode())
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read_published(path):
+    """(port, token) or None while rank 0 has not published yet.  A file that is a symlink, belongs to someone else or is readable
+    by others is refused: its content is not rank 0's."""
+    try:
+        fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except FileNotFoundError:
+        return None
+    except OSError as e:
+        raise RuntimeError("bootstrap: refusing rendezvous file %s: %s" % (path, e))
+    try:
+        st = os.fstat(fd)
+        if st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+            raise RuntimeError("bootstrap: refusing rendezvous file %s (owner %d, mode %o): not written by this job" % (path, st.st_uid, st.st_mode & 0o777))
+        text = os.read(fd, 256).decode("ascii", "replace").split()
+    finally:
+        os.close(fd)
+    if len(text) != 2 or not text[0].isdigit() or len(text[1]) != _TOKEN_BYTES:
+        return None
+    return int(text[0]), text[1]
 
 
 class _TcpStar(object):
@@ -85,28 +202,37 @@ class _TcpStar(object):
         if world == 1:
             return
         if rank == 0:
+            import hmac
+            import secrets
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind(("127.0.0.1", 0))
             srv.listen(world)
-            srv.settimeout(timeout)
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "w") as f:
-                f.write("%d\n" % srv.getsockname()[1])
-            os.replace(tmp, path)          # atomic: a reader sees no file or the whole port
+            token = secrets.token_hex(_TOKEN_BYTES // 2)
+            _publish(path, srv.getsockname()[1], token)
             self._path = path
             socks = {}
+            deadline = time.time() + timeout
             try:
                 while len(socks) < world - 1:
+                    srv.settimeout(max(0.01, deadline - time.time()))
                     conn, _ = srv.accept()
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(min(timeout, 10.0))
+                    try:          # nothing of a peer is parsed before it has shown the token
+                        if not hmac.compare_digest(_recv_exact(conn, _TOKEN_BYTES), token.encode()):
+                            raise ValueError("wrong token")
+                        r = _recv_msg(conn)
+                        if not isinstance(r, int) or not 0 < r < world or r in socks:
+                            raise ValueError("unexpected rank announcement %r" % (r,))
+                    except (ValueError, ConnectionError, socket.timeout, OSError):
+                        conn.close()      # not one of ours: keep waiting for the real ranks
+                        continue
                     conn.settimeout(timeout)
-                    r = _recv_msg(conn)
-                    if not isinstance(r, int) or not 0 < r < world or r in socks:
-                        raise RuntimeError("bootstrap: unexpected rank announcement %r" % (r,))
                     socks[r] = conn
             except socket.timeout:
-                raise RuntimeError("bootstrap: only %d of %d ranks joined within %.0f s" % (len(socks) + 1, world, timeout))
+                missing = [r for r in range(1, world) if r not in socks]
+                raise RuntimeError("bootstrap: rank(s) %s of %d never joined within %.0f s" % (", ".join(map(str, missing)), world, timeout))
             finally:
                 srv.close()
                 try:
@@ -116,18 +242,18 @@ class _TcpStar(object):
             self.peers = [socks[r] for r in range(1, world)]
         else:
             deadline = time.time() + timeout
-            port = None
-            while port is None:
-                try:
-                    with open(path) as f:
-                        port = int(f.read().strip())
-                except (OSError, ValueError):
+            found = None
+            while found is None:
+                found = _read_published(path)
+                if found is None:
                     if time.time() > deadline:
-                        raise RuntimeError("bootstrap: rank 0 never published %s" % path)
+                        raise RuntimeError("bootstrap: rank 0 never published %s (rank %d waited %.0f s)" % (path, rank, timeout))
                     time.sleep(0.01)
+            port, token = found
             s = socket.create_connection(("127.0.0.1", port), timeout=timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
+            s.sendall(token.encode())
             _send_msg(s, rank)
             self.root = s
 
@@ -135,12 +261,20 @@ class _TcpStar(object):
         if self.world == 1:
             return [obj]
         if self.rank == 0:
-            items = [obj] + [_recv_msg(p) for p in self.peers]
+            items = [obj]
+            for r, p in enumerate(self.peers, start=1):
+                try:
+                    items.append(_recv_msg(p))
+                except socket.timeout:
+                    raise RuntimeError("rank %d did not answer within the timeout" % r)
             for p in self.peers:
                 _send_msg(p, items)
             return items
         _send_msg(self.root, obj)
-        return _recv_msg(self.root)
+        try:
+            return _recv_msg(self.root)
+        except socket.timeout:
+            raise RuntimeError("rank 0 did not answer within the timeout (a peer rank is missing or stuck)")
 
     def close(self):
         for s in self.peers + ([self.root] if self.root else []):
@@ -165,6 +299,7 @@ class NodeGroup(object):
         self.transport = "none"
         self._lib = None
         self._comm = None
+        self.timeout = timeout
         self._star = _TcpStar(self.rank, self.world, rendezvous_path(), timeout)
         if self.world == 1:
             return
@@ -178,6 +313,14 @@ class NodeGroup(object):
             import ctypes
             from clair_amd import _capi
             lib = _capi.load()
+            # Pre-flight over the sockets, BEFORE anything collective: a rank whose device ordinal is out of range or that cannot
+            # load librccl would otherwise raise alone and leave the others inside ncclCommInitRank for ever.
+            mine = "" if lib.clair_comm_preflight(self.local_rank) == 0 else lib.clair_comm_last_error(None).decode()
+            status = self._star.allgather(mine)
+            bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
+            if bad:
+                self._star.close()
+                raise _capi.EngineError("RCCL start-up refused on %d of %d ranks -- %s" % (len(bad), self.world, "; ".join(bad)))
             uid = (ctypes.c_uint8 * 128)()
             if self.rank == 0 and lib.clair_comm_unique_id(uid) != 0:
                 err = lib.clair_comm_last_error(None).decode()
@@ -280,10 +423,12 @@ class NodeGroup(object):
         out = np.concatenate(parts, axis=0)
         return out.reshape((out.shape[0],) + a.shape[1:])
 
-    def close(self):
-        if self.world > 1:
+    def close(self, barrier=True):
+        """Leave the group.  The closing barrier goes over the sockets (they time out; an RCCL collective after a peer has died
+        does not) and is skipped when the caller is unwinding from an error (barrier=False)."""
+        if self.world > 1 and barrier:
             try:
-                self.barrier()
+                self._star.allgather(None)
             except Exception:
                 pass
         if self._comm is not None:
@@ -292,9 +437,10 @@ class NodeGroup(object):
         self._star.close()
 
 
-def spawn_ranks(argv, world, env=None, rdzv_dir=None):
+def spawn_ranks(argv, world, env=None, rdzv_dir=None, stderr_pipe=False):
     """Start `world` copies of `argv` (one per GPU: RANK = LOCAL_RANK = 0..world-1) the way torch.distributed.run would,
-    with a private rendezvous file.  Returns the list of Popen objects (stdout of rank 0 is a pipe, the others inherit)."""
+    with a private rendezvous file (a fresh 0700 directory).  Returns the list of Popen objects (stdout of rank 0 is a pipe, the
+    others inherit; stderr_pipe=True makes every rank's stderr a pipe for the caller to relay)."""
     import subprocess
     base = dict(os.environ if env is None else env)
     d = rdzv_dir or tempfile.mkdtemp(prefix="clair_amd_rdzv_")
@@ -303,5 +449,5 @@ def spawn_ranks(argv, world, env=None, rdzv_dir=None):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                  CLAIR_AMD_RDZV=os.path.join(d, "port"))
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == 0 else None))
+        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == 0 else None, stderr=subprocess.PIPE if stderr_pipe else None))
     return procs

@@ -24,8 +24,8 @@ extern "C" {
 #endif
 
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
- * bump), the clair_comm_* communicator (round 2). */
-#define CLAIR_ABI_VERSION 2
+ * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight (round 3). */
+#define CLAIR_ABI_VERSION 3
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
 #define CLAIR_POSITIONS 33
@@ -150,6 +150,13 @@ int clair_timing_reset(clair_engine_t *e);
  * sized to PART of the chip so that the batches in flight on other slots run beside them; a per-kernel roofline needs that share. */
 int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups /*[CLAIR_K_COUNT]*/);
 
+/* Event counters of the handle.  which: 0 = forward passes launched with the fused layer-2 kernel (one launch for the LSTM2
+ * projection and recurrence, used on handles with one or two slots), 1 = forward passes that were RE-RUN on the two-launch path
+ * because a fused launch reported that its workgroups were not placed as it assumes.  A re-run is invisible to the caller
+ * (same arithmetic, same outputs; the reference never drops a batch, clair/call_var.py:1331-1352) except through this counter
+ * and one line on stderr; after the first one the handle stays on the two-launch path. */
+int clair_engine_counter(clair_engine_t *e, int which, int64_t *value);
+
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
  *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
  *    3 = split-K partials of the L4 product [16,n_pad,192], 4 = L3 output [n_pad,7680] (only when the engine was created
@@ -169,6 +176,10 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
 #define CLAIR_COMM_ID_BYTES 128
 enum clair_comm_op { CLAIR_COMM_SUM = 0, CLAIR_COMM_MAX = 1, CLAIR_COMM_MIN = 2 };
 typedef struct clair_comm clair_comm_t;
+/* Everything clair_comm_create needs that can be checked WITHOUT the other ranks: a HIP device with this ordinal that accepts an
+ * allocation, librccl.so loadable with the entry points bound.  The ranks exchange the result out of band before any of them
+ * enters the collective ncclCommInitRank, so one rank's failure is an error on every rank instead of a hang on the others. */
+int clair_comm_preflight(int device);
 int clair_comm_unique_id(uint8_t *id /*[CLAIR_COMM_ID_BYTES]*/);                 /* ncclGetUniqueId */
 int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_comm_t **out);   /* ncclCommInitRank */
 void clair_comm_destroy(clair_comm_t *c);

@@ -146,3 +146,102 @@ def test_nothing_under_clair_amd_imports_torch():
             if f.endswith(".py"):
                 text = open(os.path.join(dp, f)).read()
                 assert "import torch" not in text and "from torch" not in text, os.path.join(dp, f)
+
+
+def test_wire_format_round_trips_and_rejects_malformed_frames():
+    """The bootstrap / CPU transport frames its messages itself (no pickle: bytes from a local peer are parsed, never executed)."""
+    for obj in (None, 0, -5, 2 ** 40, b"\x00\x01", "rank 3: no device", [1, None, "x"], ("id", b"\x07" * 128),
+                [np.arange(6, dtype=np.float32).reshape(2, 3), np.zeros((0, 90), np.float32), np.array([1.5, -2.0]), np.arange(3, dtype=np.int64)]):
+        back, end = shard._decode(shard._encode(obj))
+        assert end == len(shard._encode(obj))
+        if isinstance(obj, list) and obj and isinstance(obj[0], np.ndarray):
+            assert all(a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) for a, b in zip(obj, back))
+        else:
+            assert back == obj and type(back) is type(obj)
+    good = shard._encode(np.arange(4, dtype=np.float32))
+    for bad in (b"", good[:10], b"XXXX" + good[4:], good[:-1], good[:4] + b"\x09" + good[5:],
+                good[:16] + b"\x07" + good[17:],                      # unknown dtype code
+                good[:24] + (5).to_bytes(8, "little") + good[32:]):   # shape does not match the payload
+        with pytest.raises(ValueError):
+            shard._decode(bad)
+    with pytest.raises(TypeError):
+        shard._encode({"a": 1})
+    with pytest.raises(TypeError):
+        shard._encode(np.zeros(2, dtype=np.complex64))
+    assert b"pickle" not in open(shard.__file__, "rb").read().replace(b"no pickle", b"")
+
+
+def test_rendezvous_file_is_private_and_foreign_files_are_refused(tmp_path):
+    path = str(tmp_path / "port")
+    shard._publish(path, 4242, "a" * 32)
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    assert shard._read_published(path) == (4242, "a" * 32)
+    os.chmod(path, 0o644)                                  # readable by others: not written by _publish
+    with pytest.raises(RuntimeError):
+        shard._read_published(path)
+    os.unlink(path)
+    target = tmp_path / "elsewhere"
+    target.write_text("1 " + "b" * 32 + "\n")
+    os.chmod(str(target), 0o600)
+    os.symlink(str(target), path)                          # a planted symlink is not followed
+    with pytest.raises(RuntimeError):
+        shard._read_published(path)
+    assert shard._read_published(str(tmp_path / "absent")) is None
+
+
+def test_a_peer_without_the_token_is_ignored_and_missing_ranks_are_named(tmp_path, monkeypatch):
+    """Rank 0 parses nothing from a connection that has not presented the token; when a rank never joins, the error names it."""
+    import threading
+    path = str(tmp_path / "port")
+    monkeypatch.setenv("CLAIR_AMD_RDZV", path)
+    result = {}
+
+    def rank0():
+        try:
+            shard.NodeGroup(transport="tcp", timeout=3.0, rank=0, world=3, local_rank=0)
+        except RuntimeError as e:
+            result["err"] = str(e)
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    found = None
+    for _ in range(300):
+        found = shard._read_published(path)
+        if found:
+            break
+        import time
+        time.sleep(0.01)
+    port, token = found
+    with socket.create_connection(("127.0.0.1", port)) as s:       # an intruder: wrong token, then a frame
+        s.sendall(b"z" * 32 + shard._encode(1))
+    with socket.create_connection(("127.0.0.1", port)) as s:       # rank 1 joins properly
+        s.sendall(token.encode() + shard._encode(1))
+        t.join(timeout=20)
+    assert "rank(s) 2 of 3 never joined" in result["err"]
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import sys
+    sys.path.insert(0, %(root)r)
+    from clair_amd import shard, _capi
+    try:
+        shard.NodeGroup(transport="rccl", timeout=20.0)
+    except _capi.EngineError as e:
+        print("REFUSED", e)
+        sys.exit(3)
+    sys.exit(0)
+""")
+
+
+def test_rccl_start_up_is_refused_on_every_rank_when_one_rank_cannot_start(tmp_path):
+    """Pre-flight before the collective init: without a device every rank reports it and every rank raises -- nobody is left
+    waiting inside ncclCommInitRank."""
+    from clair_amd import _capi
+    if _capi.load().clair_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_WORKER % {"root": ROOT})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 2)
+    out = procs[0].stdout.read().decode()
+    assert [p.wait(timeout=60) for p in procs] == [3, 3]
+    assert "refused on 2 of 2 ranks" in out and "rank 1: no HIP device" in out

@@ -5,11 +5,21 @@ exact-equality membership tests) and count the rows whose CHROM/POS/REF/ALT/GT d
 the float64 evaluation: a flip whose two candidate calls are within float32 noise of each other in float64 is a tie the
 reference itself would break differently from run to run (multithreaded Eigen, no fixed reduction order).
 
-Usage:  python tools/gt_concordance.py [--n 200000] [--platforms ont,pacbio_ccs,illumina] [--json out.json]
+Instrumented (round 3; one of nine round-2 runs showed chunks beyond the 1e-5 tolerance on a box nobody recorded):
+  * the box is identified first (GPU unique id, PCI bus, clocks, power, ECC/RAS counters, kernel selection of the handle);
+  * with --taps the LSTM1 / LSTM2 outputs of every batch are kept until its chunk has been checked;
+  * a chunk beyond the tolerance is dissected on the spot -- which candidates (batch, tile, lane), the HIP path re-run three times
+    on the same batch (bit-compared with the first pass), the oracle re-evaluated on the offending candidates alone with ONE thread
+    (float32 and float64), the first layer whose tap leaves the oracle's -- and everything needed to replay the worst 16 candidates
+    is written to <dump-dir>/excursion_<platform>_<chunk>.npz, which comes back in gpurun_out/.
+
+Usage:  python tools/gt_concordance.py [--n 200000] [--platforms ont,pacbio_ccs,illumina] [--json out.json] [--taps] [--dump-dir gpurun_out]
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,37 +30,143 @@ sys.path.insert(0, ROOT)
 
 from clair_amd import _capi, call_var as cvar, synth, weights  # noqa: E402
 
+PROB_TOL = 1e-5
+
 
 def key(row):
     f = row.split("\t")
     return (f[0], f[1], f[3], f[4], f[-1].split(":")[0])
 
 
-def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print):
+def _run(cmd, timeout=30):
+    try:
+        return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout).stdout.decode(errors="replace").strip()
+    except Exception as e:   # noqa: BLE001 -- diagnostics only
+        return "(%s: %s)" % (" ".join(cmd), e)
+
+
+def box_info(full=True):
+    """Who ran this: GPU unique id(s) from sysfs, and rocm-smi's view of id, clocks, power and RAS counters."""
+    info = {"host": os.uname().nodename, "unique_ids": []}
+    for p in sorted(glob.glob("/sys/class/drm/card*/device/unique_id")):
+        try:
+            info["unique_ids"].append(open(p).read().strip())
+        except OSError:
+            pass
+    if full:
+        info["rocm_smi"] = _run(["rocm-smi", "--showuniqueid", "--showbus", "--showclocks", "--showpower", "--showtemp"])
+        info["ras"] = _run(["rocm-smi", "--showrasinfo", "all"], timeout=60)
+    return info
+
+
+def gpu_state():
+    """One line of clocks / power while the run is hot (cheap: sysfs only)."""
+    out = []
+    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+        try:
+            sclk = [line for line in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines() if line.endswith("*")]
+            out.append("sclk %s" % (sclk[0].split(":")[1].strip(" *") if sclk else "?"))
+        except OSError:
+            pass
+        for hw in glob.glob(os.path.join(card, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(card, "hwmon/hwmon*/power1_input")):
+            try:
+                out.append("%.0f W" % (int(open(hw).read()) / 1e6))
+                break
+            except (OSError, ValueError):
+                pass
+        break
+    return ", ".join(out)
+
+
+def dissect(eng, w, platform, c0, x, got, want, batch, taps, dump_dir, log, worst_k=16):
+    """A chunk beyond the tolerance: say which side moved, where, and leave the evidence on disk."""
+    from oracle import c_oracle
+    err = np.max([np.abs(g - t).max(axis=1) for g, t in zip(got, want)], axis=0)       # per candidate
+    bad = np.flatnonzero(err > PROB_TOL)
+    order = bad[np.argsort(-err[bad])][:worst_k]
+    log("  !! %s chunk at %d: %d candidates beyond %.0e (worst %.3e); positions (batch, tile, lane) of the worst: %s"
+        % (platform, c0, len(bad), PROB_TOL, float(err.max()), [(int(i) // batch, int(i) % batch // 32, int(i) % 32) for i in order[:8]]))
+    log("     state: %s" % gpu_state())
+    rec = {"platform": platform, "chunk_start": int(c0), "index": order, "err": err[order], "x": x[order]}
+    for k, (g, t) in enumerate(zip(got, want)):
+        rec["hip_first_%d" % k], rec["oracle32_chunk_%d" % k] = g[order], t[order]
+    # (1) the HIP side again, three times, on each offending batch
+    reruns_differ = 0
+    for b in sorted({int(i) // batch for i in order}):
+        b0 = b * batch
+        mine = [int(i) for i in order if int(i) // batch == b]
+        for rep in range(3):
+            again = eng.predict(x[b0:b0 + batch])
+            d_first = max(float(np.abs(a[np.array(mine) - b0] - g[mine]).max()) for a, g in zip(again, got))
+            whole = sum(int((a != g[b0:b0 + a.shape[0]]).any(axis=1).sum()) for a, g in zip(again, got))
+            d_or = max(float(np.abs(a[np.array(mine) - b0] - t[mine]).max()) for a, t in zip(again, want))
+            reruns_differ += int(whole > 0)
+            log("     HIP re-run %d of batch %d: |again - first| on the offenders %.3e (%d rows of the batch differ bitwise); |again - oracle32| %.3e"
+                % (rep, b, d_first, whole, d_or))
+            for k, a in enumerate(again):
+                rec["hip_again%d_b%d_%d" % (rep, b, k)] = a[np.array(mine) - b0]
+        if taps is not None and b in taps:      # the re-run's taps against the first pass's
+            a1r, a2r = eng.debug_read(0, 1, taps[b][0].shape), eng.debug_read(0, 2, taps[b][1].shape)
+            log("     taps of batch %d, re-run vs first pass: a1 differs in %d values, a2 in %d" % (b, int((a1r != taps[b][0]).sum()), int((a2r != taps[b][1]).sum())))
+    # (2) the oracle side again: the offenders alone, one thread, float32 and float64
+    xs = x[order]
+    o32_1, inter32 = c_oracle.forward(w, xs, threads=1, keep_intermediates=True)
+    o64_1, inter64 = c_oracle.forward(w, xs, threads=1, keep_intermediates=True, dtype=np.float64)
+    d_or = max(float(np.abs(a - t[order]).max()) for a, t in zip(o32_1, want))
+    d_h32 = max(float(np.abs(a - g[order]).max()) for a, g in zip(o32_1, got))
+    d_h64 = max(float(np.abs(a - g[order]).max()) for a, g in zip(o64_1, got))
+    d_3264 = max(float(np.abs(a - b_).max()) for a, b_ in zip(o32_1, o64_1))
+    log("     oracle on the offenders alone, 1 thread: |alone32 - chunk32| %.3e;  |hip - alone32| %.3e;  |hip - alone64| %.3e;  |alone32 - alone64| %.3e"
+        % (d_or, d_h32, d_h64, d_3264))
+    for k in range(4):
+        rec["oracle32_alone_%d" % k], rec["oracle64_alone_%d" % k] = o32_1[k], o64_1[k]
+    # (3) first diverging layer, from the taps of the FIRST pass (kept only with --taps)
+    if taps is not None:
+        for j, i in enumerate(order):
+            b, r = int(i) // batch, int(i) % batch
+            if b not in taps:
+                continue
+            a1, a2 = taps[b][0][:, r, :], taps[b][1][:, r, :]            # [33][256]
+            rec["a1_first_%d" % j], rec["a2_first_%d" % j] = a1, a2
+            if j < 8:
+                log("     candidate %d (batch %d row %d): |a1 - o32| %.3e (o32 vs o64 %.3e);  |a2 - o32| %.3e (o32 vs o64 %.3e);  |p - o32| %.3e"
+                    % (int(i), b, r, float(np.abs(a1 - inter32["a1"][j]).max()), float(np.abs(inter32["a1"][j] - inter64["a1"][j]).max()),
+                       float(np.abs(a2 - inter32["a2"][j]).max()), float(np.abs(inter32["a2"][j] - inter64["a2"][j]).max()), float(err[i])))
+    verdict = ("oracle side moved (chunk evaluation differs from the single-thread one)" if d_or > 1e-7 else
+               "HIP side, not reproduced on re-run (transient)" if reruns_differ else
+               "HIP side, reproduced bit for bit on re-run (deterministic: arithmetic of these inputs, not a race)")
+    log("     verdict: %s" % verdict)
+    rec["verdict"] = verdict
+    if dump_dir:
+        os.makedirs(dump_dir, exist_ok=True)
+        path = os.path.join(dump_dir, "excursion_%s_%d.npz" % (platform, c0))
+        np.savez_compressed(path, **rec)
+        log("     evidence: %s" % path)
+    return {"chunk_start": int(c0), "candidates_beyond_tol": int(len(bad)), "worst": float(err.max()), "verdict": verdict}
+
+
+def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print, keep_taps=False, dump_dir=None):
     from oracle import c_oracle
     dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
-    flips, rows_total, worst = [], 0, 0.0
+    flips, rows_total, worst, excursions = [], 0, 0.0, []
     t0 = time.time()
     for c0 in range(0, n, chunk):
         m = min(chunk, n - c0)
         raw, infos = synth.synthetic_candidates(m, platform, seed=seed + c0, start=100000 + 7 * c0)
         x = synth.to_model_input(raw)
         got = [np.empty((m, k), np.float32) for k in (21, 3, 33, 33)]
+        taps = {} if keep_taps else None
         for i in range(0, m, batch):
+            nb = min(batch, m - i)
             for g, o in zip(got, eng.predict(x[i:i + batch])):
                 g[i:i + o.shape[0]] = o
+            if keep_taps:
+                n_pad = (nb + 31) // 32 * 32
+                taps[i // batch] = (eng.debug_read(0, 1, (33, n_pad, 256)), eng.debug_read(0, 2, (33, n_pad, 256)))
         want = c_oracle.forward(w, x)
         chunk_worst = max(float(np.abs(g - t).max()) for g, t in zip(got, want))
-        if chunk_worst > 1e-5:      # beyond the tolerance: which side moved?  (re-run the candidate's batch, re-evaluate the oracle on it alone)
-            k = int(np.argmax([float(np.abs(g - t).max()) for g, t in zip(got, want)]))
-            i = int(np.argmax(np.abs(got[k] - want[k]).max(axis=1)))
-            b0 = i // batch * batch
-            again = eng.predict(x[b0:b0 + batch])
-            alone32 = c_oracle.forward(w, x[i:i + 1])
-            alone64 = c_oracle.forward(w, x[i:i + 1], dtype=np.float64)
-            log("  !! %s chunk at %d: candidate %d output %d: |hip - oracle| %.2e;  hip again: |again - first| %.2e;  oracle alone: |alone32 - chunk32| %.2e, "
-                "|hip - alone32| %.2e, |hip - alone64| %.2e" % (platform, c0, i, k, chunk_worst, float(np.abs(again[k][i - b0] - got[k][i]).max()),
-                float(np.abs(alone32[k][0] - want[k][i]).max()), float(np.abs(got[k][i] - alone32[k][0]).max()), float(np.abs(got[k][i] - alone64[k][0]).max())))
+        if chunk_worst > PROB_TOL:
+            excursions.append(dissect(eng, w, platform, c0, x, got, want, batch, taps, dump_dir, log))
         worst = max(worst, chunk_worst)
         rows_g = dec.decode_batch(x, infos, got)
         rows_w = dec.decode_batch(x, infos, want)
@@ -64,8 +180,9 @@ def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print):
                 row64 = dec.decode_batch(x[idx:idx + 1], infos[idx:idx + 1], [o.astype(np.float32) for o in o64])
                 flips.append({"hip": a, "oracle32": b, "oracle64_rounded": row64[0] if row64 else None,
                               "max_abs_dp": max(float(np.abs(g[idx] - t[idx]).max()) for g, t in zip(got, want))})
-        log("%s: %d / %d candidates, %d rows, %d flips, max |dp| %.2e, %.0f s" % (platform, c0 + m, n, rows_total, len(flips), worst, time.time() - t0))
-    return {"platform": platform, "candidates": n, "vcf_rows": rows_total, "gt_flips": len(flips), "max_abs_dp": worst, "flips": flips}
+        log("%s: %d / %d candidates, %d rows, %d flips, max |dp| %.2e, %.0f s  [%s]" % (platform, c0 + m, n, rows_total, len(flips), worst, time.time() - t0, gpu_state()))
+    return {"platform": platform, "candidates": n, "vcf_rows": rows_total, "gt_flips": len(flips), "max_abs_dp": worst, "flips": flips,
+            "excursions": excursions}
 
 
 if __name__ == "__main__":
@@ -74,16 +191,25 @@ if __name__ == "__main__":
     ap.add_argument("--platforms", default="ont,pacbio_ccs,illumina")
     ap.add_argument("--json", default=None)
     ap.add_argument("--head-gain", type=float, default=4.0)
+    ap.add_argument("--taps", action="store_true", help="keep every batch's LSTM1 / LSTM2 outputs until its chunk is checked (first diverging layer on an excursion)")
+    ap.add_argument("--dump-dir", default=os.path.join(ROOT, "gpurun_out"))
     a = ap.parse_args()
+    box = box_info()
+    print("box: %s %s" % (box["host"], " ".join(box["unique_ids"])), flush=True)
+    print(box.get("rocm_smi", ""), flush=True)
+    print(box.get("ras", ""), flush=True)
     w = weights.synthetic_weights(seed=20250928, head_gain=a.head_gain)
     eng = _capi.Engine(device=0, max_batch=4096, n_slots=1)
     eng.load_weights(w)
-    res = [concordance(eng, w, p, a.n, 777) for p in a.platforms.split(",")]
+    print("kernel selection at batch 4096, one slot: workgroups %s; env %s" % (eng.kernel_workgroups(4096),
+          {k: v for k, v in os.environ.items() if k.startswith("CLAIR_AMD_")}), flush=True)
+    res = [concordance(eng, w, p, a.n, 777, keep_taps=a.taps, dump_dir=a.dump_dir, log=lambda *s: print(*s, flush=True)) for p in a.platforms.split(",")]
     eng.close()
     for r in res:
         print(json.dumps({k: v for k, v in r.items() if k != "flips"}))
         for f in r["flips"]:
             print("  FLIP", json.dumps(f))
+    print("box: %s %s  excursions: %d" % (box["host"], " ".join(box["unique_ids"]), sum(len(r["excursions"]) for r in res)))
     if a.json:
         with open(a.json, "w") as f:
-            json.dump(res, f, indent=1)
+            json.dump({"box": box, "results": res}, f, indent=1)

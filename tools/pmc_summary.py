@@ -57,7 +57,26 @@ def traffic():
         print("%-54s %14.1f %14.1f %14.1f %14.1f %8.2f" % (name[:54], f, w, f + w, a, (f + w) / a if a else 0))
     print("# sum over the forward pass: %.1f MB per batch of %d = %.0f B per candidate (SURVEY 8(d) algorithmic bytes: 4 584 B per candidate = %.1f MB)"
           % (total, batch, total * 1e6 / batch, 4584 * batch / 1e6))
-    print("# bench.py table entry: %d: {%s}" % (batch, ", ".join('"%s": %.1fe6' % (k, v / 1e6) for k, v in table.items())))
+    if "--json" in sys.argv:      # stamp the table with the sources it was measured on and merge it into profiles/pmc_traffic.json (bench.py reads it)
+        import json
+        import subprocess
+        from clair_amd import build
+        path = arg("--json", "")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        doc = json.load(open(path)) if os.path.isfile(path) else {"entries": {}}
+        fused = {k: v for k, v in table.items() if k == "layer2_fused"}
+        try:
+            head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE).stdout.decode().strip() or None
+        except OSError:
+            head = None
+        prev = doc["entries"].get(str(batch), {})
+        entry = {"csrc_digest": build.csrc_digest(), "git": head, "source": arg("--source", "")}
+        same = prev.get("csrc_digest") == entry["csrc_digest"]
+        entry["kernels"] = dict(prev.get("kernels", {}) if same else {}, **{k: v for k, v in table.items() if k != "layer2_fused"})
+        if fused or (same and prev.get("fused")):
+            entry["fused"] = dict(prev.get("fused", {}) if same else {}, **fused)
+        doc["entries"][str(batch)] = entry
+        json.dump(doc, open(path, "w"), indent=1)
 
 
 def mfma():
