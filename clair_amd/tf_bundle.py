@@ -262,32 +262,97 @@ def candidate_names(tf_name, rename, rename_prefix):
     return uniq
 
 
+def cudnn_opaque_to_canonical(opaque, input_size, units):
+    """One bidirectional CudnnLSTM layer's flat parameter buffer -> {(direction, "kernel"|"bias"): array} in the canonical
+    CudnnCompatibleLSTMCell form (kernel [input + units, 4 units], bias [4 units], gate columns i | c~ | f | o).
+
+    A GPU-trained Clair graph holds each LSTM layer as tf.contrib.cudnn_rnn.CudnnLSTM (/root/reference/clair/model.py:281-296), whose
+    only variable is the flat "opaque_kernel".  tf.train.Saver normally stores it through the layer's CudnnLSTMSaveable in the
+    canonical per-direction form (the names candidate_names() tries inside "cudnn_lstm/"); a checkpoint written without the
+    saveable carries the buffer itself.  Layout [TF-recall: cuDNN's documented canonical order, as cudnn_rnn_ops converts it]: all
+    weight matrices first -- per direction (fw, bw): W_i, W_f, W_c, W_o [units, input_size] then R_i, R_f, R_c, R_o [units, units],
+    row-major -- then all biases -- per direction: bW_i, bW_f, bW_c, bW_o, bR_i, bR_f, bR_c, bR_o [units].  The canonical kernel
+    is [W^T ; R^T] with the gate blocks reordered i, c, f, o; the canonical bias is bW + bR (forget bias 0 in both forms)."""
+    opaque = np.asarray(opaque, dtype=np.float32).ravel()
+    per_dir_w = 4 * units * (input_size + units)
+    if opaque.size != 2 * per_dir_w + 2 * 8 * units:
+        raise ValueError("opaque CudnnLSTM buffer has %d floats; a bidirectional layer with input %d and %d units has %d"
+                         % (opaque.size, input_size, units, 2 * per_dir_w + 16 * units))
+    out, order = {}, (0, 2, 1, 3)          # canonical block j takes cuDNN gate order[j]: i, c, f, o <- i, f, c, o
+    for d, name in enumerate(("fw", "bw")):
+        wbase = d * per_dir_w
+        W = opaque[wbase:wbase + 4 * units * input_size].reshape(4, units, input_size)
+        R = opaque[wbase + 4 * units * input_size:wbase + per_dir_w].reshape(4, units, units)
+        kernel = np.empty((input_size + units, 4 * units), dtype=np.float32)
+        for j, g in enumerate(order):
+            kernel[:input_size, j * units:(j + 1) * units] = W[g].T
+            kernel[input_size:, j * units:(j + 1) * units] = R[g].T
+        b = opaque[2 * per_dir_w + d * 8 * units:2 * per_dir_w + (d + 1) * 8 * units].reshape(2, 4, units)
+        out[(name, "kernel")] = kernel
+        out[(name, "bias")] = np.concatenate([b[0, g] + b[1, g] for g in order])
+    return out
+
+
+def _expand_opaque_layers(tensors):
+    """For every "<LSTMn>/.../opaque_kernel" of the right size that has no canonical twin in the file, add the canonical
+    per-direction tensors under the names the table expects."""
+    added = {}
+    for name, a in tensors.items():
+        if not name.endswith("opaque_kernel"):
+            continue
+        layer = name.split("/")[0]
+        if layer not in ("LSTM1", "LSTM2"):
+            continue
+        input_size = 32 if layer == "LSTM1" else 256
+        try:
+            parts = cudnn_opaque_to_canonical(a, input_size, 128)
+        except ValueError:
+            continue
+        for (d, kind), value in parts.items():
+            canon = "%s/stack_bidirectional_rnn/cell_0/bidirectional_rnn/%s/cudnn_compatible_lstm_cell/%s" % (layer, d, kind)
+            if canon not in tensors:
+                added[canon] = value
+    return added
+
+
 def load_checkpoint(prefix):
     """Checkpoint prefix -> weight dict keyed as clair_amd.weights.TENSOR_TABLE."""
     from clair_amd import weights
     tensors = read_tensors(prefix)
+    tensors.update(_expand_opaque_layers(tensors))
     rename, rename_prefix, override_path = _name_overrides(prefix)
     names = weights.tf_variable_names()
     w = OrderedDict((k, np.zeros(shape, dtype=np.float32)) for k, shape in weights.TENSOR_TABLE.items())
+    model_vars = {n: a for n, a in tensors.items() if not (n.endswith("/Adam") or n.endswith("/Adam_1"))}
 
     def listing():
-        rows = ["  %s %s" % (n, tuple(a.shape)) for n, a in sorted(tensors.items())
-                if not (n.endswith("/Adam") or n.endswith("/Adam_1"))]
+        rows = ["  %s %s" % (n, tuple(a.shape)) for n, a in sorted(model_vars.items())]
         more = "" if len(rows) <= 80 else "\n  ... %d more" % (len(rows) - 80)
         return ("float32 variables in %s (optimizer slots left out):\n%s%s\nTo map names, write %s.names.json "
                 "{\"rename\": {expected: actual}, \"rename_prefix\": {expected_prefix: actual_prefix}} (or point "
                 "$CLAIR_AMD_TF_NAMES at such a file)." % (prefix, "\n".join(rows[:80]), more, prefix))
 
+    def shape_hints(want, tf_name):
+        """Variables of the file that could BE the missing one: same shape (a [160,512] float variable is almost certainly an
+        LSTM1 kernel), not already claimed by another expected name; the ready-made override line comes with them."""
+        claimed = {n for t in names for n in candidate_names(t, rename, rename_prefix) if n in tensors and t != tf_name}
+        hits = [n for n, a in sorted(model_vars.items()) if tuple(a.shape) == tuple(want) and n not in claimed]
+        if not hits:
+            return "no unclaimed variable of shape %s in the file" % (tuple(want),)
+        return ("unclaimed variables of the same shape %s: %s\n  e.g. {\"rename\": {\"%s\": \"%s\"}}"
+                % (tuple(want), ", ".join(hits[:6]) + (" ... (%d)" % len(hits) if len(hits) > 6 else ""), tf_name, hits[0]))
+
     for tf_name, (key, index) in names.items():
         tried = candidate_names(tf_name, rename, rename_prefix)
         found = next((n for n in tried if n in tensors), None)
-        if found is None:
-            raise KeyError("variable %s not found in checkpoint %s (tried: %s%s)\n%s"
-                           % (tf_name, prefix, ", ".join(tried), "; overrides from " + override_path if override_path else "", listing()))
         want = w[key].shape if index is None else w[key][index].shape
+        if found is None:
+            raise KeyError("variable %s not found in checkpoint %s (tried: %s%s)\n%s\n%s"
+                           % (tf_name, prefix, ", ".join(tried), "; overrides from " + override_path if override_path else "",
+                              shape_hints(want, tf_name), listing()))
         if int(np.prod(tensors[found].shape)) != int(np.prod(want)):
-            raise ValueError("variable %s in checkpoint %s has shape %s, the graph needs %s\n%s"
-                             % (found, prefix, tuple(tensors[found].shape), tuple(want), listing()))
+            raise ValueError("variable %s in checkpoint %s has shape %s, the graph needs %s\n%s\n%s"
+                             % (found, prefix, tuple(tensors[found].shape), tuple(want), shape_hints(want, tf_name), listing()))
         if index is None:
             w[key][...] = tensors[found].reshape(want)
         else:

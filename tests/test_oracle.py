@@ -145,3 +145,53 @@ def test_blocked_cpu_port_matches_the_checker(n, platform):
         assert g.shape == t.shape and np.isfinite(g).all()
         assert np.abs(g - t).max() <= 1e-5
         assert np.abs(g.sum(axis=1) - 1).max() < 1e-5
+
+
+# ---- the TensorFlow-1.13 golden vectors (tools/mint_tf_golden.py) ---------------------------------------------------------------------
+TF_GOLDEN = os.path.join(ROOT, "tests", "golden", "nn_tf113_64.npz")
+TF_GOLDEN_ABSENT = ("tests/golden/nn_tf113_64.npz is NOT in the repository: the network arithmetic is still checked only against this "
+                    "repository's own restatement of TensorFlow 1.13 (parity unpinned).  Anyone with tensorflow==1.13.2 can pin it: "
+                    "`python tools/mint_tf_golden.py`, commit the file, and this test compares the oracle with the real reference.")
+
+
+def _mint():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mint_tf_golden
+    return mint_tf_golden
+
+
+def test_tf_golden_recipe_is_pinned():
+    """The weights and candidates the TF-1.13 golden file is minted on are defined by an integer hash, not by a NumPy random
+    stream: the same bits under the NumPy 1.16 a TF-1.13 environment has and under the NumPy 2 of this image.  Pinned here so
+    that a change of the recipe cannot go unnoticed (the minted file records the same checksum)."""
+    m = _mint()
+    assert np.array_equal(m._uniform(1, 5), np.array([0.7666216, 0.13312304, 0.18237936, -0.7730994, -0.13708842], dtype=np.float32))
+    w = m.recipe_weights()
+    assert [k for k, _ in m.tensor_shapes()] == list(weights.TENSOR_TABLE) and all(w[k].shape == tuple(s) for k, s in weights.TENSOR_TABLE.items())
+    assert abs(sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values()) - 117751.35826626392) < 1e-6
+    assert m.tf_variable_names() == weights.tf_variable_names()          # the minting script loads TF's variables by the loader's names
+    x = m.golden_input()
+    assert x.shape == (64, 33, 8, 4) and x.dtype == np.float32
+    outs = c_oracle.forward(w, x)
+    assert abs(float(outs[0][0, 2]) - 0.27634575963020325) < 1e-5          # informative, peaky outputs (not a flat softmax)
+    assert 0.5 < float(outs[0].max(axis=1).mean()) < 0.99
+
+
+def test_oracle_matches_the_tf113_golden_vectors_when_present():
+    """THE pin of the oracle: outputs and intermediates TensorFlow 1.13 itself computed for the recipe weights on the 64
+    golden candidates.  Tolerances: 1e-5 on probabilities, 5e-6 on activations (two float32 evaluations with different
+    summation orders; the oracle's own float32 / float64 twins differ by 4e-6 on this set)."""
+    if not os.path.isfile(TF_GOLDEN):
+        pytest.skip(TF_GOLDEN_ABSENT)
+    m = _mint()
+    w, x = m.recipe_weights(), m.golden_input()
+    with np.load(TF_GOLDEN) as z:
+        assert str(z["recipe"]) == m.RECIPE
+        assert abs(float(z["weights_checksum"]) - sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values())) < 1e-6
+        outs, inter = c_oracle.forward(w, x, keep_intermediates=True)
+        for got, key in zip(outs, ("gt21", "genotype", "len1", "len2")):
+            assert np.abs(got - z[key]).max() <= 1e-5, key
+        assert np.abs(inter["a1"][:4].transpose(1, 0, 2) - z["a1_first4"]).max() <= 5e-6
+        assert np.abs(inter["a2"][:4].transpose(1, 0, 2) - z["a2_first4"]).max() <= 5e-6
+        assert np.abs(inter["l3"][:4] - z["l3_first4"]).max() <= 5e-6
+        assert np.abs(inter["l4"] - z["l4"]).max() <= 5e-6

@@ -58,3 +58,4 @@ def test_concordance_dissects_an_excursion(synth_weights, tmp_path):
     assert r["excursions"] == []        # call 0 is clean
     box = gt_concordance.box_info(full=False)
     assert "host" in box and isinstance(box["unique_ids"], list)
+    assert isinstance(gt_concordance.gpu_state(), str)

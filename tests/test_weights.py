@@ -173,3 +173,83 @@ def test_checkpoint_with_other_variable_names_loads_through_fallback_and_overrid
     tf_bundle.write_checkpoint(prefix, tensors)
     with pytest.raises(ValueError, match="has shape"):
         weights.load_weights(prefix)
+
+
+def test_a_miss_names_the_shape_compatible_variables_and_the_override_line(tmp_path, monkeypatch):
+    """A checkpoint that calls a tensor something else: the error proposes the unclaimed variables of the same shape and the
+    override that would map them."""
+    monkeypatch.delenv("CLAIR_AMD_TF_NAMES", raising=False)
+    w = weights.synthetic_weights(seed=9)
+    tensors = {}
+    for tf_name, (key, index) in weights.tf_variable_names().items():
+        a = w[key] if index is None else w[key][index]
+        if tf_name == "LSTM1/stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/cudnn_compatible_lstm_cell/kernel":
+            tf_name = "rnn_a/forward/weights"
+        tensors[tf_name] = a
+    prefix = str(tmp_path / "model")
+    tf_bundle.write_checkpoint(prefix, tensors)
+    with pytest.raises(KeyError) as ei:
+        weights.load_weights(prefix)
+    msg = str(ei.value)
+    assert "unclaimed variables of the same shape (160, 512): rnn_a/forward/weights" in msg      # not the bw kernel: that one is claimed
+    assert '"rename": {"LSTM1/stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/cudnn_compatible_lstm_cell/kernel": "rnn_a/forward/weights"}' in msg
+
+
+def test_opaque_cudnn_lstm_buffers_are_converted_to_the_canonical_cell_form(tmp_path, monkeypatch):
+    """A GPU-trained graph keeps each LSTM layer as ONE flat CudnnLSTM buffer (clair/model.py:281-296).  When a checkpoint carries the
+    buffer itself instead of the saveable's canonical tensors, the loader converts it: weights [gate][unit][input] in cuDNN's gate
+    order i, f, c, o (input part, then recurrent part, per direction), then two bias sets per direction that add up.  The buffer
+    here is assembled from that description, independently of the converter."""
+    monkeypatch.delenv("CLAIR_AMD_TF_NAMES", raising=False)
+    w = weights.synthetic_weights(seed=10, lstm_bias_scale=0.1)
+    rng = np.random.default_rng(3)
+    tensors = {}
+    for tf_name, (key, index) in weights.tf_variable_names().items():
+        if not tf_name.startswith("LSTM"):
+            tensors[tf_name] = w[key] if index is None else w[key][index]
+    cudnn_gate_of_tf_block = {0: 0, 1: 2, 2: 1, 3: 3}        # TF column block (i, c~, f, o) -> position in cuDNN's (i, f, c, o)
+    for layer, input_size in ((1, 32), (2, 256)):
+        mats, biases = [], []
+        for d in ("fw", "bw"):
+            k, b = w["lstm%d_%s_kernel" % (layer, d)], w["lstm%d_%s_bias" % (layer, d)]
+            blocks = {cudnn_gate_of_tf_block[j]: k[:, j * 128:(j + 1) * 128] for j in range(4)}
+            mats += [blocks[g][:input_size].T.ravel() for g in range(4)] + [blocks[g][input_size:].T.ravel() for g in range(4)]
+            bparts = {cudnn_gate_of_tf_block[j]: b[j * 128:(j + 1) * 128] for j in range(4)}
+            split = [rng.standard_normal(128).astype(np.float32) for _ in range(4)]        # bW arbitrary, bR = b - bW
+            biases += split + [bparts[g] - split[g] for g in range(4)]
+        tensors["LSTM%d/cudnn_lstm/opaque_kernel" % layer] = np.concatenate(mats + biases)
+    assert tensors["LSTM1/cudnn_lstm/opaque_kernel"].size == 165888
+    prefix = str(tmp_path / "model")
+    tf_bundle.write_checkpoint(prefix, tensors)
+    r = weights.load_weights(prefix)
+    for k in w:
+        if k.endswith("_bias") and k.startswith("lstm"):
+            assert np.abs(w[k] - r[k]).max() < 1e-6, k       # bW + bR: one float32 rounding away from b
+        else:
+            assert np.array_equal(w[k], r[k]), k
+    with pytest.raises(ValueError, match="opaque CudnnLSTM buffer"):
+        tf_bundle.cudnn_opaque_to_canonical(np.zeros(100, np.float32), 32, 128)
+
+
+def test_reader_on_a_checkpoint_written_by_tensorflow_itself_when_present():
+    """tools/mint_tf_golden.py --mini-checkpoint, run under TF 1.13, leaves a tf.train.Saver checkpoint of a 4-unit version of the
+    graph (real tensor-bundle bytes, real variable names, an optimizer-scope variable and the int64 global step to skip) plus a JSON
+    listing of what TF holds.  Until someone commits those files the reader has only ever read bundles written by this repository."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = os.path.join(root, "tests", "golden", "tf113_mini")
+    if not os.path.isfile(prefix + ".index"):
+        pytest.skip("tests/golden/tf113_mini.* absent: no checkpoint written by TensorFlow itself has been read yet -- "
+                    "`python tools/mint_tf_golden.py --mini-checkpoint` under tensorflow==1.13.2 mints it")
+    doc = json.load(open(prefix + ".json"))
+    got = tf_bundle.read_tensors(prefix)
+    floats = {n: v for n, v in doc["variables"].items() if v["dtype"] == "float32"}
+    assert set(floats) <= set(got)
+    for n, v in floats.items():
+        assert list(got[n].shape) == v["shape"] and np.array_equal(got[n].ravel(), np.asarray(v["values"], dtype=np.float32)), n
+    h = doc["widths"][0]
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import mint_tf_golden
+    assert set(mint_tf_golden.tf_variable_names(h)) <= set(got)          # TF's names ARE the loader's names

@@ -27,8 +27,8 @@ passes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 N = 262144
 MODES = ((3, 1024), (1, 4096), (2, 1024), (3, 4096), (1, 1024), (2, 2048), (3, 8192), (3, 512))
 
-if not os.path.isfile(build.WAITALL_OUT):
-    build.build_waitall()
+if not os.path.isfile(build.WAITALL_OUT) or os.path.getmtime(build.WAITALL_OUT) < os.path.getmtime(build.OUT):
+    build.build_waitall()          # stale or absent: the check build must come from the same sources as the production one
 box = box_info(full=False)
 print("box: %s %s" % (box["host"], " ".join(box["unique_ids"])), flush=True)
 w = weights.synthetic_weights(seed=20250928, head_gain=4.0)

@@ -45,24 +45,38 @@ def _run(cmd, timeout=30):
         return "(%s: %s)" % (" ".join(cmd), e)
 
 
+_PCI = []        # sysfs directory of the GPU this process sees (found once by box_info)
+
+
 def box_info(full=True):
-    """Who ran this: GPU unique id(s) from sysfs, and rocm-smi's view of id, clocks, power and RAS counters."""
-    info = {"host": os.uname().nodename, "unique_ids": []}
-    for p in sorted(glob.glob("/sys/class/drm/card*/device/unique_id")):
-        try:
-            info["unique_ids"].append(open(p).read().strip())
-        except OSError:
-            pass
+    """Who ran this.  A box holds eight GPUs and the container sees one: rocm-smi (which honours the container's view) names its
+    unique id and PCI bus; clocks and power are then read from THAT device's sysfs directory."""
+    import re
+    info = {"host": os.uname().nodename, "unique_ids": [], "pci": None}
+    smi = _run(["rocm-smi", "--showuniqueid", "--showbus", "--showclocks", "--showpower", "--showtemp"])
+    info["unique_ids"] = re.findall(r"Unique ID:\s*(0x[0-9a-fA-F]+)", smi)
+    m = re.search(r"PCI Bus:\s*([0-9a-fA-F:.]+)", smi)
+    if m:
+        info["pci"] = m.group(1)
+        path = "/sys/bus/pci/devices/%s" % m.group(1).lower()
+        if os.path.isdir(path) and not _PCI:
+            _PCI.append(path)
+    if not info["unique_ids"]:          # no rocm-smi: every card the kernel shows
+        for p in sorted(glob.glob("/sys/class/drm/card*/device/unique_id")):
+            try:
+                info["unique_ids"].append("0x" + open(p).read().strip())
+            except OSError:
+                pass
     if full:
-        info["rocm_smi"] = _run(["rocm-smi", "--showuniqueid", "--showbus", "--showclocks", "--showpower", "--showtemp"])
+        info["rocm_smi"] = smi
         info["ras"] = _run(["rocm-smi", "--showrasinfo", "all"], timeout=60)
     return info
 
 
 def gpu_state():
-    """One line of clocks / power while the run is hot (cheap: sysfs only)."""
+    """One line of clocks / power while the run is hot (cheap: sysfs of the device box_info found)."""
     out = []
-    for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+    for card in _PCI[:1]:
         try:
             sclk = [line for line in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines() if line.endswith("*")]
             out.append("sclk %s" % (sclk[0].split(":")[1].strip(" *") if sclk else "?"))
@@ -74,7 +88,6 @@ def gpu_state():
                 break
             except (OSError, ValueError):
                 pass
-        break
     return ", ".join(out)
 
 
