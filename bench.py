@@ -57,8 +57,8 @@ DESIGN_BYTES = {
     "proj2": 33 * 256 * 4 + 33 * 1024 * 4,
     "lstm2": 33 * 1024 * 4 + 33 * 256 * 4,
     "l3": 0,
-    "l4": 33 * 256 * 4 + 16 * 192 * 4,
-    "tail": 16 * 192 * 4 + 90 * 4,
+    "l4": 33 * 256 * 4 + 32 * 192 * 4,
+    "tail": 32 * 192 * 4 + 90 * 4,
 }
 # HBM bytes per launch come from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py traffic --json writes profiles/pmc_traffic.json).  Not collected

@@ -16,7 +16,7 @@ SYMBOLS = (
     "clair_abi_version", "clair_device_count", "clair_last_error",
     "clair_engine_create", "clair_engine_destroy",
     "clair_set_tensor", "clair_finalize_weights",
-    "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts",
+    "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts", "clair_submit_ex", "clair_decode",
     "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
@@ -24,7 +24,7 @@ SYMBOLS = (
     "clair_comm_preflight", "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_last_error", "clair_comm_barrier",
     "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
 )
-KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail")
+KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail", "decode")
 
 _lib = None
 _libs = {}
@@ -61,6 +61,8 @@ def load(path=None):
     lib.clair_finalize_weights.argtypes = [c_vp]
     lib.clair_predict.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.clair_submit.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
+    lib.clair_submit_ex.argtypes = [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+    lib.clair_decode.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
     lib.clair_wait.argtypes = [c_vp, c_int]
     lib.clair_slot_input.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
     lib.clair_submit_counts.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
@@ -175,6 +177,40 @@ class Engine(object):
         outs = self._alloc_out(c.shape[0])
         self._check(self._lib.clair_submit_counts(self._h, slot, _ptr(c), c.shape[0], *[_ptr(o) for o in outs]), "clair_submit_counts")
         self._pending[slot] = (c, outs)
+
+    def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
+        """clair_submit_ex: forward pass + decode on the device.  batch: [n,33,8,4] float32, or raw int16 counts with counts=True;
+        centre: uint8 [n,2] (clair_amd._hostapi.centre_bytes).  wait(slot) then returns the call records (structured array,
+        _hostapi.CALL_DTYPE), or (records, [gt21, genotype, len1, len2]) with with_probabilities=True."""
+        from clair_amd._hostapi import CALL_DTYPE
+        if counts:
+            x = np.ascontiguousarray(batch, dtype=np.int16)
+            if x.ndim != 4 or x.shape[1:] != (33, 8, 4):
+                raise ValueError("counts must have shape [n,33,8,4], got %r" % (x.shape,))
+        else:
+            x = self._prep_x(batch)
+        n = x.shape[0]
+        c = np.ascontiguousarray(centre, dtype=np.uint8)
+        if c.shape != (n, 2):
+            raise ValueError("centre must be uint8 [%d,2], got %r" % (n, c.shape))
+        calls = np.zeros(n, dtype=CALL_DTYPE)
+        outs = self._alloc_out(n) if with_probabilities else None
+        ptrs = [_ptr(o) for o in outs] if outs else [None] * 4
+        self._check(self._lib.clair_submit_ex(self._h, int(slot), _ptr(x), int(bool(counts)), n, _ptr(c), _ptr(calls), *ptrs), "clair_submit_ex")
+        self._pending[slot] = ((x, c), (calls, outs) if outs else calls)
+
+    def decode(self, x, Y, centre, slot=0):
+        """clair_decode: the device decode on given probabilities Y = [gt21, genotype, len1, len2] -> call records."""
+        from clair_amd._hostapi import CALL_DTYPE
+        x = self._prep_x(x)
+        n = x.shape[0]
+        ys = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
+        c = np.ascontiguousarray(centre, dtype=np.uint8)
+        if c.shape != (n, 2) or [a.shape for a in ys] != [(n, 21), (n, 3), (n, 33), (n, 33)]:
+            raise ValueError("decode: shapes do not match %d candidates" % n)
+        calls = np.zeros(n, dtype=CALL_DTYPE)
+        self._check(self._lib.clair_decode(self._h, int(slot), _ptr(x), *[_ptr(a) for a in ys], n, _ptr(c), _ptr(calls)), "clair_decode")
+        return calls
 
     def slot_input(self, slot):
         """The slot's page-locked input buffer as a NumPy array [max_batch,33,8,4] float32: fill rows [0,n) and submit

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_crc32c", "clair_host_parse_tensors",
            "clair_host_counts_to_input_i16", "clair_host_counts_to_input_i32",
-           "clair_host_decode_rows", "clair_host_decode_rows_ex",
+           "clair_host_decode_rows", "clair_host_decode_rows_ex", "clair_host_resolve_calls", "clair_host_format_calls", "clair_host_centre_bytes",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
            "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
@@ -33,6 +33,9 @@ def load():
         lib.clair_host_decode_rows.argtypes = [vp, vp, vp, vp, vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64,
                                                ctypes.POINTER(i64), ctypes.POINTER(i32)]
         lib.clair_host_decode_rows_ex.argtypes = lib.clair_host_decode_rows.argtypes + [vp]
+        lib.clair_host_resolve_calls.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+        lib.clair_host_format_calls.argtypes = [vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32), vp]
+        lib.clair_host_centre_bytes.argtypes = [ctypes.c_char_p, vp, i32, vp]
         lib.clair_host_pileup_create.argtypes = [ctypes.c_char_p, i64, i64, vp, i64, i32, i32, i32, i32, i64, i32, ctypes.POINTER(vp)]
         lib.clair_host_pileup_destroy.argtypes = [vp]
         lib.clair_host_pileup_destroy.restype = None
@@ -57,8 +60,8 @@ def load():
         lib.clair_host_evc_take_text.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         lib.clair_host_counts_to_input_i16.argtypes = [vp, i64, vp]
         lib.clair_host_counts_to_input_i32.argtypes = [vp, i64, vp]
-        if lib.clair_host_abi_version() != 4:
-            raise RuntimeError("libclair_host.so has ABI version %d, expected 4: run `python -m clair_amd.build`"
+        if lib.clair_host_abi_version() != 5:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 5: run `python -m clair_amd.build`"
                                % lib.clair_host_abi_version())
         _lib = lib
     return _lib
@@ -170,16 +173,7 @@ def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitiv
         return ([], np.zeros(0, np.uint8)) if with_status else []
     x = np.ascontiguousarray(X, dtype=np.float32).reshape(n, N_VALUES)
     gt21, genotype, len1, len2 = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
-    if hasattr(infos, "native_meta"):          # tensor_binary.InfoTable: the record columns as they are
-        meta, tok = infos.native_meta()
-    else:
-        parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
-        lens = np.fromiter(map(len, parts), dtype=np.int32, count=3 * n)
-        tok = np.empty((n, 6), dtype=np.int32)
-        tok[:, 1::2] = lens.reshape(n, 3)
-        starts = np.cumsum(lens, dtype=np.int64) - lens
-        tok[:, 0::2] = starts.reshape(n, 3)
-        meta = "".join(parts).encode("ascii")
+    meta, tok = _meta_of(infos)
     cap = 4096 + 256 * n + 2 * len(meta)
     out = ctypes.create_string_buffer(cap)
     out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)
@@ -189,6 +183,77 @@ def decode_rows(X, infos, Y, show_reference, haploid_precision, haploid_sensitiv
                                        int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
                                        int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows),
                                        status.ctypes.data)
+    if rc != 0:
+        raise ValueError("native decode: " + lib.clair_host_last_error().decode())
+    rows = out.raw[:out_len.value - 1].decode("ascii").split("\n") if out_len.value else []
+    return (rows, status) if with_status else rows
+
+
+CALL_DTYPE = np.dtype([("status", "u1"), ("family", "u1"), ("index", "<u2"), ("flags", "<u2"), ("gt", "u1"), ("gi", "u1"),
+                       ("alt_b0", "u1"), ("alt_b1", "u1"), ("ins_avail", "u1"), ("reserved0", "u1"), ("ins_code", "<u4"),
+                       ("depth", "<f4"), ("support", "<f4"), ("p_call", "<f4"), ("rounds", "<u4")])      # include/clair_call.h
+assert CALL_DTYPE.itemsize == 32
+
+
+def _meta_of(infos):
+    """(meta bytes, tok int32 [n,6]) of a batch's [[ctg, pos, seq], ...] -- the layout the native decode functions take."""
+    n = len(infos)
+    if hasattr(infos, "native_meta"):          # tensor_binary.InfoTable / MetaInfoTable: the record columns as they are
+        return infos.native_meta()
+    parts = [s for info in infos for s in (info[0], str(info[1]), info[2])]
+    lens = np.fromiter(map(len, parts), dtype=np.int32, count=3 * n)
+    tok = np.empty((n, 6), dtype=np.int32)
+    tok[:, 1::2] = lens.reshape(n, 3)
+    starts = np.cumsum(lens, dtype=np.int64) - lens
+    tok[:, 0::2] = starts.reshape(n, 3)
+    return "".join(parts).encode("ascii"), tok
+
+
+def centre_bytes(infos):
+    """uint8 [n,2]: the centre character of every candidate's reference window and min(window length, 255) -- what the call
+    resolution needs of the candidate's text (clair_host_resolve_calls, clair_submit_ex)."""
+    lib = load()
+    n = len(infos)
+    meta, tok = _meta_of(infos)
+    out = np.zeros((n, 2), dtype=np.uint8)
+    if n and lib.clair_host_centre_bytes(meta, tok.ctypes.data, n, out.ctypes.data) != 0:
+        raise ValueError("native decode: " + lib.clair_host_last_error().decode())
+    return out
+
+
+def resolve_calls(X, Y, centre):
+    """clair_host_resolve_calls: the arithmetic half of the decode on the CPU -> structured array of call records (CALL_DTYPE)."""
+    lib = load()
+    n = len(centre)
+    calls = np.zeros(n, dtype=CALL_DTYPE)
+    if n == 0:
+        return calls
+    x = np.ascontiguousarray(X, dtype=np.float32).reshape(n, N_VALUES)
+    gt21, genotype, len1, len2 = [np.ascontiguousarray(a, dtype=np.float32) for a in Y]
+    c = np.ascontiguousarray(centre, dtype=np.uint8)
+    if lib.clair_host_resolve_calls(x.ctypes.data, gt21.ctypes.data, genotype.ctypes.data, len1.ctypes.data, len2.ctypes.data,
+                                    c.ctypes.data, n, calls.ctypes.data) != 0:
+        raise ValueError("native decode: " + lib.clair_host_last_error().decode())
+    return calls
+
+
+def format_calls(calls, infos, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2, with_status=False):
+    """clair_host_format_calls: call records (from the GPU decode kernel or resolve_calls) + the batch's text -> VCF rows."""
+    lib = load()
+    n = len(infos)
+    if n == 0:
+        return ([], np.zeros(0, np.uint8)) if with_status else []
+    calls = np.ascontiguousarray(calls, dtype=CALL_DTYPE)
+    if len(calls) != n:
+        raise ValueError("%d call records for %d candidates" % (len(calls), n))
+    meta, tok = _meta_of(infos)
+    cap = 4096 + 256 * n + 2 * len(meta)
+    out = ctypes.create_string_buffer(cap)
+    out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)
+    status = np.zeros(n, dtype=np.uint8)
+    rc = lib.clair_host_format_calls(calls.ctypes.data, meta, tok.ctypes.data, n, int(bool(show_reference)), int(bool(haploid_precision)),
+                                     int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
+                                     int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows), status.ctypes.data)
     if rc != 0:
         raise ValueError("native decode: " + lib.clair_host_last_error().decode())
     rows = out.raw[:out_len.value - 1].decode("ascii").split("\n") if out_len.value else []

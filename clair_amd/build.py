@@ -71,8 +71,21 @@ def build_waitall():
     return WAITALL_OUT
 
 
+PROBE_OUT = os.path.join(HERE, "libclair_amd_probe.so")
+
+
+def build_probe():
+    """The PROBE build (-DCLAIR_L34_STAMPS): l3l4_kernel stamps its phase boundaries with s_memtime (tools/gpu/l34_stamps.py).
+    Timing instrument only; nothing ships or tests against it."""
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-DCLAIR_L34_STAMPS"]
+                          + SRCS + ["-o", PROBE_OUT, "-ldl"])
+    return PROBE_OUT
+
+
 if __name__ == "__main__":
-    if "--waitall" in sys.argv:
+    if "--probe" in sys.argv:
+        print(build_probe())
+    elif "--waitall" in sys.argv:
         print(build_waitall())
     else:
         print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

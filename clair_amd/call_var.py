@@ -431,8 +431,7 @@ class VariantDecoder(object):
         (call_var.py:498-524, 540-565, 805-823): the native decoder flags exactly those candidates and only they are decoded
         again on the Python look-up path; everything else runs on the Python restatement below."""
         cfg = self.cfg
-        if (self.native and not cfg.is_debug and not cfg.is_output_for_ensemble and not self.bases.always_use_bam
-                and isinstance(cfg.quality_score_for_pass, (int, type(None)))):
+        if self.native_applies():
             if len(Y[0]) != len(infos):
                 sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(Y[0])))
             from clair_amd import _hostapi
@@ -451,6 +450,38 @@ class VariantDecoder(object):
                 at += int(st & 1)
             return out
         return self.decode_batch_py(X, infos, Y)
+
+    def native_applies(self):
+        """The configuration the native decoders cover (host: clair_host_decode_rows_ex; device: clair_submit_ex + clair_host_format_calls):
+        no --debug, no --output_for_ensemble, no --pysam_for_all_indel_bases, an integer --qual."""
+        cfg = self.cfg
+        return (self.native and not cfg.is_debug and not cfg.is_output_for_ensemble and not self.bases.always_use_bam
+                and isinstance(cfg.quality_score_for_pass, (int, type(None))))
+
+    def decode_calls(self, X, infos, calls, Y=None):
+        """Rows of one batch from the call records the GPU decode kernel left (include/clair_call.h): only text is made here.  With a BAM
+        open, the candidates whose record says the reference would have consulted it are decoded again on the Python look-up path --
+        which needs their probabilities (Y)."""
+        from clair_amd import _hostapi
+        cfg = self.cfg
+        if len(calls) != len(infos):
+            sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(calls)))
+        rows, status = _hostapi.format_calls(calls, infos, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
+                                             cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass, self.arith == "numpy2",
+                                             with_status=True)
+        if self.lookup.sam is None or not (status & 2).any():
+            return rows
+        if Y is None:
+            raise ValueError("decode_calls: candidates that consult the BAM need their probabilities")
+        out, at = [], 0
+        Y = [np.asarray(a, dtype=np.float32) for a in Y]
+        for i, st in enumerate(status):
+            if st & 2:
+                out.extend(self.decode_batch_py(X[i:i + 1], infos[i:i + 1], [a[i:i + 1] for a in Y]))
+            elif st & 1:
+                out.append(rows[at])
+            at += int(st & 1)
+        return out
 
     def decode_batch_py(self, X, infos, Y):
         gt21, genotype, len1, len2 = [np.asarray(a, dtype=np.float32) for a in Y]
@@ -615,6 +646,12 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     t0 = time()
     use_async = hasattr(m, "submit") and hasattr(m, "wait")
     n_slots = max(1, int(getattr(m, "n_slots", 2))) if use_async else 1
+    # The decode on the device (include/clair_amd.h: clair_submit_ex): the outcome products and the arg-max run as one more kernel behind
+    # the forward pass and 32-byte call records come back instead of 360 bytes of probabilities; the emit thread only formats text.
+    # Same rows, byte for byte (tests/test_e2e_gpu.py).  CLAIR_AMD_DEVICE_DECODE=0 keeps the decode on the host.
+    device_decode = (use_async and hasattr(m, "submit_calls") and getattr(decoder, "native_applies", lambda: False)()
+                     and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0")
+    keep_probabilities = device_decode and decoder.lookup.sam is not None      # candidates that consult the BAM are decoded again from them
     loaded = queue.Queue(maxsize=n_slots + 2)      # batches parsed ahead
     finished = queue.Queue(maxsize=n_slots + 2)    # (batch, prediction) waiting to be decoded and written
     failures = []                                  # exc_info of a stage that died on its helper thread
@@ -655,7 +692,11 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
                 if item is END:
                     return
                 batch, prediction = item
-                writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
+                if device_decode:
+                    calls, probabilities = prediction if keep_probabilities else (prediction, None)
+                    writer.write_rows(decoder.decode_calls(batch[0], batch[1], calls, probabilities))
+                else:
+                    writer.write_rows(decoder.decode_batch(batch[0], batch[1], prediction))
         except BaseException:
             failures.append(sys.exc_info())
             stop.set()
@@ -673,7 +714,7 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     def retire():
         slot, batch = inflight.pop(0)
         prediction = m.wait(slot)
-        m.prediction = prediction
+        m.prediction = (prediction[1] if keep_probabilities else None) if device_decode else prediction
         put(finished, (batch, prediction))
 
     try:
@@ -690,7 +731,12 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
             if len(inflight) == n_slots:
                 retire()
             slot = k % n_slots
-            if len(current) > 2 and current[2] is not None and hasattr(m, "submit_counts"):
+            has_counts = len(current) > 2 and current[2] is not None
+            if device_decode:
+                from clair_amd import _hostapi
+                m.submit_calls(slot, current[2] if has_counts else current[0], _hostapi.centre_bytes(current[1]), counts=has_counts,
+                               with_probabilities=keep_probabilities)
+            elif has_counts and hasattr(m, "submit_counts"):
                 m.submit_counts(slot, current[2])
             else:
                 m.submit(slot, current[0])

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace clair {
 
@@ -16,7 +17,7 @@ constexpr int L3_OUT = 7680;   // 30*256, flat index u*256+c (clair/model.py:474
 constexpr int L4_UNITS = 192;  // clair/model.py:82
 constexpr int L5_UNITS = 96;   // clair/model.py:84-91
 constexpr int OUT_FLOATS = 90; // 21 + 3 + 33 + 33
-constexpr int L4_SPLITS = 16;  // split-K factor of the 7680->192 GEMM
+constexpr int L4_SPLITS = 32;  // split-K factor of the 7680->192 GEMM: one partial per group of 8 LSTM2 features (dense.hip.h)
 
 // exp via v_exp_f32 (2^x); relative error ~1 ulp, enough for the 2e-6 probability tolerance.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -88,6 +89,12 @@ __device__ __forceinline__ void split2_pk4(const float (&x)[4], uint2 &hi, uint2
 __device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
     // v_mfma_f32_16x16x32_f16: lane (i = l&15, q = l>>4) supplies A[i][8q..8q+7] / B[8q..8q+7][i]; C/D as mfma16
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
+    // v_mfma_f32_32x32x16_f16: lane (i = l%32, q = l/32) supplies A[i][8q..8q+7] / B[8q..8q+7][i];
+    // C/D: column l%32, rows 8*(reg/4) + 4*(l/32) + reg%4
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 typedef __attribute__((address_space(3))) void *lptr_t;

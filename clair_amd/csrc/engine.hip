@@ -16,6 +16,7 @@
 
 #include "common.hip.h"
 #include "dense.hip.h"
+#include "decode.hip.h"
 #include "gemm_split.hip.h"
 #include "lstm32.hip.h"
 #include "lstm32_pair.hip.h"
@@ -41,8 +42,8 @@ struct Slot {
     float *d_x = nullptr;     // [max_pad][1056]
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
     unsigned short *a1 = nullptr;   // [2][33][max_pad][256] fp16: LSTM1 output as its 2-way split
-    float *a2 = nullptr;      // [33][max_pad][256]
-    float *l4part = nullptr;  // [16][max_pad][192]
+    float *a2 = nullptr;      // LSTM2 output, channel-group-major: [32 groups of 8 features][33][n_pad][8]
+    float *l4part = nullptr;  // [32 groups][max_pad rounded to 64][192] split-K partials in the accumulator layout (dense.hip.h)
     unsigned *fuse_flags = nullptr;   // lstm2_fused.hip.h: [2][max_pad/32][33][8] ticket words, one error word, one claim word per workgroup
     unsigned fuse_ticket = 0;         // ticket of the last fused forward pass on this slot
     float *d_out = nullptr;   // [max_pad][90]
@@ -50,6 +51,10 @@ struct Slot {
     float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
     short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first clair_submit_counts
     short *h_counts = nullptr;   // pinned [max_batch][1056]: staging of a caller's pageable count buffer (as h_x is for float input)
+    // device decode (clair_submit_ex): the candidates' centre bytes in, call records out
+    unsigned char *d_centre = nullptr, *h_centre = nullptr;   // [max_pad][2], pinned twin
+    clair_call_t *d_calls = nullptr, *h_calls = nullptr;      // [max_pad], pinned twin
+    clair_call_t *o_calls = nullptr;                          // caller's array of the pending submit (NULL: no decode requested)
     // pending host outputs of a submit
     float *o_gt21 = nullptr, *o_gt = nullptr, *o_l1 = nullptr, *o_l2 = nullptr;
     int pending_n = 0;
@@ -82,15 +87,17 @@ struct clair_engine {
     int fused_recoveries = 0;     // passes re-run on the two-launch path after a fused launch raised its error word
     int proj2_groups = 8;      // persistent workgroup groups per XCD of the projection GEMM: 8 XCDs x 4 gate tiles x groups workgroups (see clair_engine_create)
     int w4_shift = 0;          // the W4 image is W4 * 2^w4_shift (clair_finalize_weights)
+    int w3_shift = 0;          // the (W3 | b3) image is the tensor * 2^w3_shift
+    bool l34_stamps = false;   // CLAIR_AMD_L34_STAMPS=1: l3l4_kernel writes its per-wave phase clocks into the (dead) zx workspace for clair_debug_read(5)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<Slot> slots;
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
     float *bx1 = nullptr, *bx2 = nullptr;   // gate-scaled biases [2][512] of the two layers
-    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr;   // fp16 split MFMA fragment images (lstm32.hip.h, dense.hip.h)
+    unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr, *w3s = nullptr;   // fp16 split MFMA fragment images (lstm32.hip.h, dense.hip.h)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
-    float *w3f = nullptr, *b3 = nullptr, *b4 = nullptr;
+    float *b4 = nullptr;
     float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
     double ms_sum[CLAIR_K_COUNT] = {0};
     int64_t launches[CLAIR_K_COUNT] = {0};
@@ -196,6 +203,10 @@ void free_slot(Slot &s) {
     if (s.h_x) (void)hipHostFree(s.h_x);
     if (s.d_counts) (void)hipFree(s.d_counts);
     if (s.h_counts) (void)hipHostFree(s.h_counts);
+    if (s.d_centre) (void)hipFree(s.d_centre);
+    if (s.h_centre) (void)hipHostFree(s.h_centre);
+    if (s.d_calls) (void)hipFree(s.d_calls);
+    if (s.h_calls) (void)hipHostFree(s.h_calls);
     if (s.stream) (void)hipStreamDestroy(s.stream);
 }
 
@@ -292,14 +303,24 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
-        L3L4Args a{s.a2, e->w3f, e->b3, e->w4s, s.l4part, n_pad, e->tap_l3 ? s.zx : nullptr};   // zx is dead by now
-        hipLaunchKernelGGL(l3l4_kernel, dim3((n_pad / L34_CAND) * L4_SPLITS), dim3(256), 0, s.stream, a);
+        L3L4Args a{s.a2, e->w3s, e->w4s, s.l4part, n_pad, std::ldexp(1.0f, -e->w3_shift), e->tap_l3 ? s.zx : nullptr,
+                   e->l34_stamps ? (unsigned long long *)s.zx : nullptr};   // zx is dead by now
+        hipLaunchKernelGGL(l3l4_kernel, dim3(((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS), dim3(256), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
         TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE};
         hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
+    HIP_TRY(e, hipGetLastError());
+    return 0;
+}
+
+// The decode of the slot's batch on the device (decode.hip.h): probabilities in d_out + window in d_x + centre bytes -> call records.
+int enqueue_decode(clair_engine *e, Slot &s, int n) {
+    KernelTimer kt(e, s, CLAIR_K_DECODE);
+    DecodeArgs a{s.d_x, s.d_out, s.d_centre, s.d_calls, n};
+    hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(256), 0, s.stream, a);
     HIP_TRY(e, hipGetLastError());
     return 0;
 }
@@ -377,6 +398,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     e->max_batch = max_batch;
     e->max_pad = (max_batch + 31) & ~31;
     { const char *t = getenv("CLAIR_AMD_TAP_L3"); e->tap_l3 = t && t[0] == '1'; }
+    { const char *t = getenv("CLAIR_AMD_L34_STAMPS"); e->l34_stamps = !e->tap_l3 && t && t[0] == '1'; }
     // A handle with one slot runs its kernels alone: the projection GEMM takes every CU (8 XCDs x 4 gate tiles x 8 groups).  With
     // batches in flight on several slots the 64-workgroup recurrent kernels of the other slots hold whole CUs for ~80 us; a
     // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Four groups (128
@@ -396,7 +418,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.a1, ((size_t)2 * T_POS * mp * 256 + 128 * 256) * sizeof(unsigned short));   // + slack rows read (never used) by gemm_split's ragged last tile
         if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * mp * L4_UNITS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * ((mp + L34_CAND - 1) / L34_CAND * L34_CAND) * L4_UNITS * sizeof(float));
         if (r == hipSuccess && fused_possible(e)) {
             const size_t words = fuse_words(e->max_pad) + 1 + fuse_claims(e);   // tickets | error word | claims
             r = hipMalloc((void **)&s.fuse_flags, words * sizeof(unsigned));
@@ -418,9 +440,9 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
-    float *w[] = {e->bx1, e->bx2, e->w3f, e->b3, e->b4, e->w5f, e->b5, e->whf, e->bhf};
+    float *w[] = {e->bx1, e->bx2, e->b4, e->w5f, e->b5, e->whf, e->bhf};
     for (float *p : w) (void)hipFree(p);
-    (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s);
+    (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s); (void)hipFree(e->w3s);
     delete e;
 }
 
@@ -440,7 +462,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
-    float **dev[] = {&e->bx1, &e->bx2, &e->w3f, &e->b3, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
+    float **dev[] = {&e->bx1, &e->bx2, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
     if (upload(e, &e->bx1, pack_bias32(T[1], T[3])) || upload(e, &e->bx2, pack_bias32(T[5], T[7]))) return 1;
@@ -465,42 +487,55 @@ int clair_finalize_weights(clair_engine_t *e) {
     }
     if (upload16(e, &e->wh1s, pack_wt32(T[0], T[2], F_IN, 8)) || upload16(e, &e->wh2s, pack_wt32(T[4], T[6], 2 * HID, 8)) ||
         upload16(e, &e->wx1s, pack_wt32(T[0], T[2], 0, 2, (float)(1 << L32_X_SHIFT)))) return 1;
-    {   // L3 B fragments (dense.hip.h: l3l4_kernel): w3f[c][lane][kk*2 + nbk] = W3[c][t = lq*9 + kk][u = nbk*16 + li]
-        std::vector<float> w3f((size_t)256 * 64 * 20, 0.0f);
+    // Power-of-two image shift of a tensor: puts its largest magnitude into [2^13, 2^14).  A freshly initialised W4 has sigma = 0.011 and a
+    // trained one may be smaller still, i.e. residuals below the fp16 normal range -- the low plane would keep them to 3e-8 ABSOLUTE
+    // only (common.hip.h); the kernel that consumes the product multiplies by 2^-shift (exact).
+    auto image_shift = [](float vmax) {
+        if (!(vmax > 0.0f) || !std::isfinite(vmax)) return 0;
+        int ex = 0;
+        (void)std::frexp(vmax, &ex);              // vmax = m * 2^ex, m in [0.5, 1)
+        return std::max(-20, std::min(40, 14 - ex));
+    };
+    {   // L3 A fragments (dense.hip.h: l3l4_kernel): (W3[c]^T | b3[c]) * 2^w3_shift as fp16 split, [c][kk][plane][lane][8]: row u = lane%32,
+        // k = 16kk + 8(lane/32) + j: t for k < 33, the bias at k = 33 (the activation operand carries 1.0 there), zero beyond and for u >= 30
+        float vmax = 0.0f;
+        for (float v : T[8]) vmax = std::max(vmax, std::fabs(v));
+        for (float v : T[9]) vmax = std::max(vmax, std::fabs(v));
+        e->w3_shift = image_shift(vmax);
+        const float pow2 = std::ldexp(1.0f, e->w3_shift);
+        std::vector<unsigned short> w3s((size_t)256 * 3 * 2 * 64 * 8, 0);
         for (int c = 0; c < 256; ++c)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int kk = 0; kk < 9; ++kk)
-                    for (int nbk = 0; nbk < 2; ++nbk) {
-                        const int t = (lane >> 4) * 9 + kk, u = nbk * 16 + (lane & 15);
-                        if (t < T_POS && u < L3_UNITS)
-                            w3f[((size_t)c * 64 + lane) * 20 + kk * 2 + nbk] = T[8][((size_t)c * T_POS + t) * L3_UNITS + u];
+            for (int kk = 0; kk < 3; ++kk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int u = lane & 31, k = 16 * kk + 8 * (lane >> 5) + j;
+                        float v = 0.0f;
+                        if (u < L3_UNITS && k < T_POS) v = T[8][((size_t)c * T_POS + k) * L3_UNITS + u];
+                        else if (u < L3_UNITS && k == T_POS) v = T[9][(size_t)c * L3_UNITS + u];
+                        unsigned short hi, lo;
+                        split2_host(v * pow2, hi, lo);
+                        const size_t base = ((((size_t)c * 3 + kk) * 2) * 64 + lane) * 8 + j;
+                        w3s[base] = hi;
+                        w3s[base + 64 * 8] = lo;
                     }
-        if (upload(e, &e->w3f, w3f) || upload(e, &e->b3, T[9])) return 1;
+        if (upload16(e, &e->w3s, w3s)) return 1;
     }
-    {   // W4 as fp16 split B fragments of the fused L3/L4 kernel (dense.hip.h): [cg][ks][nb][plane][lane][8]
-        // The image is W4 * 2^w4_shift (exact): a freshly initialised W4 has sigma = 0.011 and a trained one may be smaller still,
-        // i.e. residuals below the fp16 normal range -- the low plane would keep them to 3e-8 ABSOLUTE only (common.hip.h).  The
-        // shift puts the largest |W4| into [2^13, 2^14); the kernel that reduces the split-K partials multiplies by 2^-w4_shift.
+    {   // W4 as fp16 split B fragments of the fused L3/L4 kernel (dense.hip.h): [cg][ks][nb][plane][lane][8]: row (2ks + lane/32)*256 + cg*8 + j
+        // of W4 * 2^w4_shift, column nb*32 + lane%32; the kernel that reduces the split-K partials multiplies by 2^-w4_shift.
         float w4max = 0.0f;
         for (float v : T[10]) w4max = std::max(w4max, std::fabs(v));
-        e->w4_shift = 0;
-        if (w4max > 0.0f && std::isfinite(w4max)) {
-            int ex = 0;
-            (void)std::frexp(w4max, &ex);              // w4max = m * 2^ex, m in [0.5, 1)
-            e->w4_shift = std::max(-20, std::min(40, 14 - ex));
-        }
+        e->w4_shift = image_shift(w4max);
         const float w4_pow2 = std::ldexp(1.0f, e->w4_shift);
-        std::vector<unsigned short> w4s((size_t)16 * 15 * 12 * 2 * 64 * 8);
-        for (int cg = 0; cg < 16; ++cg)
-            for (int ks = 0; ks < 15; ++ks)
-                for (int nb = 0; nb < 12; ++nb)
+        std::vector<unsigned short> w4s((size_t)L4_SPLITS * L34_KS * 6 * 2 * 64 * 8);
+        for (int cg = 0; cg < L4_SPLITS; ++cg)
+            for (int ks = 0; ks < L34_KS; ++ks)
+                for (int nb = 0; nb < 6; ++nb)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int j = 0; j < 8; ++j) {
-                            const int li = lane & 15, lq = lane >> 4;
-                            const int u = 2 * ks + (lq >> 1), ch = 8 * (lq & 1) + j;
+                            const int u = 2 * ks + (lane >> 5), col = nb * 32 + (lane & 31);
                             unsigned short hi, lo;
-                            split2_host(T[10][((size_t)u * 256 + cg * 16 + ch) * L4_UNITS + nb * 16 + li] * w4_pow2, hi, lo);
-                            const size_t base = (((((size_t)cg * 15 + ks) * 12 + nb) * 2) * 64 + lane) * 8 + j;
+                            split2_host(T[10][((size_t)u * 256 + cg * L34_CH + j) * L4_UNITS + col] * w4_pow2, hi, lo);
+                            const size_t base = (((((size_t)cg * L34_KS + ks) * 6 + nb) * 2) * 64 + lane) * 8 + j;
                             w4s[base] = hi;
                             w4s[base + 64 * 8] = lo;
                         }
@@ -555,6 +590,7 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
     if (s.fuse_flags)
         HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
     s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
+    s.o_calls = nullptr;
     s.pending_n = n;
     return 0;
 }
@@ -589,6 +625,7 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
     if (s.fuse_flags)
         HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
     s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
+    s.o_calls = nullptr;
     s.pending_n = n;
     return 0;
 }
@@ -614,18 +651,115 @@ int clair_wait(clair_engine_t *e, int slot) {
         memcpy(&bad, s.h_out + (size_t)e->max_batch * OUT_FLOATS, sizeof bad);
         if (bad && !s.fused_runs.empty()) {   // re-run on the two-launch path (d_x still holds the input), fetch the outputs again
             if (recover_fused(e, s)) { s.pending_n = 0; return 1; }
-            HIP_TRY(e, hipMemcpy(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
+            if (s.o_calls) {
+                if (enqueue_decode(e, s, n)) { s.pending_n = 0; return 1; }
+                HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
+            }
+            if (s.o_gt21) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(e, hipStreamSynchronize(s.stream));
         }
         s.fused_runs.clear();
     }
-    for (int i = 0; i < n; ++i) {
-        const float *row = s.h_out + (size_t)i * OUT_FLOATS;
-        memcpy(s.o_gt21 + (size_t)i * 21, row, 21 * sizeof(float));
-        memcpy(s.o_gt + (size_t)i * 3, row + 21, 3 * sizeof(float));
-        memcpy(s.o_l1 + (size_t)i * 33, row + 24, 33 * sizeof(float));
-        memcpy(s.o_l2 + (size_t)i * 33, row + 57, 33 * sizeof(float));
-    }
+    if (s.o_gt21)
+        for (int i = 0; i < n; ++i) {
+            const float *row = s.h_out + (size_t)i * OUT_FLOATS;
+            memcpy(s.o_gt21 + (size_t)i * 21, row, 21 * sizeof(float));
+            memcpy(s.o_gt + (size_t)i * 3, row + 21, 3 * sizeof(float));
+            memcpy(s.o_l1 + (size_t)i * 33, row + 24, 33 * sizeof(float));
+            memcpy(s.o_l2 + (size_t)i * 33, row + 57, 33 * sizeof(float));
+        }
+    if (s.o_calls) memcpy(s.o_calls, s.h_calls, (size_t)n * sizeof(clair_call_t));
+    s.o_calls = nullptr;
     s.pending_n = 0;
+    return 0;
+}
+
+// The pipelined call with the decode on the device: input as float32 tensor (input_is_counts == 0) or raw int16 counts; calls != NULL
+// asks for the call records (centre: [n][2] bytes, required then); the four probability arrays are optional then (all or none).
+int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int n, const uint8_t *centre, clair_call_t *calls,
+                    float *gt21, float *genotype, float *l1, float *l2) {
+    if (check_slot(e, slot)) return 1;
+    if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
+    const bool want_probs = gt21 || genotype || l1 || l2;
+    if (!input) return fail(e, "NULL input pointer");
+    if (want_probs && !(gt21 && genotype && l1 && l2)) return fail(e, "the four probability arrays come together or not at all");
+    if (!want_probs && !calls) return fail(e, "nothing asked for: neither call records nor probabilities");
+    if (calls && !centre) return fail(e, "call records need the candidates' centre bytes");
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
+    const int n_pad = (n + 31) & ~31;
+    if (input_is_counts) {
+        if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
+        if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
+        memcpy(s.h_counts, input, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short));   // page-locked staging, as in clair_submit
+        HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
+        const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
+        hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
+    } else {
+        if (input != s.h_x) {
+            if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+            memcpy(s.h_x, input, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float));
+        }
+        HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+    }
+    if (n_pad > n)
+        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
+    if (calls) {
+        if (!s.d_centre) {
+            HIP_TRY(e, hipMalloc((void **)&s.d_centre, (size_t)e->max_pad * 2));
+            HIP_TRY(e, hipHostMalloc((void **)&s.h_centre, (size_t)e->max_batch * 2, hipHostMallocDefault));
+            HIP_TRY(e, hipMalloc((void **)&s.d_calls, (size_t)e->max_pad * sizeof(clair_call_t)));
+            HIP_TRY(e, hipHostMalloc((void **)&s.h_calls, (size_t)e->max_batch * sizeof(clair_call_t), hipHostMallocDefault));
+        }
+        memcpy(s.h_centre, centre, (size_t)n * 2);
+        HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.stream));
+    }
+    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
+    if (calls) {
+        if (enqueue_decode(e, s, n)) return 1;
+        HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
+    }
+    if (want_probs) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    if (s.fuse_flags)
+        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
+    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
+    s.o_calls = calls;
+    s.pending_n = n;
+    return 0;
+}
+
+// The decode alone, on probabilities the caller already has (call_var's --input_probabilities path, clair/call_var.py:1276-1309): synchronous.
+int clair_decode(clair_engine_t *e, int slot, const float *x, const float *gt21, const float *genotype, const float *l1, const float *l2, int n,
+                 const uint8_t *centre, clair_call_t *calls) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(e, "slot %d out of range [0,%d)", slot, (int)e->slots.size());
+    if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
+    if (!x || !gt21 || !genotype || !l1 || !l2 || !centre || !calls) return fail(e, "NULL input/output pointer");
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
+    if (!s.d_centre) {
+        HIP_TRY(e, hipMalloc((void **)&s.d_centre, (size_t)e->max_pad * 2));
+        HIP_TRY(e, hipHostMalloc((void **)&s.h_centre, (size_t)e->max_batch * 2, hipHostMallocDefault));
+        HIP_TRY(e, hipMalloc((void **)&s.d_calls, (size_t)e->max_pad * sizeof(clair_call_t)));
+        HIP_TRY(e, hipHostMalloc((void **)&s.h_calls, (size_t)e->max_batch * sizeof(clair_call_t), hipHostMallocDefault));
+    }
+    for (int i = 0; i < n; ++i) {   // the packed [n][90] rows the kernels exchange
+        float *row = s.h_out + (size_t)i * OUT_FLOATS;
+        memcpy(row, gt21 + (size_t)i * 21, 21 * sizeof(float));
+        memcpy(row + 21, genotype + (size_t)i * 3, 3 * sizeof(float));
+        memcpy(row + 24, l1 + (size_t)i * 33, 33 * sizeof(float));
+        memcpy(row + 57, l2 + (size_t)i * 33, 33 * sizeof(float));
+    }
+    memcpy(s.h_centre, centre, (size_t)n * 2);
+    HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(e, hipMemcpyAsync(s.d_out, s.h_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.stream));
+    if (enqueue_decode(e, s, n)) return 1;
+    HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    memcpy(calls, s.h_calls, (size_t)n * sizeof(clair_call_t));
     return 0;
 }
 
@@ -726,8 +860,9 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
         workgroups[CLAIR_K_LSTM2] = 32 * e->fused_groups + 32 * ((ntiles / 2 + 7) / 8);
         workgroups[CLAIR_K_PROJ2] = 0;
     }
-    workgroups[CLAIR_K_L4] = (n_pad / L34_CAND) * L4_SPLITS;
+    workgroups[CLAIR_K_L4] = ((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS;
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
+    workgroups[CLAIR_K_DECODE] = (n + 3) / 4;       // launched only by clair_submit_ex with call records asked for
     return 0;
 }
 
@@ -757,21 +892,34 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
         for (int64_t i = 0; i < count; ++i) host[i] = f16_value(planes[i]) + f16_value(planes[avail + i]);
         return 0;
     }
+    if (which == 2) {   // LSTM2 output lives channel-group-major [32][33][n_pad][8] (lstm32.hip.h): hand it back as [33][n_pad][256]
+        avail = (int64_t)T_POS * np * 256;
+        if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap 2 holds %lld", (long long)count, (long long)avail);
+        std::vector<float> raw((size_t)avail);
+        HIP_TRY(e, hipMemcpy(raw.data(), s.a2, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < count; ++i) {
+            const int64_t t = i / (np * 256), n = (i / 256) % np, c = i % 256;
+            host[i] = raw[(size_t)((((c / 8) * T_POS + t) * np + n) * 8 + c % 8)];
+        }
+        return 0;
+    }
     switch (which) {
-        case 2: src = s.a2; avail = (int64_t)T_POS * np * 256; break;
         case 4: if (!e->tap_l3) return fail(e, "clair_debug_read: tap 4 needs CLAIR_AMD_TAP_L3=1 at engine creation");
                 src = s.zx; avail = np * L3_OUT; break;
-        case 3: {   // split-K partials live in the accumulator layout (dense.hip.h): hand them back as [16][n_pad][192] in W4's own units
+        case 5: if (!e->l34_stamps) return fail(e, "clair_debug_read: tap 5 needs CLAIR_AMD_L34_STAMPS=1 at engine creation");
+                src = s.zx; avail = ((np + L34_CAND - 1) / L34_CAND) * L4_SPLITS * 4 * 16 * 2; break;   // uint64 pairs of floats
+        case 3: {   // split-K partials live in the accumulator layout (dense.hip.h): hand them back as [32][n_pad][192] in W4's own units
             avail = (int64_t)L4_SPLITS * np * L4_UNITS;
             if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap 3 holds %lld", (long long)count, (long long)avail);
-            std::vector<float> raw((size_t)avail);
+            const int64_t nblk = (np + L34_CAND - 1) / L34_CAND;
+            std::vector<float> raw((size_t)L4_SPLITS * nblk * L34_CAND * L4_UNITS);
             HIP_TRY(e, hipMemcpy(raw.data(), s.l4part, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
             const float inv = std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE;
-            const int64_t nblocks = np / 32;
             for (int64_t i = 0; i < count; ++i) {
                 const int64_t cg = i / (np * L4_UNITS), n = (i / L4_UNITS) % np, col = i % L4_UNITS;
-                const int64_t block = n / 32, row = n % 32, w = col / 48, nb = (col % 48) / 16, li = col % 16, mb = row / 16, lq = (row % 16) / 4, r = row % 4;
-                host[i] = raw[(size_t)(((((cg * nblocks + block) * 4 + w) * 6 + mb * 3 + nb) * 64 + lq * 16 + li) * 4 + r)] * inv;
+                const int64_t blk = n / 64, row = n % 64, mb = row / 32, a = (row % 32) / 8, hq = (row % 8) / 4, r = row % 4;
+                const int64_t nh = col / 96, nb = (col % 96) / 32, l32 = col % 32;
+                host[i] = raw[(size_t)((((((cg * nblk + blk) * 2 + nh) * 6 + mb * 3 + nb) * 4 + a) * 64 + hq * 32 + l32) * 4 + r)] * inv;
             }
             return 0;
         }

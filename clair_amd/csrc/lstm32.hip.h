@@ -44,8 +44,6 @@
 #pragma once
 #include "common.hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 namespace clair {
 
 constexpr int L32_TILE = 32;      // candidates per workgroup
@@ -71,17 +69,11 @@ struct Lstm32Args {
                                 // opened a new page for every CU: ~1100 cycles of translation latency per step, lstm32_probe)
     const unsigned short *whs;  // [2 dir][4 wave][4 b][8 kk][2 plane][64 lane][8] fp16  A fragments of Wh^T, gate-scaled
     unsigned short *aout2;      // FIRST: [2 plane][33][n_pad][256] fp16 planes of the layer output
-    float *aout;                // !FIRST: [33][n_pad][256] fp32
+    float *aout;                // !FIRST: [32 groups of 8 features][33][n_pad][8] fp32 (feature = direction * 128 + unit)
     int n_pad;
     int ntiles;                 // n_pad / 32
     int dir_only;               // -1: workgroup id = 2*tile + direction; 0 / 1: this direction only, workgroup id = tile
 };
-
-__device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
-    // v_mfma_f32_32x32x16_f16: lane (i = l%32, q = l/32) supplies A[i][8q..8q+7] / B[8q..8q+7][i];
-    // C/D: column l%32, rows 8*(reg/4) + 4*(l/32) + reg%4
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 // The same MFMA as inline asm, accumulating in VGPRs, the resident weight operand pinned to the AGPR half of
 // the register file ("a").  hipcc pads no hazards around an asm statement (cdna_hip_programming.md 5.7):
@@ -253,7 +245,11 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
     //      ~200 issue cycles; this way a store covers two whole 512-byte fp32 rows / four 256-byte fp16 rows).  Split into an LDS
     //      read, conversion micro-steps and the stores so that the pieces can sit in different MFMA shadows.
     //      layer 1: piece j = 16-byte chunk g = 256 j + tid of [plane][32 rows][16 chunks of 8 units]
-    //      layer 2: piece j = 16-byte chunk g = 256 j + tid of [32 rows][32 chunks of 4 units] (fp32 sum of the two planes)
+    //      layer 2: piece j = 16-byte chunk g = 256 j + tid of [16 channel groups][32 candidates][2 halves of 4 units] (fp32 sum of the two
+    //      planes): the output is stored channel-group-major, [32 groups of 8 features][33 t][n_pad][8], because its only reader
+    //      (l3l4_kernel) stages [t][64 candidates][one group] tiles: with candidate rows of 256 features that tile was 2 112 separate
+    //      32-byte quarter-lines per workgroup and its 66 LDS-DMA instructions took 9 700 cycles to ISSUE (a quarter of the
+    //      kernel, tools/gpu/l34_stamps.py); group-major it is 66 contiguous KiB
     f16x8 cp[FIRST ? 4 : 1];
     f16x4 c4[FIRST ? 1 : 4][2];
     f32x4 co[FIRST ? 1 : 4];
@@ -262,9 +258,9 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
         for (int j = 0; j < 4; ++j) {
             const int g = j * 256 + tid;
             if (FIRST) cp[j] = *(const f16x8 *)&hbuf[s & 1][g >> 9][(g >> 4) & 31][(g & 15) * 8];
-            else {
-                c4[j][0] = *(const f16x4 *)&hbuf[s & 1][0][g >> 5][(g & 31) * 4];
-                c4[j][1] = *(const f16x4 *)&hbuf[s & 1][1][g >> 5][(g & 31) * 4];
+            else {   // chunk g: channel group g >> 6 (8 units), candidate (g & 63) >> 1, half g & 1
+                c4[j][0] = *(const f16x4 *)&hbuf[s & 1][0][(g & 63) >> 1][(g >> 6) * 8 + (g & 1) * 4];
+                c4[j][1] = *(const f16x4 *)&hbuf[s & 1][1][(g & 63) >> 1][(g >> 6) * 8 + (g & 1) * 4];
             }
         }
     };
@@ -281,8 +277,8 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
         if (FIRST) {
             const size_t plane = (size_t)T_POS * p.n_pad * (2 * HID);
             *(f16x8 *)(p.aout2 + (g >> 9) * plane + row0 + (size_t)((g >> 4) & 31) * (2 * HID) + (g & 15) * 8) = cp[j];
-        } else {
-            *(f32x4 *)(p.aout + row0 + (size_t)(g >> 5) * (2 * HID) + (g & 31) * 4) = co[j];
+        } else {   // a2 is channel-group-major for its only reader (dense.hip.h): [32 groups][33 t][n_pad][8]; a wave store = one group's 32 x 8 block, 1 KiB
+            *(f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile * L32_TILE) * 8) + (g & 63) * 4) = co[j];
         }
     };
 

@@ -18,7 +18,7 @@ namespace clair {
 struct Lstm32PairArgs {
     const float *zx;            // [2 dir][n_pad/32][33][4 wave][4 b][4 a][64 lane][4 c]  x-projection, bias included (gemm_split.hip.h)
     const unsigned short *whs;  // [2 dir][4 wave][4 b][8 kk][2 plane][64 lane][8] fp16  A fragments of Wh^T, gate-scaled
-    float *aout;                // [33][n_pad][256] fp32
+    float *aout;                // [32 groups of 8 features][33][n_pad][8] fp32
     int n_pad;
     int ntiles;                 // n_pad / 32; workgroup id = 2 * pair + direction, tiles 2*pair and min(2*pair + 1, ntiles - 1)
 };
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             z[4 * a + 0] = v[0]; z[4 * a + 1] = v[1]; z[4 * a + 2] = v[2]; z[4 * a + 3] = v[3];
         }
     };
-    // h (both planes complete in LDS) -> HBM as fp32, piece j = 16-byte chunk g = 256 j + tid of [32 rows][32 chunks of 4 units],
+    // h (both planes complete in LDS) -> HBM as fp32, piece j = 16-byte chunk g = 256 j + tid of [16 groups][32 candidates][2 halves of 4 units],
     //   in two halves of two pieces each (registers: the whole tile at once would spill)
     f16x4 c4[2][2];
     f32x4 co[2];
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int g = (half * 2 + j) * 256 + tid;
-            c4[j][0] = *(const f16x4 *)&hbuf[tl][s & 1][0][g >> 5][(g & 31) * 4];
-            c4[j][1] = *(const f16x4 *)&hbuf[tl][s & 1][1][g >> 5][(g & 31) * 4];
+            c4[j][0] = *(const f16x4 *)&hbuf[tl][s & 1][0][(g & 63) >> 1][(g >> 6) * 8 + (g & 1) * 4];   // chunk g: group g >> 6, candidate (g & 63) >> 1, half g & 1
+            c4[j][1] = *(const f16x4 *)&hbuf[tl][s & 1][1][(g & 63) >> 1][(g >> 6) * 8 + (g & 1) * 4];
         }
     };
     auto copy_cvt = [&](int i) {   // micro-step i = 0..3 of a half: two units each
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto copy_write = [&](int tl, int s, int half, int j) {
         const int t = d ? T_POS - 1 - s : s;
         const int g = (half * 2 + j) * 256 + tid;
-        const size_t row0 = ((size_t)t * p.n_pad + (size_t)tile_of[tl] * L32_TILE) * (2 * HID) + d * HID;
-        *(f32x4 *)(p.aout + row0 + (size_t)(g >> 5) * (2 * HID) + (g & 31) * 4) = co[j];
+        *(f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile_of[tl] * L32_TILE) * 8) + (g & 63) * 4) = co[j];   // group-major (lstm32.hip.h)
     };
 
     f32x16 acc[2];        // block b accumulates in acc[b & 1]

@@ -89,6 +89,11 @@ class Clair(object):
         run on the device, the host link carries half the bytes.  Same outputs as submit() on the float32 tensor."""
         self._engine.submit_counts(slot, counts)
 
+    def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
+        """Forward pass + decode on the device (include/clair_amd.h: clair_submit_ex): wait(slot) returns the call records of
+        include/clair_call.h -- or (records, probabilities) -- instead of the probabilities."""
+        self._engine.submit_calls(slot, batch, centre, counts=counts, with_probabilities=with_probabilities)
+
     def wait(self, slot):
         return self._engine.wait(slot)
 

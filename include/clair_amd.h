@@ -18,13 +18,14 @@
 #define CLAIR_AMD_H
 
 #include <stdint.h>
+#include "clair_call.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
- * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight (round 3). */
+ * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode and kernel id CLAIR_K_DECODE (round 3). */
 #define CLAIR_ABI_VERSION 3
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
@@ -73,7 +74,8 @@ enum clair_kernel_id {
     CLAIR_K_L3 = 4,     /* (unused: slice dense is fused into CLAIR_K_L4)    */
     CLAIR_K_L4 = 5,     /* slice dense 256 x (33->30) + selu, split-K GEMM 7680->192 */
     CLAIR_K_TAIL = 6,   /* L4 reduce+selu, L5 x4, heads, selu, softmax       */
-    CLAIR_K_COUNT = 7
+    CLAIR_K_DECODE = 7, /* probabilities -> call records (clair_submit_ex only) */
+    CLAIR_K_COUNT = 8
 };
 
 typedef struct clair_engine clair_engine_t;
@@ -124,6 +126,26 @@ int clair_slot_input(clair_engine_t *e, int slot, float **x_pinned);
 int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int n, float *gt21, float *genotype,
                         float *indel_len1, float *indel_len2);
 
+/* The pipelined call with the DECODE on the device.  What call_var does with the probabilities of a batch -- the ten outcome families
+ * (1 179 float32 products, clair/call_var.py:589-690), the iterative arg-max with exact-equality membership tests (:693-947), genotype,
+ * depth, supporting reads and the probability QUAL starts from (:1002-1166) -- runs as one more kernel behind the forward pass, and what
+ * comes back per candidate is the 32-byte call record of include/clair_call.h instead of (or besides) the 360 bytes of probabilities.
+ * clair_host_format_calls (include/clair_host.h) turns records into VCF rows; clair_host_resolve_calls is the CPU twin of the kernel
+ * (bit-identical records).  input: [n][33][8][4] float32 as for clair_submit (input_is_counts == 0) or raw int16 counts as for
+ * clair_submit_counts (!= 0).  centre: [n][2] bytes per candidate -- the centre character of its reference window (refseq[16],
+ * clair/call_var.py:1015) and min(length of refseq, 255); required when calls != NULL.  calls: caller's array of n records, or NULL.
+ * gt21 / genotype / indel_len1 / indel_len2: all four or all NULL (NULL: the probabilities stay on the device).  Pair with
+ * clair_wait(slot); buffers must stay valid until it returns. */
+int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int n, const uint8_t *centre,
+                    clair_call_t *calls, float *gt21, float *genotype, float *indel_len1, float *indel_len2);
+
+/* The decode alone, on probabilities the caller already holds (call_var --input_probabilities, clair/call_var.py:1276-1309, and the
+ * tests that feed the kernel crafted probabilities: exact ties, exact zeros, products that underflow).  Synchronous; does not need
+ * weights.  x: the candidates' network input [n][33][8][4] float32 (the decode reads depth, supporting reads and the votes on
+ * inserted bases from it). */
+int clair_decode(clair_engine_t *e, int slot, const float *x, const float *gt21, const float *genotype, const float *indel_len1,
+                 const float *indel_len2, int n, const uint8_t *centre, clair_call_t *calls);
+
 /* -- device-resident candidate sets (benchmark / multi-GPU shard driver) ------------------------
  * The candidate set lives in HBM: x_dev [N,33,8,4]; outputs out_dev [N,90] rows laid out
  * gt21(21) | genotype(3) | len1(33) | len2(33).  clair_run_resident enqueues the forward pass
@@ -159,7 +181,7 @@ int clair_engine_counter(clair_engine_t *e, int which, int64_t *value);
 
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
  *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
- *    3 = split-K partials of the L4 product [16,n_pad,192], 4 = L3 output [n_pad,7680] (only when the engine was created
+ *    3 = split-K partials of the L4 product [32,n_pad,192], 4 = L3 output [n_pad,7680] (only when the engine was created
  *    with CLAIR_AMD_TAP_L3=1 in the environment)
  *    (L3/L4 activations only ever exist in LDS / split-K partials).  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);

@@ -10,11 +10,12 @@
 #ifndef CLAIR_HOST_H
 #define CLAIR_HOST_H
 #include <stdint.h>
+#include "clair_call.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define CLAIR_HOST_ABI_VERSION 4
+#define CLAIR_HOST_ABI_VERSION 5
 #define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
 
 int clair_host_abi_version(void);
@@ -66,6 +67,21 @@ int clair_host_decode_rows_ex(const float *x, const float *gt21, const float *ge
                               const char *meta, const int32_t *meta_tok, int n, int show_reference, int haploid_precision,
                               int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out, int64_t out_cap,
                               int64_t *out_len, int *n_rows, uint8_t *status);
+
+/* The two halves of that decode, apart (include/clair_call.h describes the 32-byte record between them).
+ * clair_host_resolve_calls: everything arithmetic -- the ten outcome families, the iterative arg-max, genotype, depth, supporting
+ *   reads, the probability QUAL starts from, the tensor's vote on inserted bases -- for n candidates; centre[2i] = the reference
+ *   window's centre character refseq[16], centre[2i + 1] = min(length of refseq, 255).  It is the CPU twin of the GPU decode kernel
+ *   (include/clair_amd.h: clair_submit_ex) and the yardstick that kernel is compared with bit for bit.
+ * clair_host_format_calls: records + the candidates' text -> rows, exactly the rows clair_host_decode_rows_ex writes for the same
+ *   candidates (that function IS resolve + format per candidate); status as there.
+ * clair_host_centre_bytes: the centre[] array of a batch from its meta table. */
+int clair_host_resolve_calls(const float *x, const float *gt21, const float *genotype, const float *len1, const float *len2,
+                             const uint8_t *centre, int n, clair_call_t *calls);
+int clair_host_format_calls(const clair_call_t *calls, const char *meta, const int32_t *meta_tok, int n, int show_reference,
+                            int haploid_precision, int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out,
+                            int64_t out_cap, int64_t *out_len, int *n_rows, uint8_t *status);
+int clair_host_centre_bytes(const char *meta, const int32_t *meta_tok, int n, uint8_t *centre);
 
 /* -- pileup: alignments -> [33][8][4] count windows, the work of dataPrepScripts/CreateTensor.py:179-394 (OutputAlnTensor) and
  *    :29-65 (generate_tensor) as a streaming builder.  The caller supplies what the reference obtains from its sub-processes:

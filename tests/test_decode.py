@@ -154,6 +154,56 @@ def test_driver_end_to_end_matches_reference_driver(tmp_path, tag, cfgname):
     assert open(out).read() == open(os.path.join(GOLD, "e2e_230_%s.vcf" % tag)).read()
 
 
+class _CallsModel(_OracleModel):
+    """An asynchronous model whose wait() returns call records (include/clair_call.h), as clair_amd.model.Clair does on the GPU: the
+    oracle's probabilities, resolved by the decode kernel's CPU twin."""
+    n_slots = 2
+
+    def __init__(self, w):
+        _OracleModel.__init__(self, w)
+        self.slots, self.calls_submits = {}, 0
+
+    def submit(self, slot, batchX):
+        self.slots[slot] = ("probs", np.asarray(batchX), None, False)
+
+    def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
+        assert not counts
+        self.calls_submits += 1
+        self.slots[slot] = ("calls", np.asarray(batch), centre, with_probabilities)
+
+    def wait(self, slot):
+        from clair_amd import _hostapi
+        kind, x, centre, with_probs = self.slots.pop(slot)
+        Y = self.predict(x)
+        if kind == "probs":
+            return Y
+        calls = _hostapi.resolve_calls(x, Y, centre)
+        return (calls, Y) if with_probs else calls
+
+
+@pytest.mark.parametrize("tag,cfgname", [("default", "default"), ("showref", "showref_qual")])
+def test_driver_with_the_decode_on_the_device_side_writes_the_same_vcf(tmp_path, monkeypatch, tag, cfgname):
+    """call_variants hands a model that offers submit_calls the centre bytes of each batch and formats the call records it gets
+    back: the same VCF as the reference driver's, byte for byte; CLAIR_AMD_DEVICE_DECODE=0 keeps the probabilities path."""
+    from clair_amd import weights
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    for env, expect_calls in ((None, True), ("0", False)):
+        if env is None:
+            monkeypatch.delenv("CLAIR_AMD_DEVICE_DECODE", raising=False)
+        else:
+            monkeypatch.setenv("CLAIR_AMD_DEVICE_DECODE", env)
+        out = str(tmp_path / "o.vcf")
+        args = cvar.build_parser().parse_args(["--tensor_fn", os.path.join(GOLD, "e2e_230.txt.gz"), "--call_fn", out])
+        dec = cvar.VariantDecoder(cvar.OutputConfig(*CONFIGS[cfgname]), arith="numpy2")
+        wr = cvar.VcfWriter(out, "SAMPLE", None, False)
+        m = _CallsModel(w)
+        with redirect_stderr(io.StringIO()):
+            cvar.call_variants(args, m, dec, wr, batch_size=100)
+        wr.close()
+        assert (m.calls_submits > 0) == expect_calls
+        assert open(out).read() == open(os.path.join(GOLD, "e2e_230_%s.vcf" % tag)).read()
+
+
 def test_ensemble_roundtrip_through_input_probabilities(decode_cases, tmp_path):
     """--output_for_ensemble lines fed back through --input_probabilities give the rows the decode
     produces from the %.6f-rounded probabilities (call_var.py:950-1000, 1276-1309)."""

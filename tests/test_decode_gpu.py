@@ -1,0 +1,80 @@
+"""GPU decode (clair_amd/csrc/decode.hip.h) against its CPU twin (clair_host_resolve_calls) and against the full native decode.
+
+Bit-exact: the call record is integers plus three float32 values that are sums / products of inputs in a fixed order."""
+import numpy as np
+import pytest
+
+from clair_amd import _hostapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed, platform="ont", peak=6.0):
+    from test_host import decode_cases
+    return decode_cases(n=n, seed=seed, platform=platform, peak=peak)
+
+
+def _same_records(got, want):
+    for name in want.dtype.names:
+        if name.startswith("reserved"):
+            continue
+        a, b = got[name], want[name]
+        same = a.view(np.uint32) == b.view(np.uint32) if a.dtype.kind == "f" else a == b
+        assert same.all(), "%s differs at %s: device %s, host %s" % (name, np.flatnonzero(~same)[:8], a[~same][:8], b[~same][:8])
+
+
+@pytest.mark.parametrize("platform,peak,seed", [("ont", 6.0, 77), ("illumina", 2.0, 5), ("pacbio_ccs", 12.0, 9), ("ont", 0.5, 11)])
+def test_device_records_equal_the_host_records_bit_for_bit(engine, platform, peak, seed):
+    """Crafted probabilities -- exact ties between classes, exact zeros, indel-heavy rows, truncated reference windows, non-callable and
+    'U' centres, a zero-depth window -- through clair_decode: every field of every record equals clair_host_resolve_calls'."""
+    x, infos, Y = _cases(1000, seed, platform, peak)
+    centre = _hostapi.centre_bytes(infos)
+    want = _hostapi.resolve_calls(x, Y, centre)
+    got = engine.decode(x, Y, centre)
+    _same_records(got, want)
+    ok = want["status"] & 1 == 1
+    assert ok.sum() > 900 and (want["rounds"][ok] > 1).any() and len(np.unique(want["family"][ok])) >= 8
+    # and the rows: format(device records) == the native decode of the same probabilities
+    for cfg in ((True, False, False, None), (False, True, False, 30)):
+        assert _hostapi.format_calls(got, infos, *cfg, False) == _hostapi.decode_rows(x, infos, Y, *cfg, False)
+
+
+def test_products_that_underflow_keep_their_denormal_bits(engine):
+    """Tiny probabilities: products in the float32 denormal range (and below: exact zeros by underflow) must tie and order exactly as
+    on the host, where SSE arithmetic keeps denormals."""
+    rng = np.random.default_rng(3)
+    n = 512
+    x, infos = synth.synthetic_input(n, "ont", seed=21)
+    Y = []
+    for k in (21, 3, 33, 33):
+        e = rng.uniform(-45.0, 0.0, size=(n, k))
+        Y.append(np.power(10.0, e).astype(np.float32))          # 1e-45 .. 1: pairs and triples of these underflow
+    centre = _hostapi.centre_bytes(infos)
+    want = _hostapi.resolve_calls(x, Y, centre)
+    _same_records(engine.decode(x, Y, centre), want)
+    p = want["p_call"][want["status"] & 1 == 1]
+    assert ((p > 0) & (p < 1.2e-38)).any() or (p == 0).any()    # the set really reaches the denormal range
+
+
+def test_nan_probabilities_resolve_to_no_call_on_both_sides(engine):
+    x, infos = synth.synthetic_input(8, "ont", seed=2)
+    Y = [np.full((8, k), np.nan, np.float32) for k in (21, 3, 33, 33)]
+    centre = _hostapi.centre_bytes(infos)
+    _same_records(engine.decode(x, Y, centre), _hostapi.resolve_calls(x, Y, centre))
+
+
+@pytest.mark.parametrize("counts", [False, True])
+def test_submit_ex_returns_the_records_of_its_own_probabilities(engine, synth_weights, counts):
+    """Forward pass + decode in one submit: the records equal the host resolution of the probabilities the same submit returns, and
+    without the probabilities (records only) they are the same records."""
+    raw, infos = synth.synthetic_candidates(1000, "ont", seed=31)
+    x = synth.to_model_input(raw)
+    centre = _hostapi.centre_bytes(infos)
+    batch = raw.astype(np.int16) if counts else x
+    engine.submit_calls(0, batch, centre, counts=counts, with_probabilities=True)
+    calls, Y = engine.wait(0)
+    _same_records(calls, _hostapi.resolve_calls(x, Y, centre))
+    engine.submit_calls(1, batch, centre, counts=counts)
+    only = engine.wait(1)
+    _same_records(only, calls)
+    assert _hostapi.format_calls(only, infos, True, False, False, None, False) == _hostapi.decode_rows(x, infos, Y, True, False, False, None, False)

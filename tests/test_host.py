@@ -21,7 +21,7 @@ def test_host_header_symbols_are_exported():
     assert declared and sorted(_hostapi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.clair_host_abi_version() == 4
+    assert lib.clair_host_abi_version() == 5
 
 
 def _collect(gen, path, batch):
@@ -274,3 +274,61 @@ def test_text_reader_hands_the_native_decoder_the_parsed_fields_as_bytes(tmp_pat
             assert rows == dec.decode_batch(x, as_list, Y) and len(rows) > 0.9 * len(x)
             total += len(x)
     assert total == n - len(range(0, n, 13))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the decode in two halves around the 32-byte call record (include/clair_call.h): resolve (arithmetic) | format (text)
+# ---------------------------------------------------------------------------------------------------------------------
+def decode_cases(n=3000, seed=77, platform="ont", peak=6.0):
+    """Candidates that walk every branch of the decode: peaky random probabilities with exact ties and exact zeros, non-callable
+    and 'U' centres, a zero-depth window, truncated reference windows (deletions that cannot be written down)."""
+    rng = np.random.default_rng(seed)
+    x, infos = synth.synthetic_input(n, platform, seed=seed + 1)
+    infos = [list(i) for i in infos]
+    for k in range(0, n, 97):
+        infos[k][2] = infos[k][2][:16] + "N" + infos[k][2][17:]
+    for k in range(5, n, 131):
+        infos[k][2] = infos[k][2][:16] + "U" + infos[k][2][17:]
+    for k in range(9, n, 61):
+        infos[k][2] = infos[k][2][:17 + (k % 9)]                       # 17 .. 25 characters: short or empty deletion text
+    x[7] = 0.0
+    Y = [_random_probs(rng, n, k, peak) for k in (21, 3, 33, 33)]
+    hot = rng.random(n) < 0.5                                          # make indel outcomes win often, long ones included
+    Y[1][hot] = np.float32([0.02, 0.49, 0.49])
+    for a in (Y[2], Y[3]):
+        a[hot, 16] *= np.float32(0.01)
+        a[hot, 32] += np.float32(0.3) * (rng.random(int(hot.sum())) < 0.2)
+        a[hot, 0] += np.float32(0.3) * (rng.random(int(hot.sum())) < 0.2)
+    return x, infos, Y
+
+
+@pytest.mark.parametrize("arith", ["legacy", "numpy2"])
+def test_resolve_then_format_is_the_native_decode(arith):
+    x, infos, Y = decode_cases()
+    centre = _hostapi.centre_bytes(infos)
+    assert centre.shape == (len(infos), 2) and centre[0, 1] == 33 and chr(centre[0, 0]) == infos[0][2][16]
+    calls = _hostapi.resolve_calls(x, Y, centre)
+    for cfg in ((True, False, False, None), (False, False, False, 100), (True, True, False, None), (True, False, True, 50)):
+        want, st_w = _hostapi.decode_rows(x, infos, Y, *cfg, arith == "numpy2", with_status=True)
+        got, st_g = _hostapi.format_calls(calls, infos, *cfg, arith == "numpy2", with_status=True)
+        assert got == want and np.array_equal(st_g, st_w)
+    # the record itself: every family wins somewhere, fall-throughs happen, flags carry the ties, the probability is a product of two inputs
+    ok = calls["status"] & 1 == 1
+    assert set(np.unique(calls["family"][ok])) == set(range(10))
+    assert (calls["rounds"][ok] > 1).any() and (calls["status"] & 2).any() and (calls["status"] & 8).any()
+    multi_flag = np.array([bin(int(f)).count("1") for f in calls["flags"][ok]])
+    assert (multi_flag >= 1).all() and (multi_flag > 1).any()
+    assert not ok[7] and not ok[0] and ok[5]                            # zero depth / 'N' centre / 'U' centre
+    i = int(np.flatnonzero(ok & (calls["gi"] < 21))[0])
+    zi = {0: 0, 1: 1, 2: 2, 3: 2}[int(calls["gt"][i])]
+    assert calls["p_call"][i] == Y[0][i, calls["gi"][i]] * Y[1][i, zi]
+    assert calls.dtype.itemsize == 32
+
+
+def test_format_rejects_a_record_whose_class_contradicts_its_strings():
+    x, infos, Y = decode_cases(n=200)
+    calls = _hostapi.resolve_calls(x, Y, _hostapi.centre_bytes(infos))
+    i = int(np.flatnonzero((calls["status"] & 1 == 1) & (calls["family"] == 1) & (calls["status"] & 8 == 0))[0])
+    calls["gi"][i] = (calls["gi"][i] + 1) % 21
+    with pytest.raises(ValueError, match="gt21 class"):
+        _hostapi.format_calls(calls, infos, True, False, False, None, False)
