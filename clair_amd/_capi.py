@@ -61,8 +61,10 @@ def load(path=None):
     lib.clair_finalize_weights.argtypes = [c_vp]
     lib.clair_predict.argtypes = [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     lib.clair_submit.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
-    lib.clair_submit_ex.argtypes = [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
-    lib.clair_decode.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
+    older_ok = path is not None or bool(os.environ.get("CLAIR_AMD_LIB"))
+    if not older_ok or hasattr(lib, "clair_submit_ex"):     # an OLDER build named by `path` (A/B timing, tools/gpu/ab_libs.sh) may predate these
+        lib.clair_submit_ex.argtypes = [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+        lib.clair_decode.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
     lib.clair_wait.argtypes = [c_vp, c_int]
     lib.clair_slot_input.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
     lib.clair_submit_counts.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
@@ -91,6 +93,8 @@ def load(path=None):
     lib.clair_comm_allgather.argtypes = [c_vp, c_vp, c_vp, c_i64]
     lib.clair_comm_allgather_device.argtypes = [c_vp, c_vp, c_vp, c_i64]
     for name in SYMBOLS:
+        if older_ok and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if name not in ("clair_last_error", "clair_engine_destroy", "clair_comm_last_error", "clair_comm_destroy"):
             fn.restype = c_int
@@ -179,24 +183,27 @@ class Engine(object):
         self._pending[slot] = (c, outs)
 
     def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
-        """clair_submit_ex: forward pass + decode on the device.  batch: [n,33,8,4] float32, or raw int16 counts with counts=True;
+        """clair_submit_ex: forward pass + decode on the device.  batch: [n,33,8,4] float32, or raw int16 counts with counts=True (the
+        candidates may be a strided view, e.g. the counts column of an array of binary tensor records: no copy is made here);
         centre: uint8 [n,2] (clair_amd._hostapi.centre_bytes).  wait(slot) then returns the call records (structured array,
         _hostapi.CALL_DTYPE), or (records, [gt21, genotype, len1, len2]) with with_probabilities=True."""
         from clair_amd._hostapi import CALL_DTYPE
-        if counts:
-            x = np.ascontiguousarray(batch, dtype=np.int16)
-            if x.ndim != 4 or x.shape[1:] != (33, 8, 4):
-                raise ValueError("counts must have shape [n,33,8,4], got %r" % (x.shape,))
-        else:
-            x = self._prep_x(batch)
+        dtype = np.int16 if counts else np.float32
+        x = np.asarray(batch)
+        if x.ndim != 4 or x.shape[1:] != (33, 8, 4):
+            raise ValueError("batch must have shape [n,33,8,4], got %r" % (x.shape,))
         n = x.shape[0]
+        inner_dense = x.dtype == dtype and n > 0 and x[0].flags.c_contiguous and x.strides[0] >= x[0].nbytes
+        if not inner_dense:
+            x = np.ascontiguousarray(x, dtype=dtype)
+        stride = 0 if x.flags.c_contiguous else int(x.strides[0])
         c = np.ascontiguousarray(centre, dtype=np.uint8)
         if c.shape != (n, 2):
             raise ValueError("centre must be uint8 [%d,2], got %r" % (n, c.shape))
         calls = np.zeros(n, dtype=CALL_DTYPE)
         outs = self._alloc_out(n) if with_probabilities else None
         ptrs = [_ptr(o) for o in outs] if outs else [None] * 4
-        self._check(self._lib.clair_submit_ex(self._h, int(slot), _ptr(x), int(bool(counts)), n, _ptr(c), _ptr(calls), *ptrs), "clair_submit_ex")
+        self._check(self._lib.clair_submit_ex(self._h, int(slot), _ptr(x), int(bool(counts)), stride, n, _ptr(c), _ptr(calls), *ptrs), "clair_submit_ex")
         self._pending[slot] = ((x, c), (calls, outs) if outs else calls)
 
     def decode(self, x, Y, centre, slot=0):

@@ -212,6 +212,8 @@ def _meta_of(infos):
 def centre_bytes(infos):
     """uint8 [n,2]: the centre character of every candidate's reference window and min(window length, 255) -- what the call
     resolution needs of the candidate's text (clair_host_resolve_calls, clair_submit_ex)."""
+    if hasattr(infos, "centre_bytes"):          # tensor_binary.InfoTable: straight from the record columns
+        return infos.centre_bytes()
     lib = load()
     n = len(infos)
     meta, tok = _meta_of(infos)

@@ -640,8 +640,6 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     import queue
     writer.write_header()
     batch_size = batch_size or param.predictBatchSize
-    if generator is None:
-        generator = ingest.tensor_generator_from(args.tensor_fn, batch_size)
     logging.info("Calling variants ...")
     t0 = time()
     use_async = hasattr(m, "submit") and hasattr(m, "wait")
@@ -652,6 +650,8 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     device_decode = (use_async and hasattr(m, "submit_calls") and getattr(decoder, "native_applies", lambda: False)()
                      and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0")
     keep_probabilities = device_decode and decoder.lookup.sam is not None      # candidates that consult the BAM are decoded again from them
+    if generator is None:      # with the decode on the device nobody on the host reads the float32 tensor (unless a BAM is consulted)
+        generator = ingest.tensor_generator_from(args.tensor_fn, batch_size, with_input=not device_decode or keep_probabilities)
     loaded = queue.Queue(maxsize=n_slots + 2)      # batches parsed ahead
     finished = queue.Queue(maxsize=n_slots + 2)    # (batch, prediction) waiting to be decoded and written
     failures = []                                  # exc_info of a stage that died on its helper thread

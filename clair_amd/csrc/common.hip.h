@@ -46,6 +46,26 @@ __device__ __forceinline__ float selu_scaled(float x, float k) {   // k * selu(x
 }
 __device__ __forceinline__ float selu_f(float x) { return selu_scaled(x, 1.0f); }
 
+// Two values at once on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: one issue slot per PAIR): ~10 slots per value
+// instead of ~14.  Same function, bit for bit: the positive and the negative branch are computed on max(x, 0) and min(x, 0) and added --
+// one of the two terms is exactly zero (the polynomial branch gives p(0) * 0 = 0 for x >= 0), so the sum is the other term unrounded.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 selu_scaled2(f32x2 x, float k) {
+    constexpr float alpha = 1.6732632423543772848170429916717f;
+    constexpr float scale = 1.0507009873554804934193349852946f;
+    const f32x2 xm = {fminf(x[0], 0.0f), fminf(x[1], 0.0f)}, xp = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    f32x2 p = xm * (1.0f / 720.0f) + (1.0f / 120.0f);
+    p = p * xm + (1.0f / 24.0f);
+    p = p * xm + (1.0f / 6.0f);
+    p = p * xm + 0.5f;
+    p = p * xm + 1.0f;
+    const f32x2 small = p * xm;
+    const f32x2 t = xm * 1.44269504088896340736f;
+    const f32x2 big = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} - 1.0f;
+    const f32x2 em1 = {xm[0] > -0.125f ? small[0] : big[0], xm[1] > -0.125f ? small[1] : big[1]};
+    return em1 * (alpha * scale * k) + xp * (scale * k);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

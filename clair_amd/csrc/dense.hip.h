@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void l3l4_kernel(L3L4Args p) {
             for (int r = 0; r < 4; ++r) {
                 const int u = 8 * a + 4 * hq + r;
                 if (a < 3 || u < L3_UNITS) {
-                    float y[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) y[cc] = selu_scaled(acc3[cc][4 * a + r] * p.l3_unscale, L34_ACT_SCALE);
+                    const f32x2 y01 = selu_scaled2((f32x2){acc3[0][4 * a + r], acc3[1][4 * a + r]} * p.l3_unscale, L34_ACT_SCALE);
+                    const f32x2 y23 = selu_scaled2((f32x2){acc3[2][4 * a + r], acc3[3][4 * a + r]} * p.l3_unscale, L34_ACT_SCALE);
+                    const float y[4] = {y01[0], y01[1], y23[0], y23[1]};
                     uint2 hi, lo;
                     split2_pk4(y, hi, lo);
                     *(uint2 *)&l3h[0][cand][u * L34_CH + cq * 4] = hi;
@@ -318,9 +318,13 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
         for (int f = tid; f < 12 * 64; f += 256) {
             const int g = f >> 6, ln = f & 63, nh = g / 6, rem = g - nh * 6, nb = rem >> 1, ai = rem & 1;
             const size_t at = ((((size_t)blk * 2 + nh) * 6 + mb * 3 + nb) * 4 + 2 * h + ai) * 256 + ln * 4;
-            f32x4 s = *(const f32x4 *)(p.l4part + at);
-#pragma unroll 8
-            for (int sp = 1; sp < L4_SPLITS; ++sp) s += *(const f32x4 *)(p.l4part + (size_t)sp * nblk * (2 * 6 * 4 * 256) + at);
+            // all 32 partials of the quad in flight at once (one memory round trip per quad instead of four), summed in split order
+            f32x4 part[L4_SPLITS];
+#pragma unroll
+            for (int sp = 0; sp < L4_SPLITS; ++sp) part[sp] = *(const f32x4 *)(p.l4part + (size_t)sp * nblk * (2 * 6 * 4 * 256) + at);
+            f32x4 s = part[0];
+#pragma unroll
+            for (int sp = 1; sp < L4_SPLITS; ++sp) s += part[sp];
             const int col = nh * 96 + nb * 32 + (ln & 31);
             const float b4 = p.b4[col];
 #pragma unroll

@@ -316,6 +316,12 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     return 0;
 }
 
+// n candidates of `row` bytes each, `stride` bytes apart in the caller's buffer (0: dense), into a dense staging buffer
+void gather_rows(void *dst, const void *src, int n, size_t row, int64_t stride) {
+    if (stride == 0 || (size_t)stride == row) { memcpy(dst, src, (size_t)n * row); return; }
+    for (int i = 0; i < n; ++i) memcpy((char *)dst + (size_t)i * row, (const char *)src + (size_t)i * (size_t)stride, row);
+}
+
 // The decode of the slot's batch on the device (decode.hip.h): probabilities in d_out + window in d_x + centre bytes -> call records.
 int enqueue_decode(clair_engine *e, Slot &s, int n) {
     KernelTimer kt(e, s, CLAIR_K_DECODE);
@@ -676,8 +682,8 @@ int clair_wait(clair_engine_t *e, int slot) {
 
 // The pipelined call with the decode on the device: input as float32 tensor (input_is_counts == 0) or raw int16 counts; calls != NULL
 // asks for the call records (centre: [n][2] bytes, required then); the four probability arrays are optional then (all or none).
-int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int n, const uint8_t *centre, clair_call_t *calls,
-                    float *gt21, float *genotype, float *l1, float *l2) {
+int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int64_t input_stride_bytes, int n, const uint8_t *centre,
+                    clair_call_t *calls, float *gt21, float *genotype, float *l1, float *l2) {
     if (check_slot(e, slot)) return 1;
     if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
     const bool want_probs = gt21 || genotype || l1 || l2;
@@ -685,6 +691,8 @@ int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is
     if (want_probs && !(gt21 && genotype && l1 && l2)) return fail(e, "the four probability arrays come together or not at all");
     if (!want_probs && !calls) return fail(e, "nothing asked for: neither call records nor probabilities");
     if (calls && !centre) return fail(e, "call records need the candidates' centre bytes");
+    if (input_stride_bytes != 0 && input_stride_bytes < (int64_t)(CLAIR_INPUT_FLOATS * (input_is_counts ? sizeof(short) : sizeof(float))))
+        return fail(e, "input stride of %lld bytes is shorter than one candidate", (long long)input_stride_bytes);
     HIP_TRY(e, hipSetDevice(e->device));
     Slot &s = e->slots[slot];
     if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
@@ -692,14 +700,14 @@ int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is
     if (input_is_counts) {
         if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
         if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
-        memcpy(s.h_counts, input, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short));   // page-locked staging, as in clair_submit
+        gather_rows(s.h_counts, input, n, CLAIR_INPUT_FLOATS * sizeof(short), input_stride_bytes);   // page-locked staging, as in clair_submit
         HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
         const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
         hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
     } else {
         if (input != s.h_x) {
             if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
-            memcpy(s.h_x, input, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float));
+            gather_rows(s.h_x, input, n, CLAIR_INPUT_FLOATS * sizeof(float), input_stride_bytes);
         }
         HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
     }

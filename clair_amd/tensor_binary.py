@@ -47,6 +47,7 @@ class InfoTable(object):
     def __init__(self, ctg, ctg_len, pos, seq, seq_len):
         self.ctg, self.ctg_len, self.pos, self.seq, self.seq_len = ctg, ctg_len, pos, seq, seq_len
         self._rows = None
+        self._meta = None
 
     def __len__(self):
         return len(self.pos)
@@ -69,6 +70,8 @@ class InfoTable(object):
     def native_meta(self):
         """-> (meta bytes, tok int32 [n,6]) in the form clair_host_decode_rows takes: per candidate (offset, length) of contig,
         decimal position and reference sequence inside `meta`, here fixed-width rows of 37 + 20 + 33 bytes."""
+        if self._meta is not None:
+            return self._meta
         n = len(self)
         width = MAX_CTG + 20 + 33
         meta = np.zeros((n, width), dtype=np.uint8)
@@ -95,17 +98,29 @@ class InfoTable(object):
         tok[:, 3] = plen
         tok[:, 4] = base + MAX_CTG + 20
         tok[:, 5] = self.seq_len
-        return meta.tobytes(), tok
+        self._meta = (meta.tobytes(), tok)
+        return self._meta
+
+    def centre_bytes(self):
+        """uint8 [n,2]: the centre character of each reference window and its length -- what the device decode takes of the text
+        (include/clair_amd.h: clair_submit_ex).  Every kept record has more than 16 characters (read_batches filters on it)."""
+        n = len(self)
+        out = np.empty((n, 2), dtype=np.uint8)
+        out[:, 0] = np.frombuffer(np.ascontiguousarray(self.seq).tobytes(), dtype=np.uint8).reshape(n, 33)[:, 16] if n else 0
+        out[:, 1] = self.seq_len
+        return out
 
 
 _IUPAC_TABLE = np.zeros(256, dtype=bool)
 _IUPAC_TABLE[list(IUPAC)] = True
 
 
-def read_batches(stream, batch_size, first=b""):
+def read_batches(stream, batch_size, first=b"", with_input=True):
     """Yield (X float32 [n,33,8,4], infos, counts int16 [n,33,8,4]) from a binary record stream positioned after MAGIC.
     Batching follows clair/utils.py:72-109: batch_size records are TAKEN per batch, those whose centre base is not an IUPAC
-    code are dropped from it, empty batches are skipped, progress goes to stderr.  infos is an InfoTable (list-like)."""
+    code are dropped from it, empty batches are skipped, progress goes to stderr.  infos is an InfoTable (list-like).
+    with_input=False: X is None and counts is the records' own column (a strided view, no copy) -- for a consumer that sends the
+    raw counts to the GPU and decodes there (clair_amd.call_var with the device decode): the batch costs no pass over its 8.6 MB."""
     processed = 0
     want = batch_size * RECORD.itemsize
     carry = first
@@ -143,7 +158,10 @@ def read_batches(stream, batch_size, first=b""):
         print("Processed %d tensors" % processed, file=sys.stderr)
         if n == 0:
             continue
-        counts = np.ascontiguousarray(rec["counts"])
-        from clair_amd import _hostapi
-        x = _hostapi.counts_to_input(counts)
+        if with_input:
+            counts = np.ascontiguousarray(rec["counts"])
+            from clair_amd import _hostapi
+            x = _hostapi.counts_to_input(counts)
+        else:
+            counts, x = rec["counts"], None
         yield x, InfoTable(rec["ctg"].copy(), rec["ctg_len"].copy(), rec["pos"].copy(), rec["seq"].copy(), rec["seq_len"].copy()), counts

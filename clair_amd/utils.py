@@ -118,8 +118,9 @@ def _open_source(tensor_file_path, binary=False):
     return proc, proc.stdout
 
 
-def tensor_generator_from(tensor_file_path, batch_size):
-    """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size.
+def tensor_generator_from(tensor_file_path, batch_size, with_input=True):
+    """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size.  (with_input=False: binary records may
+    leave X as None and hand their raw counts on as a third element instead, tensor_binary.read_batches.)
 
     The text is parsed by the native helper (include/clair_host.h: clair_host_parse_tensors, ~20x the NumPy path below);
     `tensor_generator_from_py` is the line-by-line restatement of the reference it is tested against."""
@@ -129,7 +130,7 @@ def tensor_generator_from(tensor_file_path, batch_size):
     proc, stream = _open_source(tensor_file_path, binary=True)
     head = stream.read(len(tensor_binary.MAGIC))
     if head == tensor_binary.MAGIC:              # fixed-size binary records (clair_amd/tensor_binary.py) instead of text
-        for batch in tensor_binary.read_batches(stream, batch_size):
+        for batch in tensor_binary.read_batches(stream, batch_size, with_input=with_input):
             yield batch
         if proc is not None:
             stream.close()

@@ -132,12 +132,14 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
  * comes back per candidate is the 32-byte call record of include/clair_call.h instead of (or besides) the 360 bytes of probabilities.
  * clair_host_format_calls (include/clair_host.h) turns records into VCF rows; clair_host_resolve_calls is the CPU twin of the kernel
  * (bit-identical records).  input: [n][33][8][4] float32 as for clair_submit (input_is_counts == 0) or raw int16 counts as for
- * clair_submit_counts (!= 0).  centre: [n][2] bytes per candidate -- the centre character of its reference window (refseq[16],
+ * clair_submit_counts (!= 0); input_stride_bytes = distance between consecutive candidates in the caller's buffer (0 = dense), so that the
+ * counts can be taken straight out of an array of binary tensor records (clair_amd/tensor_binary.py: 2 192-byte records) without a
+ * host-side copy to make them contiguous.  centre: [n][2] bytes per candidate -- the centre character of its reference window (refseq[16],
  * clair/call_var.py:1015) and min(length of refseq, 255); required when calls != NULL.  calls: caller's array of n records, or NULL.
  * gt21 / genotype / indel_len1 / indel_len2: all four or all NULL (NULL: the probabilities stay on the device).  Pair with
  * clair_wait(slot); buffers must stay valid until it returns. */
-int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int n, const uint8_t *centre,
-                    clair_call_t *calls, float *gt21, float *genotype, float *indel_len1, float *indel_len2);
+int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int64_t input_stride_bytes, int n,
+                    const uint8_t *centre, clair_call_t *calls, float *gt21, float *genotype, float *indel_len1, float *indel_len2);
 
 /* The decode alone, on probabilities the caller already holds (call_var --input_probabilities, clair/call_var.py:1276-1309, and the
  * tests that feed the kernel crafted probabilities: exact ties, exact zeros, products that underflow).  Synchronous; does not need
