@@ -105,5 +105,22 @@ def mfma():
     print("# wait_inst = issue stalls (matrix pipe busy, dependencies).")
 
 
+def counters():
+    """Per-kernel averages of whatever counters a pass collected: pmc_summary.py counters <db> [--skip-first N]"""
+    db = sqlite3.connect(sys.argv[2])
+    names = [r[0] for r in db.execute("select distinct counter_name from counters_collection order by 1")]
+    skip = arg("--skip-first", 2)
+    cols = {n: per_kernel(sys.argv[2], n, skip) for n in names}
+    kernels = sorted({k for c in cols.values() for k in c})
+    print("%-56s %s" % ("kernel", " ".join("%18s" % n[-18:] for n in names)))
+    for k in kernels:
+        if short(k) is None:
+            continue
+        print("%-56s %s" % (k[:56], " ".join("%18.0f" % cols[n].get(k, float("nan")) for n in names)))
+        if "TCC_HIT_sum" in cols and "TCC_MISS_sum" in cols:
+            h, m = cols["TCC_HIT_sum"].get(k, 0.0), cols["TCC_MISS_sum"].get(k, 0.0)
+            print("%-56s L2 hit rate %.1f %% of %.0f requests" % ("", 100.0 * h / max(h + m, 1.0), h + m))
+
+
 if __name__ == "__main__":
-    {"traffic": traffic, "mfma": mfma}[sys.argv[1]]()
+    {"traffic": traffic, "mfma": mfma, "counters": counters}[sys.argv[1]]()

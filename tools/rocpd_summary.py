@@ -8,9 +8,9 @@ rocprofv3 7.2 records arch_vgpr_count as the allocation granule (e.g. 244 for a 
 when the kernel descriptor reserves 256 AGPRs.  --resource-usage takes the compiler's own -Rpass-analysis=kernel-resource-usage
 output (profiles/rNN_kernel_resource_usage.txt) and prints ITS VGPR / AGPR / SGPR / scratch numbers beside the tracer's.  --skip-first drops the first N dispatches of each
 kernel (warm-up launches) so the means line up with bench.py's timed region.  --phases W,K,I splits each kernel's dispatches the way bench.py issues
-them -- W warm-up launches, K timed steps (batches in flight on the slots), K steps with HIP events around the dominant kernel only
-(`roofline.kernel_ms` is the dominant kernel's mean there), K steps with events around every kernel, I launches alone on one stream
-(`roofline.alone_kernel_ms`) -- and prints the mean of each phase.
+them -- W warm-up launches, K timed steps (batches in flight on the slots), K steps with events around every kernel, I launches alone on
+one stream (`roofline.alone_kernel_ms`), K steps with HIP events around the dominant kernel only (`roofline.kernel_ms` is the dominant
+kernel's mean there), one launch of the parity check -- and prints the mean of each phase.
 """
 import sqlite3
 import sys
@@ -65,14 +65,14 @@ def main():
                   % (mangled[:62], r.get("VGPRs", 0), r.get("AGPRs", 0), r.get("TotalSGPRs", 0), r.get("ScratchSize", 0), r.get("LDS", 0), r.get("Occupancy", 0)))
     if "--phases" in sys.argv:
         w, k, i = (int(v) for v in sys.argv[sys.argv.index("--phases") + 1].split(","))
-        print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches in flight | %d steps, events on the dominant kernel | "
-              "%d steps, events on every kernel | %d launches alone on one stream" % (w, k, k, k, i))
-        print("%-58s %10s %10s %10s %10s %10s" % ("kernel", "warm-up", "timed", "ev.dominant", "ev.all", "alone"))
+        print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches in flight | %d steps, events on every kernel | "
+              "%d launches alone on one stream | %d steps, events on the dominant kernel only (+ the parity check's launch)" % (w, k, k, i, k))
+        print("%-58s %10s %10s %10s %10s %10s" % ("kernel", "warm-up", "timed", "ev.all", "alone", "ev.dominant"))
         for name, rs in per.items():
             d = [(r[2] - r[1]) / 1e3 for r in rs]
-            if len(d) != w + 3 * k + i:
+            if len(d) not in (w + 3 * k + i, w + 3 * k + i + 1):
                 continue
-            cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:w + 3 * k], d[w + 3 * k:]]
+            cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:w + 2 * k + i], d[w + 2 * k + i:w + 3 * k + i]]
             short = name if len(name) <= 58 else name[:55] + "..."
             print("%-58s %10.2f %10.2f %10.2f %10.2f %10.2f" % ((short,) + tuple(sum(c) / max(len(c), 1) for c in cut)))
 
