@@ -630,3 +630,23 @@ def test_hip_matches_the_tf113_golden_vectors_when_present():
         for g, key in zip(got, ("gt21", "genotype", "len1", "len2")):
             assert np.abs(g - z[key]).max() <= PROB_TOL, key
         assert np.abs(a1[:, :4] - z["a1_first4"]).max() <= 1e-5 and np.abs(a2[:, :4] - z["a2_first4"]).max() <= 1e-5
+
+
+def test_predict_larger_than_the_engine_batch_is_pipelined_over_the_slots(synth_weights):
+    """`Clair.predict` with more candidates than one engine batch (clair_amd/model.py: _predict_pieces): max_batch-sized pieces over
+    the slots, outputs concatenated in input order -- the same bits as predicting the pieces one by one."""
+    from clair_amd.model import Clair
+    x, _ = synth.synthetic_input(2500, "ont", seed=123)
+    m = Clair(device=0, max_batch=1024, n_slots=2)
+    try:
+        m.set_parameters(synth_weights)
+        whole = m.predict(x)                                    # 1024 + 1024 + 452
+        assert [a.shape for a in whole] == [(2500, 21), (2500, 3), (2500, 33), (2500, 33)] and m.prediction is whole
+        parts = [m.predict(x[i:i + 1024]) for i in range(0, 2500, 1024)]
+        for k in range(4):
+            assert np.array_equal(whole[k], np.concatenate([p[k] for p in parts]))
+        want = _oracle(synth_weights, x[2040:2060])
+        for g, w_ in zip(whole, want):
+            assert np.abs(g[2040:2060] - w_).max() <= PROB_TOL
+    finally:
+        m.close()
