@@ -78,3 +78,33 @@ def test_submit_ex_returns_the_records_of_its_own_probabilities(engine, synth_we
     only = engine.wait(1)
     _same_records(only, calls)
     assert _hostapi.format_calls(only, infos, True, False, False, None, False) == _hostapi.decode_rows(x, infos, Y, True, False, False, None, False)
+
+
+def test_call_records_survive_a_fused_launch_failure(synth_weights, monkeypatch):
+    """clair_submit_ex on a handle whose fused layer-2 launch reports a placement failure (CLAIR_AMD_FUSED_FAULT): the engine re-runs the
+    forward pass on the two-launch path AND the decode behind it; the records are the ones an undisturbed handle returns."""
+    from clair_amd import _capi
+    raw, infos = synth.synthetic_candidates(1024, "ont", seed=41)
+    counts, centre = raw.astype(np.int16), _hostapi.centre_bytes(infos)
+    want = None
+    for fault in (None, "2"):
+        if fault is None:
+            monkeypatch.delenv("CLAIR_AMD_FUSED_FAULT", raising=False)
+        else:
+            monkeypatch.setenv("CLAIR_AMD_FUSED_FAULT", fault)
+        eng = _capi.Engine(device=0, max_batch=1024, n_slots=2)
+        try:
+            eng.load_weights(synth_weights)
+            got = []
+            for rep in range(3):
+                eng.submit_calls(rep % 2, counts, centre, counts=True)
+                got.append(eng.wait(rep % 2))
+            if fault is None:
+                want = got[0]
+                assert eng.counter("fused_recoveries") == 0
+            else:
+                assert eng.counter("fused_recoveries") == 1
+            for g in got:
+                _same_records(g, want)
+        finally:
+            eng.close()
