@@ -245,3 +245,62 @@ def test_rccl_start_up_is_refused_on_every_rank_when_one_rank_cannot_start(tmp_p
     out = procs[0].stdout.read().decode()
     assert [p.wait(timeout=60) for p in procs] == [3, 3]
     assert "refused on 2 of 2 ranks" in out and "rank 1: no HIP device" in out
+
+
+BENCH_WORKER = textwrap.dedent("""
+    import sys, numpy as np
+    sys.path.insert(0, %(root)r)
+    import bench
+    from clair_amd import _capi
+    from oracle import c_oracle
+
+    class FakeEngine(object):
+        '''Stands in for the HIP engine on a GPU-less host: the oracle's outputs, made-up kernel times.'''
+        def __init__(self, device=0, max_batch=1024, n_slots=1, lib_path=None):
+            self.max_batch, self.x, self.w, self.runs = max_batch, None, None, 0
+        def load_weights(self, w): self.w = w
+        def dataset_alloc(self, n): return 1, 2
+        def dataset_upload(self, xd, first, x): self.x = np.array(x)
+        def run_resident(self, slot, xd, od, first, n): self.runs += 1
+        def sync(self): pass
+        def timing_enable(self, on=True, only=None): pass
+        def timing_reset(self): pass
+        def kernel_times(self):
+            t = {k: (0.0, 0) for k in _capi.KERNEL_NAMES}
+            t.update(lstm1=(8.0, 100), proj2=(7.0, 100), lstm2=(8.0, 100), l4=(2.5, 100), tail=(2.0, 100))
+            return t
+        def kernel_workgroups(self, n): return dict(proj1=0, lstm1=64, proj2=128, lstm2=64, l3=0, l4=512, tail=64, decode=256)
+        def dataset_download(self, od, first, n): return np.concatenate(c_oracle.forward(self.w, self.x[first:first + n]), axis=1)
+        def dataset_free(self, xd, od): pass
+        def close(self): pass
+
+    _capi.Engine = FakeEngine
+    sys.argv = ["bench.py"] + %(args)r
+    sys.exit(bench.main())
+""")
+
+
+@pytest.mark.parametrize("args,total", [(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline"], 2 * 6 * 64),
+                                        (["--gpus", "2", "--scaling", "strong", "--candidates", "1000", "--batch", "64", "--warmup", "1", "--no-cpu-baseline"], 1000)])
+def test_bench_two_rank_flow_with_a_stand_in_engine(tmp_path, args, total):
+    """bench.py's multi-rank bookkeeping on two CPU ranks (the engine replaced by the oracle, the sockets as transport): one JSON line from
+    rank 0, per-rank table, real candidate counts under strong scaling -- and, since no rank holds an RCCL communicator, n_gpus 0 and a
+    non-zero exit code: a multi-GPU number is only ever reported over RCCL."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(BENCH_WORKER % {"root": ROOT, "args": args})
+    env = dict(os.environ, BENCH_WARM_STEPS="0", OMP_NUM_THREADS="2")
+    procs = shard.spawn_ranks([sys.executable, str(script)], 2, env=env, stderr_pipe=True)
+    out = procs[0].stdout.read().decode()
+    errs = [p.stderr.read().decode() for p in procs]
+    rcs = [p.wait(timeout=300) for p in procs]
+    assert rcs[1] == 0 and rcs[0] == 1, errs
+    assert "0 of 2 ranks hold an RCCL communicator" in errs[0]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 0 and d["config"]["transport"] == "tcp" and d["config"]["ranks_with_rccl_communicator"] == 0
+    assert len(d["per_rank"]) == 2 and sum(r["candidates"] for r in d["per_rank"]) == total == d["config"]["candidates_total"]
+    assert d["scaling"] == ("strong" if "strong" in args else "weak") and d["parity_max_abs_err"] == 0.0
+    assert d["value"] > 0 and d["steps"] == max(r["steps"] for r in d["per_rank"])          # the slowest rank's step count; times are fake here
+    assert "cpu_baseline" not in d and d["roofline"]["kernel"].split()[0] == "proj2"
