@@ -16,7 +16,7 @@ SYMBOLS = (
     "clair_abi_version", "clair_device_count", "clair_last_error",
     "clair_engine_create", "clair_engine_destroy",
     "clair_set_tensor", "clair_finalize_weights",
-    "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts", "clair_submit_ex", "clair_decode",
+    "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts", "clair_submit_ex", "clair_decode", "clair_pinned_alloc", "clair_pinned_free",
     "clair_dataset_alloc", "clair_dataset_free", "clair_dataset_upload", "clair_dataset_download",
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
@@ -65,6 +65,8 @@ def load(path=None):
     if not older_ok or hasattr(lib, "clair_submit_ex"):     # an OLDER build named by `path` (A/B timing, tools/gpu/ab_libs.sh) may predate these
         lib.clair_submit_ex.argtypes = [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
         lib.clair_decode.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]
+        lib.clair_pinned_alloc.argtypes = [c_vp, c_i64, ctypes.POINTER(c_vp)]
+        lib.clair_pinned_free.argtypes = [c_vp, c_vp]
     lib.clair_wait.argtypes = [c_vp, c_int]
     lib.clair_slot_input.argtypes = [c_vp, c_int, ctypes.POINTER(c_vp)]
     lib.clair_submit_counts.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
@@ -205,6 +207,13 @@ class Engine(object):
         ptrs = [_ptr(o) for o in outs] if outs else [None] * 4
         self._check(self._lib.clair_submit_ex(self._h, int(slot), _ptr(x), int(bool(counts)), stride, n, _ptr(c), _ptr(calls), *ptrs), "clair_submit_ex")
         self._pending[slot] = ((x, c), (calls, outs) if outs else calls)
+
+    def pinned_buffer(self, nbytes):
+        """A page-locked uint8 array of nbytes (clair_pinned_alloc): data placed in it -- e.g. read from a file with readinto -- goes to
+        the GPU from where it lies when a view INTO it is handed to submit_calls.  It lives as long as the engine."""
+        p = ctypes.c_void_p()
+        self._check(self._lib.clair_pinned_alloc(self._h, int(nbytes), ctypes.byref(p)), "clair_pinned_alloc")
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
 
     def decode(self, x, Y, centre, slot=0):
         """clair_decode: the device decode on given probabilities Y = [gt21, genotype, len1, len2] -> call records."""

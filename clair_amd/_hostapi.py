@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclair_host.so")
 SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_threads", "clair_host_crc32c", "clair_host_parse_tensors",
            "clair_host_counts_to_input_i16", "clair_host_counts_to_input_i32",
-           "clair_host_decode_rows", "clair_host_decode_rows_ex", "clair_host_resolve_calls", "clair_host_format_calls", "clair_host_centre_bytes",
+           "clair_host_decode_rows", "clair_host_decode_rows_ex", "clair_host_resolve_calls", "clair_host_format_calls", "clair_host_format_calls_records", "clair_host_centre_bytes",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
            "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
@@ -36,6 +36,8 @@ def load():
         lib.clair_host_resolve_calls.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
         lib.clair_host_format_calls.argtypes = [vp, ctypes.c_char_p, vp, i32, i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32), vp]
         lib.clair_host_centre_bytes.argtypes = [ctypes.c_char_p, vp, i32, vp]
+        lib.clair_host_format_calls_records.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i64, ctypes.POINTER(i64),
+                                                        ctypes.POINTER(i32), vp]
         lib.clair_host_pileup_create.argtypes = [ctypes.c_char_p, i64, i64, vp, i64, i32, i32, i32, i32, i64, i32, ctypes.POINTER(vp)]
         lib.clair_host_pileup_destroy.argtypes = [vp]
         lib.clair_host_pileup_destroy.restype = None
@@ -239,26 +241,41 @@ def resolve_calls(X, Y, centre):
     return calls
 
 
-def format_calls(calls, infos, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2, with_status=False):
-    """clair_host_format_calls: call records (from the GPU decode kernel or resolve_calls) + the batch's text -> VCF rows."""
+def format_calls(calls, infos, show_reference, haploid_precision, haploid_sensitive, qual_threshold, arith_numpy2, with_status=False, as_text=False):
+    """clair_host_format_calls: call records (from the GPU decode kernel or resolve_calls) + the batch's text -> VCF rows (a list of
+    strings; as_text=True: the rows as one bytes object, each '\\n'-terminated, ready for the file).  A batch of binary tensor records
+    (tensor_binary.InfoTable) hands its columns over as they are (clair_host_format_calls_records)."""
     lib = load()
     n = len(infos)
     if n == 0:
-        return ([], np.zeros(0, np.uint8)) if with_status else []
+        empty = b"" if as_text else []
+        return (empty, np.zeros(0, np.uint8)) if with_status else empty
     calls = np.ascontiguousarray(calls, dtype=CALL_DTYPE)
     if len(calls) != n:
         raise ValueError("%d call records for %d candidates" % (len(calls), n))
-    meta, tok = _meta_of(infos)
-    cap = 4096 + 256 * n + 2 * len(meta)
-    out = ctypes.create_string_buffer(cap)
+    flags = (int(bool(show_reference)), int(bool(haploid_precision)), int(bool(haploid_sensitive)),
+             -1 if qual_threshold is None else int(qual_threshold), int(bool(arith_numpy2)))
     out_len, n_rows = ctypes.c_int64(0), ctypes.c_int(0)
     status = np.zeros(n, dtype=np.uint8)
-    rc = lib.clair_host_format_calls(calls.ctypes.data, meta, tok.ctypes.data, n, int(bool(show_reference)), int(bool(haploid_precision)),
-                                     int(bool(haploid_sensitive)), -1 if qual_threshold is None else int(qual_threshold),
-                                     int(bool(arith_numpy2)), out, cap, ctypes.byref(out_len), ctypes.byref(n_rows), status.ctypes.data)
+    if hasattr(infos, "record_columns"):
+        ctg, ctg_len, pos, seq, seq_len = infos.record_columns()
+        cap = 4096 + 320 * n
+        out = ctypes.create_string_buffer(cap)
+        rc = lib.clair_host_format_calls_records(calls.ctypes.data, ctg.ctypes.data, ctg_len.ctypes.data, pos.ctypes.data, seq.ctypes.data,
+                                                 seq_len.ctypes.data, n, *flags, out, cap, ctypes.byref(out_len), ctypes.byref(n_rows),
+                                                 status.ctypes.data)
+    else:
+        meta, tok = _meta_of(infos)
+        cap = 4096 + 256 * n + 2 * len(meta)
+        out = ctypes.create_string_buffer(cap)
+        rc = lib.clair_host_format_calls(calls.ctypes.data, meta, tok.ctypes.data, n, *flags, out, cap, ctypes.byref(out_len), ctypes.byref(n_rows),
+                                         status.ctypes.data)
     if rc != 0:
         raise ValueError("native decode: " + lib.clair_host_last_error().decode())
-    rows = out.raw[:out_len.value - 1].decode("ascii").split("\n") if out_len.value else []
+    if as_text:
+        rows = out.raw[:out_len.value]
+    else:
+        rows = out.raw[:out_len.value - 1].decode("ascii").split("\n") if out_len.value else []
     return (rows, status) if with_status else rows
 
 

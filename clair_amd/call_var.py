@@ -459,17 +459,21 @@ class VariantDecoder(object):
                 and isinstance(cfg.quality_score_for_pass, (int, type(None))))
 
     def decode_calls(self, X, infos, calls, Y=None):
-        """Rows of one batch from the call records the GPU decode kernel left (include/clair_call.h): only text is made here.  With a BAM
+        """Rows of one batch (a list, or the finished text as bytes when no BAM is open) from the call records the GPU decode kernel left
+        (include/clair_call.h): only text is made here.  With a BAM
         open, the candidates whose record says the reference would have consulted it are decoded again on the Python look-up path --
         which needs their probabilities (Y)."""
         from clair_amd import _hostapi
         cfg = self.cfg
         if len(calls) != len(infos):
             sys.exit("Inconsistent shape between input tensor and output predictions %d/%d" % (len(infos), len(calls)))
+        if self.lookup.sam is None:      # nothing to splice in: the rows go to the file as the bytes the formatter wrote
+            return _hostapi.format_calls(calls, infos, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
+                                         cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass, self.arith == "numpy2", as_text=True)
         rows, status = _hostapi.format_calls(calls, infos, cfg.is_show_reference, cfg.is_haploid_precision_mode_enabled,
                                              cfg.is_haploid_sensitive_mode_enabled, cfg.quality_score_for_pass, self.arith == "numpy2",
                                              with_status=True)
-        if self.lookup.sam is None or not (status & 2).any():
+        if not (status & 2).any():
             return rows
         if Y is None:
             raise ValueError("decode_calls: candidates that consult the BAM need their probabilities")
@@ -605,7 +609,10 @@ class VcfWriter(object):
         print(text, file=self.fp)
 
     def write_rows(self, rows):
-        if rows:
+        if isinstance(rows, bytes):      # finished text of a batch (VariantDecoder.decode_calls): rows already '\n'-terminated
+            if rows:
+                self.fp.write(rows.decode("ascii"))
+        elif rows:
             self.fp.write("\n".join(rows))
             self.fp.write("\n")
 
@@ -650,8 +657,15 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
     device_decode = (use_async and hasattr(m, "submit_calls") and getattr(decoder, "native_applies", lambda: False)()
                      and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0")
     keep_probabilities = device_decode and decoder.lookup.sam is not None      # candidates that consult the BAM are decoded again from them
+    pool = None
     if generator is None:      # with the decode on the device nobody on the host reads the float32 tensor (unless a BAM is consulted)
-        generator = ingest.tensor_generator_from(args.tensor_fn, batch_size, with_input=not device_decode or keep_probabilities)
+        lean = device_decode and not keep_probabilities
+        if lean and hasattr(m, "pinned_buffer"):
+            # binary records are read straight into page-locked buffers of the engine and go to the GPU from there (a strided 2-D copy
+            # of the counts column): no pass over the batch on the host.  A buffer returns to the pool when its batch leaves the GPU.
+            from clair_amd import tensor_binary
+            pool = tensor_binary.BufferPool([m.pinned_buffer(batch_size * tensor_binary.RECORD.itemsize) for _ in range(2 * n_slots + 4)])
+        generator = ingest.tensor_generator_from(args.tensor_fn, batch_size, with_input=not lean, record_buffers=pool)
     loaded = queue.Queue(maxsize=n_slots + 2)      # batches parsed ahead
     finished = queue.Queue(maxsize=n_slots + 2)    # (batch, prediction) waiting to be decoded and written
     failures = []                                  # exc_info of a stage that died on its helper thread
@@ -715,7 +729,9 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
         slot, batch = inflight.pop(0)
         prediction = m.wait(slot)
         m.prediction = (prediction[1] if keep_probabilities else None) if device_decode else prediction
-        put(finished, (batch, prediction))
+        if pool is not None and len(batch) > 3:
+            pool.put(batch[3])                         # the GPU has the batch: its record buffer may be refilled
+        put(finished, (batch[:2], prediction))
 
     try:
         k = 0
@@ -748,6 +764,8 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
         stop.set()
         raise
     finally:
+        if pool is not None:
+            pool.close()
         put(finished, END)
         emitter.join()
         stop.set()

@@ -50,6 +50,8 @@ struct Slot {
     float *h_out = nullptr;   // pinned [max_batch][90]
     float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
     short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first clair_submit_counts
+    char *d_records = nullptr;   // candidates copied with the caller's stride (binary tensor records as they lie), clair_submit_ex
+    size_t d_records_bytes = 0;
     short *h_counts = nullptr;   // pinned [max_batch][1056]: staging of a caller's pageable count buffer (as h_x is for float input)
     // device decode (clair_submit_ex): the candidates' centre bytes in, call records out
     unsigned char *d_centre = nullptr, *h_centre = nullptr;   // [max_pad][2], pinned twin
@@ -91,6 +93,7 @@ struct clair_engine {
     bool l34_stamps = false;   // CLAIR_AMD_L34_STAMPS=1: l3l4_kernel writes its per-wave phase clocks into the (dead) zx workspace for clair_debug_read(5)
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
+    std::vector<std::pair<char *, size_t>> pinned;   // page-locked host buffers handed to the caller (clair_pinned_alloc)
     std::vector<Slot> slots;
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
@@ -202,6 +205,7 @@ void free_slot(Slot &s) {
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_x) (void)hipHostFree(s.h_x);
     if (s.d_counts) (void)hipFree(s.d_counts);
+    if (s.d_records) (void)hipFree(s.d_records);
     if (s.h_counts) (void)hipHostFree(s.h_counts);
     if (s.d_centre) (void)hipFree(s.d_centre);
     if (s.h_centre) (void)hipHostFree(s.h_centre);
@@ -314,6 +318,13 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
     }
     HIP_TRY(e, hipGetLastError());
     return 0;
+}
+
+// does [p, p + len) lie inside a buffer of clair_pinned_alloc?  (then the DMA engine can read it directly)
+bool in_pinned(const clair_engine *e, const void *p, size_t len) {
+    for (const auto &b : e->pinned)
+        if ((const char *)p >= b.first && (const char *)p + len <= b.first + b.second) return true;
+    return false;
 }
 
 // n candidates of `row` bytes each, `stride` bytes apart in the caller's buffer (0: dense), into a dense staging buffer
@@ -446,6 +457,7 @@ void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     for (auto &s : e->slots) free_slot(s);
+    for (auto &b : e->pinned) (void)hipHostFree(b.first);
     float *w[] = {e->bx1, e->bx2, e->b4, e->w5f, e->b5, e->whf, e->bhf};
     for (float *p : w) (void)hipFree(p);
     (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s); (void)hipFree(e->w3s);
@@ -610,6 +622,16 @@ __global__ __launch_bounds__(256) void counts_to_input_kernel(const short4 *coun
     x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
 }
 
+// the same for candidates `stride` bytes apart (binary tensor records copied as they lie): quad i = candidate i / 264, quad i % 264 of it
+__global__ __launch_bounds__(256) void counts_to_input_strided_kernel(const char *base, size_t stride, f32x4 *x, int n_quads) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_quads) return;
+    const int cand = i / (CLAIR_INPUT_FLOATS / 4), q = i - cand * (CLAIR_INPUT_FLOATS / 4);
+    const short4 c = *(const short4 *)(base + (size_t)cand * stride + (size_t)q * 8);
+    const float c0 = (float)c.x;
+    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
+}
+
 int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int n, float *gt21, float *genotype, float *l1, float *l2) {
     if (check_slot(e, slot)) return 1;
     if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
@@ -697,19 +719,42 @@ int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is
     Slot &s = e->slots[slot];
     if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
     const int n_pad = (n + 31) & ~31;
+    // A caller's buffer from clair_pinned_alloc is read by the DMA engine where it lies: no pass over the batch on this thread at all.
+    // Anything else goes through the slot's page-locked staging buffer.
+    const size_t row_bytes = CLAIR_INPUT_FLOATS * (input_is_counts ? sizeof(short) : sizeof(float));
+    const size_t stride = input_stride_bytes ? (size_t)input_stride_bytes : row_bytes;
+    const bool direct = in_pinned(e, input, (size_t)(n - 1) * stride + row_bytes);
     if (input_is_counts) {
         if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
-        if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
-        gather_rows(s.h_counts, input, n, CLAIR_INPUT_FLOATS * sizeof(short), input_stride_bytes);   // page-locked staging, as in clair_submit
-        HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
         const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
-        hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
+        if (direct && stride != row_bytes) {   // records as they lie: ONE contiguous copy of the span, the conversion kernel skips what lies between the counts
+            const size_t span = (size_t)(n - 1) * stride + row_bytes;
+            if (s.d_records_bytes < span) {
+                (void)hipFree(s.d_records); s.d_records = nullptr; s.d_records_bytes = 0;
+                const size_t want = std::max(span, (size_t)e->max_batch * stride);
+                HIP_TRY(e, hipMalloc((void **)&s.d_records, want));
+                s.d_records_bytes = want;
+            }
+            HIP_TRY(e, hipMemcpyAsync(s.d_records, input, span, hipMemcpyHostToDevice, s.stream));
+            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const char *)s.d_records, stride, (f32x4 *)s.d_x, n_quads);
+        } else {
+            if (direct) {
+                HIP_TRY(e, hipMemcpyAsync(s.d_counts, input, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
+            } else {
+                if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
+                gather_rows(s.h_counts, input, n, row_bytes, input_stride_bytes);   // page-locked staging, as in clair_submit
+                HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
+            }
+            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
+        }
+    } else if (direct) {
+        HIP_TRY(e, hipMemcpy2DAsync(s.d_x, row_bytes, input, stride, row_bytes, (size_t)n, hipMemcpyHostToDevice, s.stream));
     } else {
         if (input != s.h_x) {
             if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
-            gather_rows(s.h_x, input, n, CLAIR_INPUT_FLOATS * sizeof(float), input_stride_bytes);
+            gather_rows(s.h_x, input, n, row_bytes, input_stride_bytes);
         }
-        HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
     }
     if (n_pad > n)
         HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
@@ -872,6 +917,30 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
     workgroups[CLAIR_K_DECODE] = (n + 3) / 4;       // launched only by clair_submit_ex with call records asked for
     return 0;
+}
+
+int clair_pinned_alloc(clair_engine_t *e, int64_t bytes, void **ptr) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    if (!ptr || bytes < 1) return fail(e, "bad arguments to clair_pinned_alloc");
+    HIP_TRY(e, hipSetDevice(e->device));
+    void *p = nullptr;
+    HIP_TRY(e, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    e->pinned.emplace_back((char *)p, (size_t)bytes);
+    *ptr = p;
+    return 0;
+}
+
+int clair_pinned_free(clair_engine_t *e, void *ptr) {
+    if (!e) return fail(nullptr, "engine is NULL");
+    for (size_t i = 0; i < e->pinned.size(); ++i)
+        if (e->pinned[i].first == (char *)ptr) {
+            HIP_TRY(e, hipSetDevice(e->device));
+            for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));   // no copy may still be reading it
+            HIP_TRY(e, hipHostFree(ptr));
+            e->pinned.erase(e->pinned.begin() + (long)i);
+            return 0;
+        }
+    return fail(e, "clair_pinned_free: not a buffer of clair_pinned_alloc");
 }
 
 int clair_engine_counter(clair_engine_t *e, int which, int64_t *value) {

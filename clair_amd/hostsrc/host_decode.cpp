@@ -565,6 +565,24 @@ extern "C" int clair_host_format_calls(const clair_call_t *calls, const char *me
     });
 }
 
+// The same from the COLUMNS of binary tensor records (clair_amd/tensor_binary.py: contig S37 + length, position i64, refseq S33 + length),
+// n rows each: no text table has to be built for the batch first.
+extern "C" int clair_host_format_calls_records(const clair_call_t *calls, const char *ctg, const uint8_t *ctg_len, const int64_t *pos, const char *seq,
+                                               const uint8_t *seq_len, int n, int show_reference, int haploid_precision, int haploid_sensitive,
+                                               int qual_threshold, int arith_numpy2, char *out, int64_t out_cap, int64_t *out_len, int *n_rows,
+                                               uint8_t *status) {
+    if (!calls || !ctg || !ctg_len || !pos || !seq || !seq_len || !out || !out_len || !n_rows || n < 0)
+        return clair_host_fail("clair_host_format_calls_records: bad arguments");
+    if (status) memset(status, 0, (size_t)n);
+    const Config cfg{show_reference, haploid_precision, haploid_sensitive, qual_threshold >= 0, qual_threshold, arith_numpy2};
+    return rows_in_parallel(n, out, out_cap, out_len, n_rows, status, calls, [&](int i, std::string &buf, bool &consulted) {
+        if (seq_len[i] <= CENTER) { clair_host_fail("candidate %d: reference sequence has %d characters, the centre base is index 16", i, (int)seq_len[i]); return -1; }
+        if (ctg_len[i] > 37 || seq_len[i] > 33) { clair_host_fail("candidate %d: record field longer than its column", i); return -1; }
+        consulted = calls[i].status & CLAIR_CALL_CONSULTED;
+        return format_one(calls[i], ctg + (size_t)i * 37, ctg_len[i], (long long)pos[i], seq + (size_t)i * 33, seq_len[i], cfg, buf);
+    });
+}
+
 extern "C" int clair_host_centre_bytes(const char *meta, const int32_t *meta_tok, int n, uint8_t *centre) {
     if (!meta || !meta_tok || !centre || n < 0) return clair_host_fail("clair_host_centre_bytes: bad arguments");
     for (int i = 0; i < n; ++i) {

@@ -94,6 +94,10 @@ class Clair(object):
         include/clair_call.h -- or (records, probabilities) -- instead of the probabilities."""
         self._engine.submit_calls(slot, batch, centre, counts=counts, with_probabilities=with_probabilities)
 
+    def pinned_buffer(self, nbytes):
+        """Page-locked host memory of the engine (include/clair_amd.h: clair_pinned_alloc) as a uint8 array."""
+        return self._engine.pinned_buffer(nbytes)
+
     def wait(self, slot):
         return self._engine.wait(slot)
 

@@ -101,6 +101,12 @@ class InfoTable(object):
         self._meta = (meta.tobytes(), tok)
         return self._meta
 
+    def record_columns(self):
+        """(contig S37 column, its lengths, positions int64, refseq S33 column, its lengths) as contiguous arrays: what
+        clair_host_format_calls_records takes."""
+        return (np.ascontiguousarray(self.ctg), np.ascontiguousarray(self.ctg_len, dtype=np.uint8), np.ascontiguousarray(self.pos, dtype=np.int64),
+                np.ascontiguousarray(self.seq), np.ascontiguousarray(self.seq_len, dtype=np.uint8))
+
     def centre_bytes(self):
         """uint8 [n,2]: the centre character of each reference window and its length -- what the device decode takes of the text
         (include/clair_amd.h: clair_submit_ex).  Every kept record has more than 16 characters (read_batches filters on it)."""
@@ -113,6 +119,90 @@ class InfoTable(object):
 
 _IUPAC_TABLE = np.zeros(256, dtype=bool)
 _IUPAC_TABLE[list(IUPAC)] = True
+
+
+class BufferPool(object):
+    """Record buffers a reader fills and a consumer hands back: uint8 arrays of batch_size x 2 192 bytes, page-locked when they come
+    from the GPU engine (clair_amd._capi.Engine.pinned_buffer), so that a batch read into one goes to the device from where it lies.
+    get() blocks until a buffer is free, or raises Closed once the consumer has given up."""
+
+    class Closed(Exception):
+        pass
+
+    def __init__(self, arrays):
+        import queue
+        self._q = queue.Queue()
+        self._closed = False
+        for a in arrays:
+            self._q.put(a)
+
+    def get(self):
+        import queue
+        while True:
+            try:
+                return self._q.get(timeout=0.1)
+            except queue.Empty:
+                if self._closed:
+                    raise BufferPool.Closed()
+
+    def put(self, a):
+        self._q.put(a)
+
+    def close(self):
+        self._closed = True
+
+
+def _fill(stream, view):
+    """Read into `view` (a writable memoryview) until it is full or the stream ends; -> bytes read."""
+    have, want = 0, len(view)
+    readinto = getattr(stream, "readinto", None)
+    while have < want:
+        if readinto is not None:
+            k = readinto(view[have:])
+            if not k:
+                break
+        else:
+            data = stream.read(want - have)
+            if not data:
+                break
+            k = len(data)
+            view[have:have + k] = data
+        have += k
+    return have
+
+
+def read_batches_into(stream, batch_size, pool):
+    """read_batches(with_input=False) that reads every batch of records straight into a buffer of `pool` (BufferPool) -- no copy of the
+    batch is made on the host at all -- and yields (None, infos, counts view, buffer); the consumer gives the buffer back
+    (pool.put) once the GPU has taken the batch.  Same batching rules, same progress lines."""
+    processed = 0
+    want = batch_size * RECORD.itemsize
+    while True:
+        try:
+            buf = pool.get()
+        except BufferPool.Closed:
+            return
+        have = _fill(stream, memoryview(buf)[:want])
+        take = have // RECORD.itemsize * RECORD.itemsize
+        if take < have:
+            raise ValueError("truncated binary tensor record (%d trailing bytes)" % (have - take))
+        if take == 0:
+            pool.put(buf)
+            return
+        rec = buf[:take].view(RECORD)
+        seq_bytes = np.frombuffer(np.ascontiguousarray(rec["seq"]).tobytes(), dtype=np.uint8).reshape(len(rec), 33)
+        keep = (rec["seq_len"] > 16) & _IUPAC_TABLE[seq_bytes[:, 16]]
+        if not keep.all():
+            rec = rec[keep]                           # (a copy outside the buffer: that batch goes through the staging path)
+        n = len(rec)
+        processed += n
+        print("Processed %d tensors" % processed, file=sys.stderr)
+        if n == 0:
+            pool.put(buf)
+        else:
+            yield None, InfoTable(rec["ctg"].copy(), rec["ctg_len"].copy(), rec["pos"].copy(), rec["seq"].copy(), rec["seq_len"].copy()), rec["counts"], buf
+        if have < want:
+            return
 
 
 def read_batches(stream, batch_size, first=b"", with_input=True):

@@ -118,9 +118,10 @@ def _open_source(tensor_file_path, binary=False):
     return proc, proc.stdout
 
 
-def tensor_generator_from(tensor_file_path, batch_size, with_input=True):
+def tensor_generator_from(tensor_file_path, batch_size, with_input=True, record_buffers=None):
     """Yield (X float32 [n,33,8,4], infos [[ctg, pos, seq], ...]) with n <= batch_size.  (with_input=False: binary records may
-    leave X as None and hand their raw counts on as a third element instead, tensor_binary.read_batches.)
+    leave X as None and hand their raw counts on as a third element instead, tensor_binary.read_batches; record_buffers: a
+    tensor_binary.BufferPool the binary records are read INTO, a fourth element names the buffer to give back.)
 
     The text is parsed by the native helper (include/clair_host.h: clair_host_parse_tensors, ~20x the NumPy path below);
     `tensor_generator_from_py` is the line-by-line restatement of the reference it is tested against."""
@@ -130,7 +131,11 @@ def tensor_generator_from(tensor_file_path, batch_size, with_input=True):
     proc, stream = _open_source(tensor_file_path, binary=True)
     head = stream.read(len(tensor_binary.MAGIC))
     if head == tensor_binary.MAGIC:              # fixed-size binary records (clair_amd/tensor_binary.py) instead of text
-        for batch in tensor_binary.read_batches(stream, batch_size, with_input=with_input):
+        if record_buffers is not None and not with_input:      # straight into the consumer's (page-locked) buffers
+            batches = tensor_binary.read_batches_into(stream, batch_size, record_buffers)
+        else:
+            batches = tensor_binary.read_batches(stream, batch_size, with_input=with_input)
+        for batch in batches:
             yield batch
         if proc is not None:
             stream.close()

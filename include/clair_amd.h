@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
- * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode and kernel id CLAIR_K_DECODE (round 3). */
+ * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3). */
 #define CLAIR_ABI_VERSION 3
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
@@ -140,6 +140,14 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
  * clair_wait(slot); buffers must stay valid until it returns. */
 int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int64_t input_stride_bytes, int n,
                     const uint8_t *centre, clair_call_t *calls, float *gt21, float *genotype, float *indel_len1, float *indel_len2);
+
+/* Page-locked host memory the DMA engine can read in place.  A producer that fills such a buffer -- e.g. reads binary tensor records
+ * from a file straight into it -- and passes a pointer INTO it as `input` of clair_submit_ex (with the records' stride) gets the
+ * batch to the GPU without any pass over it on the submitting thread: the transfer is a strided 2-D copy from where the data lies.
+ * The buffer must not be rewritten before clair_wait of the submit that read it has returned.  Freed by clair_pinned_free (which
+ * waits for the handle's streams) or with the engine. */
+int clair_pinned_alloc(clair_engine_t *e, int64_t bytes, void **ptr);
+int clair_pinned_free(clair_engine_t *e, void *ptr);
 
 /* The decode alone, on probabilities the caller already holds (call_var --input_probabilities, clair/call_var.py:1276-1309, and the
  * tests that feed the kernel crafted probabilities: exact ties, exact zeros, products that underflow).  Synchronous; does not need

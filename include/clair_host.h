@@ -82,6 +82,12 @@ int clair_host_format_calls(const clair_call_t *calls, const char *meta, const i
                             int haploid_precision, int haploid_sensitive, int qual_threshold, int arith_numpy2, char *out,
                             int64_t out_cap, int64_t *out_len, int *n_rows, uint8_t *status);
 int clair_host_centre_bytes(const char *meta, const int32_t *meta_tok, int n, uint8_t *centre);
+/* clair_host_format_calls from the columns of binary tensor records (clair_amd/tensor_binary.py): contig names [n][37] with their
+ * lengths, positions, reference windows [n][33] with their lengths -- no text table is built for the batch.  Same rows. */
+int clair_host_format_calls_records(const clair_call_t *calls, const char *ctg, const uint8_t *ctg_len, const int64_t *pos, const char *seq,
+                                    const uint8_t *seq_len, int n, int show_reference, int haploid_precision, int haploid_sensitive,
+                                    int qual_threshold, int arith_numpy2, char *out, int64_t out_cap, int64_t *out_len, int *n_rows,
+                                    uint8_t *status);
 
 /* -- pileup: alignments -> [33][8][4] count windows, the work of dataPrepScripts/CreateTensor.py:179-394 (OutputAlnTensor) and
  *    :29-65 (generate_tensor) as a streaming builder.  The caller supplies what the reference obtains from its sub-processes:

@@ -161,15 +161,23 @@ class _CallsModel(_OracleModel):
 
     def __init__(self, w):
         _OracleModel.__init__(self, w)
-        self.slots, self.calls_submits = {}, 0
+        self.slots, self.calls_submits, self.strided, self.buffers = {}, 0, 0, []
 
     def submit(self, slot, batchX):
         self.slots[slot] = ("probs", np.asarray(batchX), None, False)
 
     def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
-        assert not counts
         self.calls_submits += 1
-        self.slots[slot] = ("calls", np.asarray(batch), centre, with_probabilities)
+        x = np.asarray(batch)
+        if counts:                                  # raw counts (possibly a strided view into a record buffer): what the device would convert
+            self.strided += int(not x.flags.c_contiguous)
+            x = x.astype(np.float32)
+            x[..., 1:] -= x[..., :1]
+        self.slots[slot] = ("calls", x, centre, with_probabilities)
+
+    def pinned_buffer(self, nbytes):
+        self.buffers.append(np.zeros(nbytes, dtype=np.uint8))
+        return self.buffers[-1]
 
     def wait(self, slot):
         from clair_amd import _hostapi
@@ -202,6 +210,32 @@ def test_driver_with_the_decode_on_the_device_side_writes_the_same_vcf(tmp_path,
         wr.close()
         assert (m.calls_submits > 0) == expect_calls
         assert open(out).read() == open(os.path.join(GOLD, "e2e_230_%s.vcf" % tag)).read()
+
+
+def test_driver_reads_binary_records_into_the_engines_buffers_and_writes_the_same_vcf(tmp_path):
+    """Binary tensor records + decode on the device side: call_variants reads every batch straight into a buffer the model lent it
+    (page-locked on the GPU), submits the counts column as a strided view of that buffer, gives the buffer back when the batch has
+    left the model, and writes the reference driver's VCF."""
+    from clair_amd import tensor_binary, utils, weights
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+    binary = str(tmp_path / "t.bin")
+    with redirect_stderr(io.StringIO()):
+        batches = list(utils.tensor_generator_from(os.path.join(GOLD, "e2e_230.txt.gz"), 1000))
+    with open(binary, "wb") as f:
+        f.write(tensor_binary.MAGIC)
+        for X, infos in batches:
+            raw = np.rint(np.concatenate([X[..., :1], X[..., 1:] + X[..., :1]], axis=-1)).astype(np.int16)
+            f.write(tensor_binary.pack_records(infos[0][0], [int(i[1]) for i in infos], [i[2] for i in infos], raw))
+    out = str(tmp_path / "o.vcf")
+    args = cvar.build_parser().parse_args(["--tensor_fn", binary, "--call_fn", out])
+    dec = cvar.VariantDecoder(cvar.OutputConfig(*CONFIGS["default"]), arith="numpy2")
+    wr = cvar.VcfWriter(out, "SAMPLE", None, False)
+    m = _CallsModel(w)
+    with redirect_stderr(io.StringIO()):
+        cvar.call_variants(args, m, dec, wr, batch_size=50)
+    wr.close()
+    assert len(m.buffers) == 2 * m.n_slots + 4 and m.calls_submits == 5 and m.strided == 5      # 230 records in batches of 50, all from the pool
+    assert open(out).read() == open(os.path.join(GOLD, "e2e_230_default.vcf")).read()
 
 
 def test_ensemble_roundtrip_through_input_probabilities(decode_cases, tmp_path):

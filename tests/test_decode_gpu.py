@@ -108,3 +108,21 @@ def test_call_records_survive_a_fused_launch_failure(synth_weights, monkeypatch)
                 _same_records(g, want)
         finally:
             eng.close()
+
+
+def test_counts_in_the_engines_pinned_buffer_go_to_the_device_from_where_they_lie(engine, synth_weights):
+    """clair_submit_ex on a strided view INTO a buffer of clair_pinned_alloc (binary tensor records read in place): a 2-D DMA of the
+    counts column, no staging copy -- the same records as the dense, pageable submit."""
+    from clair_amd import tensor_binary
+    raw, infos = synth.synthetic_candidates(900, "ont", seed=51)
+    centre = _hostapi.centre_bytes(infos)
+    engine.submit_calls(0, raw.astype(np.int16), centre, counts=True)
+    want = engine.wait(0)
+    packed = np.frombuffer(tensor_binary.pack_records(infos[0][0], [int(i[1]) for i in infos], [i[2] for i in infos], raw), dtype=np.uint8)
+    buf = engine.pinned_buffer(1024 * tensor_binary.RECORD.itemsize)
+    buf[:packed.size] = packed
+    rec = buf[:packed.size].view(tensor_binary.RECORD)
+    assert not rec["counts"].flags.c_contiguous and rec["counts"].strides[0] == 2192
+    for rep in range(2):
+        engine.submit_calls(rep, rec["counts"], centre, counts=True)
+        _same_records(engine.wait(rep), want)

@@ -332,3 +332,24 @@ def test_format_rejects_a_record_whose_class_contradicts_its_strings():
     calls["gi"][i] = (calls["gi"][i] + 1) % 21
     with pytest.raises(ValueError, match="gt21 class"):
         _hostapi.format_calls(calls, infos, True, False, False, None, False)
+
+
+def test_formatting_from_record_columns_equals_formatting_from_the_text_table():
+    """A batch of binary tensor records hands its columns to the formatter as they are (clair_host_format_calls_records) and the rows
+    come back as the bytes that go into the file: the same bytes as the list-of-strings path over the [[ctg, pos, seq], ...] table."""
+    import io
+    from contextlib import redirect_stderr
+    from clair_amd import tensor_binary
+    x, infos, Y = decode_cases(n=700)
+    keep = [i for i, inf in enumerate(infos) if len(inf[2]) == 33 and inf[2][16] in "ACGTURYSWKMBDHVN"]
+    x, infos, Y = x[keep], [infos[i] for i in keep], [a[keep] for a in Y]
+    raw = np.rint(np.concatenate([x[..., :1], x[..., 1:] + x[..., :1]], axis=-1)).astype(np.int16)          # back to raw counts
+    buf = tensor_binary.pack_records(infos[0][0], [int(i[1]) for i in infos], [i[2] for i in infos], raw)
+    with redirect_stderr(io.StringIO()):
+        (_, table, counts), = list(tensor_binary.read_batches(io.BytesIO(buf), 4096, with_input=False))
+    assert list(table) == [list(i) for i in infos] and np.array_equal(_hostapi.centre_bytes(table), _hostapi.centre_bytes(infos))
+    calls = _hostapi.resolve_calls(x, Y, _hostapi.centre_bytes(infos))
+    for cfg in ((True, False, False, None), (False, False, True, 40)):
+        rows = _hostapi.format_calls(calls, infos, *cfg, False)
+        text, status = _hostapi.format_calls(calls, table, *cfg, False, with_status=True, as_text=True)
+        assert text == ("\n".join(rows) + "\n").encode() and int((status & 1).sum()) == len(rows)
