@@ -611,7 +611,8 @@ class VcfWriter(object):
     def write_rows(self, rows):
         if isinstance(rows, bytes):      # finished text of a batch (VariantDecoder.decode_calls): rows already '\n'-terminated
             if rows:
-                self.fp.write(rows.decode("ascii"))
+                self.fp.flush()                    # what went through the text layer so far comes first
+                self.fp.buffer.write(rows)
         elif rows:
             self.fp.write("\n".join(rows))
             self.fp.write("\n")

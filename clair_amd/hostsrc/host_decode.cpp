@@ -15,12 +15,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
 
 int clair_host_fail(const char *fmt, ...);   // host_io.cpp
 extern "C" int clair_host_threads(int work_items);
+void clair_host_parallel(int nthreads, const std::function<void(int)> &work);   // host_io.cpp: persistent pool
 
 namespace {
 
@@ -486,12 +488,7 @@ int rows_in_parallel(int n, char *out, int64_t out_cap, int64_t *out_len, int *n
         }
     };
     (void)calls;
-    if (nthreads <= 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
+    clair_host_parallel(nthreads, work);
     for (int t = 0; t < nthreads; ++t)                       // the first failing candidate in input order
         if (err_at[(size_t)t] >= 0) return clair_host_fail("%s", errs[(size_t)t].c_str());
     size_t total = 0;
@@ -540,12 +537,7 @@ extern "C" int clair_host_resolve_calls(const float *x, const float *gt21, const
             resolve_one(x + (size_t)i * CLAIR_HOST_VALUES, gt21 + (size_t)i * 21, genotype + (size_t)i * 3, len1 + (size_t)i * 33, len2 + (size_t)i * 33,
                         (char)centre[2 * (size_t)i], centre[2 * (size_t)i + 1], fam, calls[i]);
     };
-    if (nthreads <= 1) work(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
-        for (auto &th : pool) th.join();
-    }
+    clair_host_parallel(nthreads, work);
     return 0;
 }
 
