@@ -66,7 +66,7 @@ def traffic():
         doc = json.load(open(path)) if os.path.isfile(path) else {"entries": {}}
         fused = {k: v for k, v in table.items() if k == "layer2_fused"}
         try:
-            head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE).stdout.decode().strip() or None
+            head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip() or None
         except OSError:
             head = None
         prev = doc["entries"].get(str(batch), {})
