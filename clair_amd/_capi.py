@@ -23,6 +23,10 @@ SYMBOLS = (
     "clair_debug_read", "clair_engine_counter",
     "clair_comm_preflight", "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_last_error", "clair_comm_barrier",
     "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
+    "clair_frontend_create", "clair_frontend_destroy", "clair_frontend_last_error", "clair_frontend_add_reads",
+    "clair_frontend_find_candidates", "clair_frontend_set_candidates", "clair_frontend_get_candidates", "clair_frontend_build_windows",
+    "clair_frontend_window_info", "clair_frontend_window_counts", "clair_frontend_counts_device", "clair_frontend_budget_inputs",
+    "clair_frontend_stats",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail", "decode")
 
@@ -94,11 +98,29 @@ def load(path=None):
     lib.clair_comm_broadcast.argtypes = [c_vp, c_vp, c_i64, c_int]
     lib.clair_comm_allgather.argtypes = [c_vp, c_vp, c_vp, c_i64]
     lib.clair_comm_allgather_device.argtypes = [c_vp, c_vp, c_vp, c_i64]
+    if not older_ok or hasattr(lib, "clair_frontend_create"):
+        lib.clair_frontend_create.argtypes = [c_int, ctypes.c_char_p, c_i64, c_i64, c_i64, c_i64, ctypes.POINTER(c_vp)]
+        lib.clair_frontend_destroy.argtypes = [c_vp]
+        lib.clair_frontend_destroy.restype = None
+        lib.clair_frontend_last_error.argtypes = [c_vp]
+        lib.clair_frontend_last_error.restype = ctypes.c_char_p
+        lib.clair_frontend_add_reads.argtypes = [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64]
+        lib.clair_frontend_find_candidates.argtypes = [c_vp, ctypes.c_double, ctypes.c_double, c_i64, c_i64, c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
+        lib.clair_frontend_set_candidates.argtypes = [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
+        lib.clair_frontend_get_candidates.argtypes = [c_vp, c_vp]
+        lib.clair_frontend_build_windows.argtypes = [c_vp, c_int, c_int, ctypes.POINTER(c_i64)]
+        lib.clair_frontend_window_info.argtypes = [c_vp, c_i64, c_i64, c_vp, c_vp]
+        lib.clair_frontend_window_counts.argtypes = [c_vp, c_i64, c_i64, c_vp]
+        lib.clair_frontend_counts_device.argtypes = [c_vp, c_i64]
+        lib.clair_frontend_counts_device.restype = c_vp
+        lib.clair_frontend_budget_inputs.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp]
+        lib.clair_frontend_stats.argtypes = [c_vp, c_vp]
     for name in SYMBOLS:
         if older_ok and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
-        if name not in ("clair_last_error", "clair_engine_destroy", "clair_comm_last_error", "clair_comm_destroy"):
+        if name not in ("clair_last_error", "clair_engine_destroy", "clair_comm_last_error", "clair_comm_destroy",
+                        "clair_frontend_last_error", "clair_frontend_destroy", "clair_frontend_counts_device"):
             fn.restype = c_int
     if path is None:
         _lib = lib
@@ -190,6 +212,17 @@ class Engine(object):
         centre: uint8 [n,2] (clair_amd._hostapi.centre_bytes).  wait(slot) then returns the call records (structured array,
         _hostapi.CALL_DTYPE), or (records, [gt21, genotype, len1, len2]) with with_probabilities=True."""
         from clair_amd._hostapi import CALL_DTYPE
+        if isinstance(batch, DeviceWindows):       # windows the device front end left in HBM: the address goes through as it is
+            n = len(batch)
+            c = np.ascontiguousarray(centre, dtype=np.uint8)
+            if c.shape != (n, 2):
+                raise ValueError("centre must be uint8 [%d,2], got %r" % (n, c.shape))
+            calls = np.zeros(n, dtype=CALL_DTYPE)
+            outs = self._alloc_out(n) if with_probabilities else None
+            ptrs = [_ptr(o) for o in outs] if outs else [None] * 4
+            self._check(self._lib.clair_submit_ex(self._h, int(slot), ctypes.c_void_p(batch.address), 1, 0, n, _ptr(c), _ptr(calls), *ptrs), "clair_submit_ex")
+            self._pending[slot] = ((batch, c), (calls, outs) if outs else calls)
+            return
         dtype = np.int16 if counts else np.float32
         x = np.asarray(batch)
         if x.ndim != 4 or x.shape[1:] != (33, 8, 4):
@@ -305,3 +338,152 @@ class Engine(object):
 def split_outputs(packed):
     """[n,90] packed rows -> [gt21, genotype, len1, len2] (copies, C-contiguous)."""
     return [np.ascontiguousarray(packed[:, a:b]) for a, b in ((0, 21), (21, 24), (24, 57), (57, 90))]
+
+
+class DeviceWindows(object):
+    """n pileup windows [33][8][4] int16 in device memory (clair_frontend_counts_device): what Engine.submit_calls takes in place of a
+    host array.  Keeps its Frontend alive; host() copies the counts back (the decode needs them only when a BAM is consulted)."""
+
+    def __init__(self, frontend, first, n):
+        self.frontend, self.first, self.n = frontend, int(first), int(n)
+        self.address = frontend.counts_address(first)
+
+    def __len__(self):
+        return self.n
+
+    def host(self):
+        return self.frontend.window_counts(self.first, self.n)
+
+
+class Frontend(object):
+    """Thin object wrapper over one clair_frontend_t (include/clair_amd.h, "front end on the device")."""
+
+    def __init__(self, device, reference_sequence, reference_start_0_based, span_lo, span_hi, lib_path=None):
+        self._lib = load(lib_path)
+        ref = reference_sequence.encode("latin-1") if isinstance(reference_sequence, str) else bytes(reference_sequence)
+        self._h = ctypes.c_void_p()
+        rc = self._lib.clair_frontend_create(int(device), ref, len(ref), int(reference_start_0_based), int(span_lo), int(span_hi), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.clair_frontend_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise EngineError("clair_frontend_create failed: %s" % msg)
+        self.slab_reads = []                # host copies of each slab's read records: the budget replay walks them
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError("%s failed: %s" % (what, self._lib.clair_frontend_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.clair_frontend_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_slab(self, packer):
+        """Send the slab a clair_amd._hostapi.SamPacker is holding to the device and start the next one."""
+        (r, o, e, q), st = packer.slab_pointers()
+        if st["reads"] and st["ops"]:
+            from clair_amd._hostapi import READ_DTYPE
+            self._check(self._lib.clair_frontend_add_reads(self._h, r, st["reads"], o, st["ops"], e, q, st["seq_bytes"]), "clair_frontend_add_reads")
+            buf = (ctypes.c_char * (st["reads"] * READ_DTYPE.itemsize)).from_address(r)
+            self.slab_reads.append(np.frombuffer(buf, dtype=READ_DTYPE).copy())
+        packer.reset()
+
+    def add_arrays(self, reads, ops, op_elem, seq):
+        """The same from NumPy arrays (tests)."""
+        from clair_amd._hostapi import OP_DTYPE, READ_DTYPE
+        reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+        ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        op_elem = np.ascontiguousarray(op_elem, dtype=np.uint32)
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        if len(reads) and len(ops):
+            self._check(self._lib.clair_frontend_add_reads(self._h, _ptr(reads), len(reads), _ptr(ops), len(ops), _ptr(op_elem), _ptr(seq), len(seq)),
+                        "clair_frontend_add_reads")
+            self.slab_reads.append(reads.copy())
+
+    def find_candidates(self, min_coverage=4, threshold=0.125, ctg_start=None, ctg_end=None, bed=None):
+        have_range = ctg_start is not None and ctg_end is not None
+        if bed is None:
+            bs = be = np.zeros(0, dtype=np.int64)
+            n_bed = -1
+        else:
+            bs = np.ascontiguousarray([b[0] for b in bed], dtype=np.int64)
+            be = np.ascontiguousarray([b[1] for b in bed], dtype=np.int64)
+            n_bed = len(bs)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.clair_frontend_find_candidates(self._h, float(min_coverage), float(threshold), int(ctg_start) if have_range else -1,
+                                                             int(ctg_end) if have_range else -1, _ptr(bs), _ptr(be), n_bed, ctypes.byref(n)),
+                    "clair_frontend_find_candidates")
+        return int(n.value)
+
+    def set_candidates(self, positions):
+        p = np.ascontiguousarray(positions, dtype=np.int64)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.clair_frontend_set_candidates(self._h, _ptr(p), len(p), ctypes.byref(n)), "clair_frontend_set_candidates")
+        return int(n.value)
+
+    def candidates(self):
+        out = np.empty(max(self.stats()["candidates"], 0), dtype=np.int64)
+        self._check(self._lib.clair_frontend_get_candidates(self._h, _ptr(out)), "clair_frontend_get_candidates")
+        return out
+
+    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True):
+        n = ctypes.c_int64(0)
+        self._check(self._lib.clair_frontend_build_windows(self._h, int(min_coverage), int(bool(drop_non_iupac_centre)), ctypes.byref(n)),
+                    "clair_frontend_build_windows")
+        return int(n.value)
+
+    def window_info(self, first, n):
+        """-> (centres int64 [n], refseq uint8 [n,34] NUL-padded)"""
+        centres = np.empty(n, dtype=np.int64)
+        seqs = np.zeros((n, 34), dtype=np.uint8)
+        self._check(self._lib.clair_frontend_window_info(self._h, int(first), int(n), _ptr(centres), _ptr(seqs)), "clair_frontend_window_info")
+        return centres, seqs
+
+    def window_counts(self, first, n):
+        counts = np.empty((n, 33, 8, 4), dtype=np.int16)
+        self._check(self._lib.clair_frontend_window_counts(self._h, int(first), int(n), _ptr(counts)), "clair_frontend_window_counts")
+        return counts
+
+    def counts_address(self, first):
+        a = self._lib.clair_frontend_counts_device(self._h, int(first))
+        if not a:
+            raise EngineError("clair_frontend_counts_device: no windows yet")
+        return int(a)
+
+    def stats(self):
+        v = (ctypes.c_int64 * 6)()
+        self._check(self._lib.clair_frontend_stats(self._h, v), "clair_frontend_stats")
+        return dict(zip(("anomalies", "slabs", "reads", "elements", "candidates", "windows"), [int(x) for x in v]))
+
+    def budget_binds(self, available_slots=5000000):
+        """Replay CreateTensor's count of free tuple slots over everything added (clair_host_tuple_budget_binds)."""
+        from clair_amd import _hostapi
+        n_cand = self.stats()["candidates"]
+        centres = np.empty(max(n_cand, 0), dtype=np.int64)
+        window_tuples = np.empty(max(n_cand, 0), dtype=np.uint64)
+        self._check(self._lib.clair_frontend_budget_inputs(self._h, 0, None, _ptr(centres), _ptr(window_tuples)), "clair_frontend_budget_inputs")
+        state = np.array([available_slots, 0], dtype=np.int64)
+        for k, reads in enumerate(self.slab_reads):
+            tuples = np.empty(len(reads), dtype=np.uint64)
+            self._check(self._lib.clair_frontend_budget_inputs(self._h, k, _ptr(tuples), None, None), "clair_frontend_budget_inputs")
+            if _hostapi.tuple_budget_binds(reads, tuples, centres, window_tuples, state):
+                return True
+        return False
+
+    def read_tuples(self, slab):
+        tuples = np.empty(len(self.slab_reads[slab]), dtype=np.uint64)
+        self._check(self._lib.clair_frontend_budget_inputs(self._h, int(slab), _ptr(tuples), None, None), "clair_frontend_budget_inputs")
+        return tuples
+
+    def window_tuples(self):
+        n_cand = max(self.stats()["candidates"], 0)
+        centres = np.empty(n_cand, dtype=np.int64)
+        window_tuples = np.empty(n_cand, dtype=np.uint64)
+        self._check(self._lib.clair_frontend_budget_inputs(self._h, 0, None, _ptr(centres), _ptr(window_tuples)), "clair_frontend_budget_inputs")
+        return centres, window_tuples

@@ -12,7 +12,9 @@ SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_thread
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
            "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
-           "clair_host_evc_pending", "clair_host_evc_reads", "clair_host_evc_take", "clair_host_evc_take_text")
+           "clair_host_evc_pending", "clair_host_evc_reads", "clair_host_evc_take", "clair_host_evc_take_text",
+           "clair_host_sampack_create", "clair_host_sampack_destroy", "clair_host_sampack_feed", "clair_host_sampack_stats",
+           "clair_host_sampack_slab", "clair_host_sampack_reset", "clair_host_tuple_budget_binds")
 N_VALUES = 1056
 _lib = None
 
@@ -62,8 +64,16 @@ def load():
         lib.clair_host_evc_take_text.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         lib.clair_host_counts_to_input_i16.argtypes = [vp, i64, vp]
         lib.clair_host_counts_to_input_i32.argtypes = [vp, i64, vp]
-        if lib.clair_host_abi_version() != 5:
-            raise RuntimeError("libclair_host.so has ABI version %d, expected 5: run `python -m clair_amd.build`"
+        lib.clair_host_sampack_create.argtypes = [ctypes.c_char_p, i32, i32, i32, i64, i64, ctypes.POINTER(vp)]
+        lib.clair_host_sampack_destroy.argtypes = [vp]
+        lib.clair_host_sampack_destroy.restype = None
+        lib.clair_host_sampack_feed.argtypes = [vp, vp, i64, i32, ctypes.POINTER(i64)]
+        lib.clair_host_sampack_stats.argtypes = [vp, vp]
+        lib.clair_host_sampack_slab.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        lib.clair_host_sampack_reset.argtypes = [vp]
+        lib.clair_host_tuple_budget_binds.argtypes = [vp, vp, i64, vp, vp, i64, vp, ctypes.POINTER(i32)]
+        if lib.clair_host_abi_version() != 6:
+            raise RuntimeError("libclair_host.so has ABI version %d, expected 6: run `python -m clair_amd.build`"
                                % lib.clair_host_abi_version())
         _lib = lib
     return _lib
@@ -460,3 +470,73 @@ class CandidateFinder(object):
         self.finish()
         while self.pending():
             yield self.take_text().decode("latin-1")
+
+
+READ_DTYPE = np.dtype([("pos0", "<i8"), ("seq0", "<u4"), ("seq_len", "<u4"), ("op0", "<u4"), ("n_ops", "<u4"), ("flags", "<u4"), ("reserved", "<u4")])
+OP_DTYPE = np.dtype([("read", "<u4"), ("code_len", "<u4"), ("ref_off", "<i4"), ("q_off", "<u4")])
+READ_REVERSE, READ_EVC, READ_PILE, READ_FLUSH = 1, 2, 4, 8
+
+
+class SamPacker(object):
+    """clair_host_sampack_*: `samtools view` text -> slabs of packed alignments (include/clair_reads.h) for the device front end."""
+
+    def __init__(self, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=None):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        a, b = (-1, -1) if pile_region is None else (int(pile_region[0]), int(pile_region[1]))
+        if self._lib.clair_host_sampack_create(ctg_name.encode(), int(dcov), int(evc_min_mq), int(pile_min_mq), a, b, ctypes.byref(h)) != 0:
+            raise ValueError("sampack: " + self._lib.clair_host_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.clair_host_sampack_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def feed(self, sam, final=False):
+        """Consume complete lines of `sam` (bytes); returns the unconsumed tail."""
+        used = ctypes.c_int64(0)
+        base = ctypes.cast(ctypes.c_char_p(sam), ctypes.c_void_p).value
+        if self._lib.clair_host_sampack_feed(self._h, base, len(sam), 1 if final else 0, ctypes.byref(used)) != 0:
+            from .create_tensor import PileupError
+            raise PileupError(self._lib.clair_host_last_error().decode())
+        return sam[used.value:]
+
+    def stats(self):
+        v = (ctypes.c_int64 * 8)()
+        self._lib.clair_host_sampack_stats(self._h, v)
+        return dict(zip(("reads", "ops", "elements", "seq_bytes", "anomalies", "lines", "evc_reads", "pile_reads"), [int(x) for x in v]))
+
+    def slab_pointers(self):
+        """-> (reads, ops, op_elem, seq) addresses of the slab being filled + its stats; valid until the next feed() / reset()."""
+        p = [ctypes.c_void_p() for _ in range(4)]
+        self._lib.clair_host_sampack_slab(self._h, *[ctypes.byref(x) for x in p])
+        return [x.value or 0 for x in p], self.stats()
+
+    def slab_arrays(self):
+        """Copies of the slab as NumPy arrays (tests, the budget replay): reads READ_DTYPE, ops OP_DTYPE, op_elem uint32, seq uint8."""
+        (r, o, e, q), st = self.slab_pointers()
+
+        def view(addr, n, dtype):
+            if n == 0:
+                return np.zeros(0, dtype)
+            return np.frombuffer((ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr), dtype=dtype).copy()
+        return view(r, st["reads"], READ_DTYPE), view(o, st["ops"], OP_DTYPE), view(e, st["ops"] + 1, np.uint32), view(q, st["seq_bytes"], np.uint8)
+
+    def reset(self):
+        self._lib.clair_host_sampack_reset(self._h)
+
+
+def tuple_budget_binds(reads, tuples, centres, window_tuples, state):
+    """clair_host_tuple_budget_binds over one slab; state = int64[2] carried between slabs ([free slots, first unreleased centre])."""
+    reads = np.ascontiguousarray(reads, dtype=READ_DTYPE)
+    tuples = np.ascontiguousarray(tuples, dtype=np.uint64)
+    centres = np.ascontiguousarray(centres, dtype=np.int64)
+    window_tuples = np.ascontiguousarray(window_tuples, dtype=np.uint64)
+    binds = ctypes.c_int(0)
+    if load().clair_host_tuple_budget_binds(reads.ctypes.data, tuples.ctypes.data, len(reads), centres.ctypes.data, window_tuples.ctypes.data,
+                                            len(centres), state.ctypes.data, ctypes.byref(binds)) != 0:
+        raise ValueError(load().clair_host_last_error().decode())
+    return bool(binds.value)

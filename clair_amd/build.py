@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("engine.hip", "comm.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("engine.hip", "comm.hip", "frontend.hip")]
 OUT = os.path.join(HERE, "libclair_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -30,11 +30,11 @@ def needs_build():
         return True
     newest = max(os.path.getmtime(os.path.join(dp, f))
                  for dp, _, fs in os.walk(os.path.join(HERE, "csrc")) for f in fs)
-    newest = max(newest, os.path.getmtime(os.path.join(HERE, "..", "include", "clair_amd.h")))
+    newest = max([newest] + [os.path.getmtime(os.path.join(HERE, "..", "include", h)) for h in ("clair_amd.h", "clair_call.h", "clair_reads.h")])
     return newest > os.path.getmtime(OUT)
 
 
-HOST_SRCS = [os.path.join(HERE, "hostsrc", f) for f in ("host_io.cpp", "host_decode.cpp", "host_pileup.cpp")]
+HOST_SRCS = [os.path.join(HERE, "hostsrc", f) for f in ("host_io.cpp", "host_decode.cpp", "host_pileup.cpp", "host_sampack.cpp")]
 HOST_OUT = os.path.join(HERE, "libclair_host.so")
 CXX = os.environ.get("CXX", "g++")
 
@@ -42,8 +42,9 @@ CXX = os.environ.get("CXX", "g++")
 def build_host(force=False):
     """Host-side helpers (include/clair_host.h): plain C++, no HIP."""
     hdr = os.path.join(HERE, "..", "include", "clair_host.h")
+    hdr2 = os.path.join(HERE, "..", "include", "clair_reads.h")
     if (force or not os.path.isfile(HOST_OUT)
-            or max([os.path.getmtime(f) for f in HOST_SRCS] + [os.path.getmtime(hdr)]) > os.path.getmtime(HOST_OUT)):
+            or max([os.path.getmtime(f) for f in HOST_SRCS] + [os.path.getmtime(hdr), os.path.getmtime(hdr2)]) > os.path.getmtime(HOST_OUT)):
         # -ffp-contract=off: the decode restates float32 product chains bit for bit (no fused multiply-add)
         subprocess.check_call([CXX, "-O3", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", "-Wall"] + HOST_SRCS + ["-o", HOST_OUT])
     return HOST_OUT

@@ -328,6 +328,13 @@ bool in_pinned(const clair_engine *e, const void *p, size_t len) {
 }
 
 // n candidates of `row` bytes each, `stride` bytes apart in the caller's buffer (0: dense), into a dense staging buffer
+// memory of this process's HIP devices (hipMalloc), as opposed to anything the host allocated
+bool is_device_pointer(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 void gather_rows(void *dst, const void *src, int n, size_t row, int64_t stride) {
     if (stride == 0 || (size_t)stride == row) { memcpy(dst, src, (size_t)n * row); return; }
     for (int i = 0; i < n; ++i) memcpy((char *)dst + (size_t)i * row, (const char *)src + (size_t)i * (size_t)stride, row);
@@ -724,10 +731,14 @@ int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is
     const size_t row_bytes = CLAIR_INPUT_FLOATS * (input_is_counts ? sizeof(short) : sizeof(float));
     const size_t stride = input_stride_bytes ? (size_t)input_stride_bytes : row_bytes;
     const bool direct = in_pinned(e, input, (size_t)(n - 1) * stride + row_bytes);
+    const bool on_device = !direct && is_device_pointer(input);   // e.g. the windows of clair_frontend_build_windows: no copy at all
+    if (on_device && !input_is_counts) return fail(e, "a device pointer is taken for int16 counts only");
     if (input_is_counts) {
         if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
         const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
-        if (direct && stride != row_bytes) {   // records as they lie: ONE contiguous copy of the span, the conversion kernel skips what lies between the counts
+        if (on_device) {
+            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const char *)input, stride, (f32x4 *)s.d_x, n_quads);
+        } else if (direct && stride != row_bytes) {   // records as they lie: ONE contiguous copy of the span, the conversion kernel skips what lies between the counts
             const size_t span = (size_t)(n - 1) * stride + row_bytes;
             if (s.d_records_bytes < span) {
                 (void)hipFree(s.d_records); s.d_records = nullptr; s.d_records_bytes = 0;

@@ -25,8 +25,9 @@ extern "C" {
 #endif
 
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
- * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3). */
-#define CLAIR_ABI_VERSION 3
+ * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3).
+ * 4: + the clair_frontend_* device front end; clair_submit_ex takes device pointers (round 3). */
+#define CLAIR_ABI_VERSION 4
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
 #define CLAIR_POSITIONS 33
@@ -222,6 +223,50 @@ int clair_comm_broadcast(clair_comm_t *c, void *host, int64_t bytes, int root); 
 int clair_comm_allgather(clair_comm_t *c, const void *send_host, void *recv_host /*[world][bytes_per_rank]*/, int64_t bytes_per_rank);
 /* the same on HBM-resident buffers (e.g. the out_dev rows of clair_dataset_alloc), no host staging */
 int clair_comm_allgather_device(clair_comm_t *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
+
+/* ---- front end on the device: alignments -> candidate sites -> pileup windows that stay in HBM -----------------------------------
+ *
+ * Stands behind the two pypy stages callVarBam pipes into call_var (clair/callVarBam.py:124-199):
+ *   dataPrepScripts/ExtractVariantCandidates.py:160-393 (make_candidates)   -> clair_frontend_find_candidates
+ *   dataPrepScripts/CreateTensor.py:173-388 (OutputAlnTensor), :29-65       -> clair_frontend_build_windows
+ *   clair/utils.py:90-98 (centre-base filter; the channel subtraction is clair_submit_ex's, input_is_counts)
+ * Input: slabs of packed alignments (include/clair_reads.h, produced from `samtools view` text by clair_host_sampack_*), the
+ * reference bases both stages index (`samtools faidx` of the region widened by 1 Mbp, upper-cased; reference_start_0_based = 0-based
+ * position of its first base), and the span of 0-based reference positions [span_lo, span_hi) the per-position tables cover
+ * (alignment bases outside it are ignored: make it the region plus a margin of >= 64).  Output: n windows of [33][8][4] int16 counts
+ * in device memory (clair_frontend_counts_device -> clair_submit_ex with input_is_counts = 1), their centres (1-based) and the 33
+ * reference bases under them.  Windows are the ones the sequential stages write, in ascending order, bit for bit, PROVIDED no
+ * CLAIR_FE_* bit (clair_reads.h) is set in stats[0] and the tuple budget did not bind (clair_frontend_budget_inputs ->
+ * clair_host_tuple_budget_binds); otherwise the caller runs clair_host_evc_* / clair_host_pileup_*, which reproduce the reference
+ * in every regime.  Left-edge windows only (CreateTensor's default; --stop_consider_left_edge stays on the host path).
+ * Calls on one handle are not concurrent; all are synchronous. */
+typedef struct clair_frontend clair_frontend_t;
+struct clair_read;
+struct clair_op;
+int clair_frontend_create(int device, const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based, int64_t span_lo, int64_t span_hi,
+                          clair_frontend_t **out);
+void clair_frontend_destroy(clair_frontend_t *f);
+const char *clair_frontend_last_error(const clair_frontend_t *f);      /* f may be NULL: failure of create */
+/* Copy one slab to the device (it stays there) and add its bases to the per-position tables.  The arrays may be reused on return. */
+int clair_frontend_add_reads(clair_frontend_t *f, const struct clair_read *reads, int64_t n_reads, const struct clair_op *ops, int64_t n_ops,
+                             const uint32_t *op_elem, const uint8_t *seq, int64_t seq_bytes);
+/* The candidate filter over the tallies: arguments as clair_host_evc_create (include/clair_host.h). */
+int clair_frontend_find_candidates(clair_frontend_t *f, double min_coverage, double threshold, int64_t ctg_start, int64_t ctg_end,
+                                   const int64_t *bed_start, const int64_t *bed_end, int64_t n_bed, int64_t *n_candidates);
+/* ... or a given list (--vcf_fn; 1-based, strictly ascending, else CLAIR_FE_CANDIDATES); positions outside the span are dropped. */
+int clair_frontend_set_candidates(clair_frontend_t *f, const int64_t *positions, int64_t n_positions, int64_t *n_candidates);
+int clair_frontend_get_candidates(clair_frontend_t *f, int64_t *positions /*[n_candidates]*/);
+/* Second pass over the resident alignments + assembly.  min_coverage: CreateTensor's --minCoverage (depth at the centre);
+ * drop_non_iupac_centre != 0 applies clair/utils.py:90-91 as well. */
+int clair_frontend_build_windows(clair_frontend_t *f, int min_coverage, int drop_non_iupac_centre, int64_t *n_windows);
+int clair_frontend_window_info(clair_frontend_t *f, int64_t first, int64_t n, int64_t *centres, char *refseq /*[n][34], NUL-padded*/);
+int clair_frontend_window_counts(clair_frontend_t *f, int64_t first, int64_t n, int16_t *counts /*[n][33][8][4], host*/);
+const int16_t *clair_frontend_counts_device(clair_frontend_t *f, int64_t first);   /* device address of window `first`; NULL before build_windows */
+/* What the budget replay needs: tuples appended per alignment of slab `slab` (read_tuples, may be NULL), all candidate centres and
+ * the tuples each window held (0 for a window no alignment opened); either pair may be NULL. */
+int clair_frontend_budget_inputs(clair_frontend_t *f, int64_t slab, uint64_t *read_tuples, int64_t *centres, uint64_t *window_tuples);
+/* stats[0..5] = CLAIR_FE_* bits seen on the device, slabs, alignments, elements, candidates (-1: not yet), windows (-1: not yet) */
+int clair_frontend_stats(clair_frontend_t *f, int64_t *stats);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CLAIR_HOST_ABI_VERSION 5
+#define CLAIR_HOST_ABI_VERSION 6
 #define CLAIR_HOST_VALUES 1056      /* 33 positions x 8 rows x 4 channels (shared/param.py:9-13) */
 
 int clair_host_abi_version(void);
@@ -144,6 +144,34 @@ int64_t clair_host_evc_pending(const clair_evc_t *e);
 int64_t clair_host_evc_reads(const clair_evc_t *e);      /* alignments that passed the filters (:295) */
 int clair_host_evc_take(clair_evc_t *e, int64_t max_rows, int64_t *positions, int64_t *n_taken);   /* 1-based positions only */
 int clair_host_evc_take_text(clair_evc_t *e, char *out, int64_t cap, int64_t *out_len, int64_t *n_taken);
+
+/* -- packed alignments for the device front end (include/clair_reads.h; include/clair_amd.h: clair_frontend_*).  One pass over
+ *    `samtools view` text replaces the line handling of BOTH reference stages (ExtractVariantCandidates.py:266-295 and
+ *    CreateTensor.py:251-287): an alignment is kept when either stage would walk it and carries one flag bit per stage --
+ *    the candidate search wants RNAME == ctg_name, MAPQ >= evc_min_mq, CIGAR != "*" and >= 55 % aligned; the pileup wants
+ *    MAPQ >= pile_min_mq, at most dcov alignments per start position (:277-287) and, when pile_start/pile_end (1-based inclusive,
+ *    -1 -1 = none) are given, an overlap with that range as `samtools view ctg:start-end` computes it (the reference gives the two
+ *    stages different regions, callVarBam.py:124-199).  Errors as clair_host_pileup_feed.  The slab grows until it is taken:
+ *    ..._slab lends the arrays (valid until the next feed / reset), ..._reset starts the next slab; the dcov and sortedness state
+ *    runs on across slabs.  stats[0..7] = alignments, operations, elements, SEQ bytes in the slab; CLAIR_FE_* bits seen so far;
+ *    lines, candidate-search alignments, pileup alignments since creation. */
+typedef struct clair_sampack clair_sampack_t;
+struct clair_read;
+struct clair_op;
+int clair_host_sampack_create(const char *ctg_name, int dcov, int evc_min_mq, int pile_min_mq, int64_t pile_start, int64_t pile_end,
+                              clair_sampack_t **out);
+void clair_host_sampack_destroy(clair_sampack_t *p);
+int clair_host_sampack_feed(clair_sampack_t *p, const char *sam, int64_t len, int final, int64_t *bytes_consumed);
+int clair_host_sampack_stats(const clair_sampack_t *p, int64_t *stats);
+int clair_host_sampack_slab(const clair_sampack_t *p, const struct clair_read **reads, const struct clair_op **ops, const uint32_t **op_elem,
+                            const uint8_t **seq);
+int clair_host_sampack_reset(clair_sampack_t *p);
+/* CreateTensor.py's count of free tuple slots (:181, 283-289, 369-373) replayed from what the device counted: alignments in stream
+ * order with the tuples each appended, candidate centres ascending with the tuples their windows held when released.  state[0] =
+ * free slots (start: 5 000 000), state[1] = first centre not released yet (start: 0); carried from slab to slab.  *binds = 1 when
+ * the count would have reached zero: the reference then drops bases in offer order and only the sequential code reproduces it. */
+int clair_host_tuple_budget_binds(const struct clair_read *reads, const uint64_t *tuples, int64_t n_reads, const int64_t *centres,
+                                  const uint64_t *window_tuples, int64_t n_centres, int64_t *state, int *binds);
 
 #ifdef __cplusplus
 }

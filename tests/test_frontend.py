@@ -1,0 +1,201 @@
+"""Device front end, the parts that run without a GPU: the packer (libclair_host.so: clair_host_sampack_*) against
+its Python twin, and the column formulation the kernels implement (oracle/frontend_np.py) against the reference-minted golden records
+of both pileup stages and against the sequential host code on fresh synthetic alignments."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import frontend_cases as fc  # noqa: E402
+
+from clair_amd import _hostapi  # noqa: E402
+from oracle import frontend_np as fe  # noqa: E402
+
+
+def columns_of(case, slabs=1, **pack_kw):
+    packed = fe.pack_sam(case["sam"], case["ctg"], **pack_kw)
+    col = fe.Columns(case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+    col.add_reads(packed)
+    return col, packed
+
+
+# ---- the packer ---------------------------------------------------------------------------------------------------------------------
+PACK_OPTIONS = [dict(), dict(dcov=3), dict(evc_min_mq=20, pile_min_mq=30), dict(pile_region=(500, 1500)), dict(pile_region=(1, 40), dcov=2)]
+
+
+@pytest.mark.parametrize("opt", range(len(PACK_OPTIONS)))
+def test_packer_matches_python_twin(opt):
+    kw = PACK_OPTIONS[opt]
+    case = fc.synth(seed=40 + opt, n_reads=400, ref_len=3000, dup_burst=8)
+    want = fe.pack_sam(case["sam"], case["ctg"], **kw)
+    p = _hostapi.SamPacker(case["ctg"], **kw)
+    tail = b""
+    for i in range(0, len(case["sam"]), 997):            # lines split across feeds
+        tail = p.feed(tail + case["sam"][i:i + 997])
+    assert p.feed(tail, final=True) == b""
+    r, o, e, s = p.slab_arrays()
+    st = p.stats()
+    assert st["reads"] == len(want["pos0"]) > 100 and st["anomalies"] == want["anomalies"] == 0
+    for name, got in (("pos0", r["pos0"]), ("flags", r["flags"]), ("seq0", r["seq0"]), ("seq_len", r["seq_len"]), ("op0", r["op0"]), ("n_ops", r["n_ops"]),
+                      ("op_read", o["read"]), ("op_code", o["code_len"] & 3), ("op_len", o["code_len"] >> 2), ("op_ref", o["ref_off"]), ("op_q", o["q_off"]),
+                      ("op_elem", e), ("seq", s)):
+        assert np.array_equal(got, want[name]), name
+    if "pile_region" in kw:
+        assert 0 < st["pile_reads"] < st["evc_reads"]
+    # slabs: taking the slab in the middle of the stream changes nothing but the offsets
+    p2 = _hostapi.SamPacker(case["ctg"], **kw)
+    half = case["sam"].index(b"\n", len(case["sam"]) // 2) + 1
+    p2.feed(case["sam"][:half])
+    r1 = p2.slab_arrays()[0]
+    p2.reset()
+    p2.feed(case["sam"][half:], final=True)
+    r2 = p2.slab_arrays()[0]
+    assert np.array_equal(np.concatenate([r1["flags"], r2["flags"]]), r["flags"]) and np.array_equal(np.concatenate([r1["pos0"], r2["pos0"]]), r["pos0"])
+    assert r2["seq0"][0] == 0 and r2["op0"][0] == 0
+
+
+def test_packer_reports_what_leaves_the_regime():
+    ok = b"r1\t0\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n"
+    p = _hostapi.SamPacker("chrS")
+    p.feed(ok + b"r2\t0\tchrS\t5\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n", final=True)
+    assert p.stats()["anomalies"] == fe.A_UNSORTED
+    p = _hostapi.SamPacker("chrS")
+    p.feed(b"r1\t0\tchrS\t10\t60\t3M0I2M\t*\t0\t0\tACGTA\tIIIII\n", final=True)
+    assert p.stats()["anomalies"] == fe.A_ZERO_INDEL
+    p = _hostapi.SamPacker("chrS")
+    p.feed(b"r1\t0\tchrS\t10\t60\t2M200000D3M\t*\t0\t0\tACGTA\tIIIII\n", final=True)
+    assert p.stats()["anomalies"] == fe.A_LONG_SPAN
+    from clair_amd.create_tensor import PileupError
+    for bad in (b"r1\t0\tchrS\n", b"r1\tx\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n", b"\n"):
+        with pytest.raises(PileupError):
+            _hostapi.SamPacker("chrS").feed(bad, final=True)
+    # an alignment neither stage walks leaves nothing behind
+    p = _hostapi.SamPacker("chrS", evc_min_mq=10, pile_min_mq=10)
+    p.feed(b"r1\t0\tchrS\t10\t5\t5M\t*\t0\t0\tACGTA\tIIIII\n" + ok, final=True)
+    assert p.stats()["reads"] == 1 and p.stats()["ops"] == 1 and p.stats()["lines"] == 2
+
+
+# ---- the column formulation against the reference's records --------------------------------------------------------------------------
+@pytest.mark.parametrize("path", fc.CT_GOLDEN, ids=[os.path.basename(p)[10:-8] for p in fc.CT_GOLDEN])
+def test_columns_reproduce_reference_tensor_records(path):
+    case = fc.ct_golden_case(path)
+    col, _ = columns_of(case, dcov=case["dcov"], pile_min_mq=case["min_mq"], pile_region=case["pile_region"])
+    w = col.windows(case["candidates"], min_cov=case["min_coverage"])
+    if "unsorted" in path:
+        assert w is None and col.anomalies == fe.A_CANDIDATES          # list order matters to the reference: the host path's business
+        return
+    if not case["left_edge"]:
+        pytest.skip("--stop_consider_left_edge stays on the host path")
+    assert col.anomalies == 0
+    assert fc.text_of(case["ctg"], w["centres"], w["refseq"], w["counts"]) == case["expected"]
+    assert sum(int(t.sum()) for t in w["tuples"]) == int(w["totals"][w["opened"]].sum()) > 0
+
+
+@pytest.mark.parametrize("path", fc.EVC_GOLDEN, ids=[os.path.basename(p)[11:-8] for p in fc.EVC_GOLDEN])
+def test_columns_reproduce_reference_candidates(path):
+    case = fc.evc_golden_case(path)
+    col, _ = columns_of(case, evc_min_mq=case["min_mq"])
+    bed = None
+    if case["bed"] is not None:
+        iv, st, en = sorted((s, e + 1 if e == s else e) for s, e in case["bed"]), [], []
+        for s, e in iv:
+            if e <= s:
+                continue
+            if st and s <= en[-1]:
+                en[-1] = max(en[-1], e)
+            else:
+                st.append(s)
+                en.append(e)
+        bed = (np.array(st, np.int64), np.array(en, np.int64))
+    got = col.candidates(min_depth=case["min_coverage"], min_af=case["threshold"], ctg_range=case["ctg_range"], bed=bed)
+    assert col.anomalies == 0 and len(got) > 10
+    assert np.array_equal(got, case["expected_positions"])
+
+
+# ---- ... and against the sequential host code on fresh alignments -------------------------------------------------------------------
+SYNTH = [
+    (101, dict(n_reads=160, ref_len=1800), dict()),
+    (103, dict(n_reads=160, ref_len=1800, cand_step=(1, 12)), dict()),
+    (5, dict(n_reads=300, ref_len=3000, dup_burst=6), dict(dcov=2, min_coverage=3)),
+    (6, dict(n_reads=300, ref_len=3000), dict(min_mq=10)),
+    (8, dict(n_reads=250, ref_len=2500, ins_rate=0.12, del_rate=0.1, cand_step=(1, 6)), dict()),
+]
+
+
+@pytest.mark.parametrize("k", range(len(SYNTH)))
+def test_columns_equal_the_sequential_pileup(k):
+    seed, synth_kw, kw = SYNTH[k]
+    case = fc.synth(seed, **synth_kw)
+    hc, hs, hcounts = fc.host_windows(case, **kw)
+    col, _ = columns_of(case, dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
+    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0))
+    assert col.anomalies == 0 and len(hc) > 50
+    assert np.array_equal(hc, w["centres"]) and np.array_equal(hs, w["refseq"]) and np.array_equal(hcounts, w["counts"])
+    assert sum(int(t.sum()) for t in w["tuples"]) == int(w["totals"][w["opened"]].sum())
+
+
+def test_columns_with_a_region_take_the_alignments_samtools_would_print():
+    case = fc.synth(21, n_reads=300, ref_len=3000)
+    region = (700, 1900)
+    cands = case["candidates"][(case["candidates"] >= region[0]) & (case["candidates"] <= region[1])]
+    hc, hs, hcounts = fc.host_windows(case, candidates=cands, pile_region=region)
+    col, packed = columns_of(case, pile_region=region)
+    w = col.windows(cands)
+    assert np.array_equal(hc, w["centres"]) and np.array_equal(hcounts, w["counts"]) and len(hc) > 20
+    assert 0 < ((packed["flags"] & fe.F_PILE) != 0).sum() < len(packed["flags"])
+
+
+@pytest.mark.parametrize("seed", [201, 207])
+def test_columns_equal_the_sequential_candidate_search(seed):
+    case = fc.synth(seed, n_reads=400, ref_len=2500, ins_rate=0.06 if seed == 207 else 0.02)
+    kw = dict(ctg_start=200, ctg_end=2300, bed=[(0, 1000), (900, 1200), (1800, 1800), (2000, 2600)], min_coverage=3, threshold=0.1, min_mq=5)
+    want = fc.host_candidates(case, **kw)
+    col, _ = columns_of(case, evc_min_mq=5)
+    got = col.candidates(min_depth=3, min_af=0.1, ctg_range=(200, 2300), bed=(np.array([0, 1800, 2000], np.int64), np.array([1200, 1801, 2600], np.int64)))
+    assert np.array_equal(want, got) and len(want) > 30
+
+
+def test_budget_replay_is_safe():
+    """Whenever the replay says the budget does not bind, the sequential code run WITH that budget gives the unbounded result; and
+    it does say "binds" for budgets that change the result."""
+    case = fc.synth(31, n_reads=200, ref_len=1500, cand_step=(1, 4))
+    col, _ = columns_of(case)
+    w = col.windows(case["candidates"])
+    free = fc.host_windows(case)
+    need = None
+    for slots in (200, 1000, 3000, 6000, 10000, 20000, 40000, 80000):
+        binds = fe.budget_binds(col.slabs, w["tuples"], case["candidates"], np.where(w["opened"], w["totals"], 0), slots)
+        got = fc.host_windows(case, available_slots=slots)
+        same = all(np.array_equal(a, b) for a, b in zip(free, got))
+        assert binds or same, slots
+        if not binds and need is None:
+            need = slots
+    assert need is not None and need > 1000                # the small budgets were reported, the large ones passed
+    assert not all(np.array_equal(a, b) for a, b in zip(free, fc.host_windows(case, available_slots=200)))
+    # the C replay (libclair_host.so) says the same as the Python one, slab by slab
+    for slots in (3000, need, 80000):
+        reads = np.zeros(len(col.slabs[0]["pos0"]), dtype=_hostapi.READ_DTYPE)
+        reads["pos0"], reads["flags"] = col.slabs[0]["pos0"], col.slabs[0]["flags"]
+        state = np.array([slots, 0], np.int64)
+        got = _hostapi.tuple_budget_binds(reads, w["tuples"][0].astype(np.uint64), case["candidates"], np.where(w["opened"], w["totals"], 0).astype(np.uint64), state)
+        assert got == fe.budget_binds(col.slabs, w["tuples"], case["candidates"], np.where(w["opened"], w["totals"], 0), slots)
+
+
+def test_columns_flag_bases_the_reference_would_trip_over():
+    case = fc.synth(3, n_reads=60, ref_len=900)
+    sam = case["sam"].decode().splitlines()
+    col7 = sam[5].split("\t")
+    col7[9] = col7[9][:10] + "*" + col7[9][11:]
+    bad = dict(case, sam=("\n".join(sam[:5] + ["\t".join(col7)] + sam[6:]) + "\n").encode())
+    col, _ = columns_of(bad)
+    assert col.anomalies & fe.A_BAD_BASE
+    short = sam[7].split("\t")
+    short[9] = short[9][:5]
+    col, _ = columns_of(dict(case, sam=("\n".join(sam[:7] + ["\t".join(short)] + sam[8:]) + "\n").encode()))
+    assert col.anomalies & fe.A_SEQ_OVERRUN
+    col, _ = columns_of(dict(case, ref=case["ref"][:300] + "-" + case["ref"][301:]))
+    assert col.anomalies & fe.A_BAD_REF

@@ -1,0 +1,183 @@
+"""Device front end on the GPU (clair_amd/csrc/frontend.hip through the C ABI): candidates and pileup windows bit for bit against the
+reference-minted golden records, the sequential host code and the NumPy restatement (oracle/frontend_np.py), the tuple counts the
+budget replay needs, the CLAIR_FE_* reports, and the hand-off of the windows to the engine without leaving HBM."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import frontend_cases as fc  # noqa: E402
+
+from clair_amd import _capi, _hostapi  # noqa: E402
+from oracle import frontend_np as fe  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def device_frontend(case, slabs=1, margin=64, **pack_kw):
+    """Pack the case's alignments (in `slabs` pieces) and put them on the device."""
+    f = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - margin, case["ref0"] + len(case["ref"]) + margin)
+    p = _hostapi.SamPacker(case["ctg"], **pack_kw)
+    sam, at = case["sam"], 0
+    for k in range(slabs):
+        cut = len(sam) if k == slabs - 1 else sam.index(b"\n", len(sam) * (k + 1) // slabs) + 1
+        assert p.feed(sam[at:cut], final=(k == slabs - 1)) == b""
+        at = cut
+        f.add_slab(p)
+    f.host_anomalies = p.stats()["anomalies"]
+    return f
+
+
+def windows_of(f):
+    n = f.stats()["windows"]
+    centres, seqs = f.window_info(0, n)
+    return centres, seqs, f.window_counts(0, n).astype(np.int32)
+
+
+@pytest.mark.parametrize("path", [p for p in fc.CT_GOLDEN if "noleft" not in p and "unsorted" not in p],
+                         ids=lambda p: os.path.basename(p)[10:-8])
+def test_windows_reproduce_reference_tensor_records(path):
+    case = fc.ct_golden_case(path)
+    f = device_frontend(case, slabs=3, dcov=case["dcov"], pile_min_mq=case["min_mq"], pile_region=case["pile_region"])
+    assert f.set_candidates(case["candidates"]) == len(case["candidates"])
+    n = f.build_windows(min_coverage=case["min_coverage"], drop_non_iupac_centre=False)
+    assert f.stats()["anomalies"] == 0 and f.host_anomalies == 0 and not f.budget_binds()
+    centres, seqs, counts = windows_of(f)
+    assert n == len(centres) > 20
+    assert fc.text_of(case["ctg"], centres, seqs, counts) == case["expected"]
+
+
+@pytest.mark.parametrize("path", fc.EVC_GOLDEN, ids=lambda p: os.path.basename(p)[11:-8])
+def test_candidates_reproduce_reference_rows(path):
+    case = fc.evc_golden_case(path)
+    f = device_frontend(case, slabs=2, evc_min_mq=case["min_mq"])
+    rng = case["ctg_range"] or (None, None)
+    n = f.find_candidates(min_coverage=case["min_coverage"], threshold=case["threshold"], ctg_start=rng[0], ctg_end=rng[1], bed=case["bed"])
+    assert f.stats()["anomalies"] == 0
+    got = f.candidates()
+    assert n == len(got) and np.array_equal(got, case["expected_positions"])
+
+
+SYNTH = [
+    (101, dict(n_reads=160, ref_len=1800), dict(), 1),
+    (103, dict(n_reads=160, ref_len=1800, cand_step=(1, 12)), dict(), 2),
+    (5, dict(n_reads=300, ref_len=3000, dup_burst=6), dict(dcov=2, min_coverage=3), 3),
+    (6, dict(n_reads=300, ref_len=3000), dict(min_mq=10), 1),
+    (8, dict(n_reads=250, ref_len=2500, ins_rate=0.12, del_rate=0.1, cand_step=(1, 6)), dict(), 4),
+    (9, dict(n_reads=2500, ref_len=30000, read_len=(200, 3000), cand_step=(1, 30)), dict(), 5),
+]
+
+
+@pytest.mark.parametrize("k", range(len(SYNTH)))
+def test_windows_equal_the_sequential_pileup_and_the_restatement(k):
+    seed, synth_kw, kw, slabs = SYNTH[k]
+    case = fc.synth(seed, **synth_kw)
+    hc, hs, hcounts = fc.host_windows(case, **kw)
+    f = device_frontend(case, slabs=slabs, dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
+    f.set_candidates(case["candidates"])
+    f.build_windows(min_coverage=kw.get("min_coverage", 0), drop_non_iupac_centre=False)
+    assert f.stats()["anomalies"] == 0 and not f.budget_binds()
+    centres, seqs, counts = windows_of(f)
+    assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts) and len(hc) > 50
+    # the tuple counts behind the budget replay, against the NumPy restatement: per alignment and per window
+    packed = fe.pack_sam(case["sam"], case["ctg"], dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
+    col = fe.Columns(case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+    col.add_reads(packed)
+    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0))
+    got = np.concatenate([f.read_tuples(s) for s in range(f.stats()["slabs"])])
+    assert np.array_equal(got.astype(np.int64), w["tuples"][0])
+    cc, wt = f.window_tuples()
+    assert np.array_equal(cc, case["candidates"]) and np.array_equal(wt.astype(np.int64), np.where(w["opened"], w["totals"], 0))
+    assert int(got.sum()) == int(wt.sum()) > 0
+
+
+def test_candidates_then_windows_equal_the_two_sequential_stages():
+    """The whole front end: one packed stream, candidate search on the tallies, windows at those candidates -- against the finder and the
+    builder run one after the other on the text, with a region (the two stages then see different alignments) and a bed file."""
+    case = fc.synth(77, n_reads=1500, ref_len=12000, read_len=(100, 1500), ins_rate=0.03, del_rate=0.03)
+    region = (2000, 9000)
+    bed = [(0, 5000), (4800, 5200), (6000, 6000), (7000, 11000)]
+    want_pos = fc.host_candidates(case, ctg_start=region[0], ctg_end=region[1], bed=bed, min_coverage=4, threshold=0.125)
+    hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region)
+    keep = fe.PILE_ROW[hs[:, 16]] != 255
+    f = device_frontend(case, slabs=3, pile_region=region)
+    n = f.find_candidates(min_coverage=4, threshold=0.125, ctg_start=region[0], ctg_end=region[1], bed=bed)
+    assert n == len(want_pos) > 100 and np.array_equal(f.candidates(), want_pos)
+    f.build_windows(min_coverage=0, drop_non_iupac_centre=True)
+    assert f.stats()["anomalies"] == 0 and not f.budget_binds()
+    centres, seqs, counts = windows_of(f)
+    assert np.array_equal(hc[keep], centres) and np.array_equal(hs[keep], seqs) and np.array_equal(hcounts[keep], counts)
+
+
+def test_budget_that_binds_is_reported():
+    case = fc.synth(31, n_reads=200, ref_len=1500, cand_step=(1, 4))
+    f = device_frontend(case, slabs=2)
+    f.set_candidates(case["candidates"])
+    f.build_windows(drop_non_iupac_centre=False)
+    assert not f.budget_binds() and f.budget_binds(available_slots=3000)
+    free = fc.host_windows(case)
+    assert not all(np.array_equal(a, b) for a, b in zip(free, fc.host_windows(case, available_slots=3000)))
+
+
+def test_reports_of_what_leaves_the_regime():
+    case = fc.synth(3, n_reads=60, ref_len=900)
+    sam = case["sam"].decode().splitlines()
+    col = sam[5].split("\t")
+    col[9] = col[9][:10] + "*" + col[9][11:]
+    f = device_frontend(dict(case, sam=("\n".join(sam[:5] + ["\t".join(col)] + sam[6:]) + "\n").encode()))
+    assert f.stats()["anomalies"] & fe.A_BAD_BASE
+    short = sam[7].split("\t")
+    short[9] = short[9][:5]
+    f = device_frontend(dict(case, sam=("\n".join(sam[:7] + ["\t".join(short)] + sam[8:]) + "\n").encode()))
+    assert f.stats()["anomalies"] & fe.A_SEQ_OVERRUN
+    f = device_frontend(dict(case, ref=case["ref"][:300] + "-" + case["ref"][301:]))
+    assert f.stats()["anomalies"] & fe.A_BAD_REF
+    f = device_frontend(case)
+    f.set_candidates(case["candidates"][::-1].copy())
+    assert f.stats()["anomalies"] & fe.A_CANDIDATES
+    # depth beyond int16: 40 000 identical alignments (dcov lifted)
+    one = b"r\t0\tchrS\t100\t60\t40M\t*\t0\t0\t" + case["ref"][99:139].encode() + b"\t" + b"I" * 40 + b"\n"
+    f = device_frontend(dict(case, sam=one * 40000), dcov=100000)
+    f.set_candidates(np.array([120], np.int64))
+    f.build_windows(drop_non_iupac_centre=False)
+    assert f.stats()["anomalies"] & fe.A_OVERFLOW
+
+
+def test_error_paths():
+    with pytest.raises(_capi.EngineError, match="empty span"):
+        _capi.Frontend(0, "ACGT", 0, 10, 10)
+    f = _capi.Frontend(0, "ACGT" * 100, 0, -64, 464)
+    with pytest.raises(_capi.EngineError, match="no candidates yet"):
+        f.build_windows()
+    with pytest.raises(_capi.EngineError, match="no windows yet"):
+        f.window_info(0, 1)
+    assert f.set_candidates(np.zeros(0, np.int64)) == 0 and f.build_windows() == 0
+    assert f.window_info(0, 0)[0].shape == (0,)
+    with pytest.raises(_capi.EngineError, match="out of range"):
+        f.window_info(0, 1)
+
+
+def test_windows_go_to_the_engine_without_leaving_the_device():
+    """clair_submit_ex on the device address of the windows = clair_submit_ex on a host copy of them: call records bit for bit."""
+    from clair_amd import weights
+    case = fc.synth(55, n_reads=1200, ref_len=9000, read_len=(100, 1200))
+    f = device_frontend(case, slabs=2)
+    f.find_candidates(min_coverage=4, threshold=0.125)
+    n = f.build_windows(drop_non_iupac_centre=True)
+    assert n > 300
+    centres, seqs = f.window_info(0, n)
+    centre = np.stack([seqs[:, 16], (seqs[:, :33] != 0).sum(axis=1).astype(np.uint8)], axis=1)
+    e = _capi.Engine(0, 256, 2)
+    e.load_weights(weights.synthetic_weights(seed=12))
+    for first in (0, 256, n - 77):
+        m = min(256, n - first)
+        e.submit_calls(0, _capi.DeviceWindows(f, first, m), centre[first:first + m])
+        on_device = e.wait(0)
+        e.submit_calls(1, f.window_counts(first, m), centre[first:first + m], counts=True)
+        from_host = e.wait(1)
+        assert on_device.tobytes() == from_host.tobytes() and (on_device["status"] != 0).any()
+    e.close()

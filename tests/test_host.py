@@ -21,7 +21,7 @@ def test_host_header_symbols_are_exported():
     assert declared and sorted(_hostapi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.clair_host_abi_version() == 5
+    assert lib.clair_host_abi_version() == 6
 
 
 def _collect(gen, path, batch):

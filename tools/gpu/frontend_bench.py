@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""The device front end against the sequential host stages on the same alignments (run on the GPU box):
+
+    python tools/gpu/frontend_bench.py [n_reads] [ref_len]
+
+Synthetic contig at ~50x with 2-9 kb reads (tests/pileup_synth.py, the inputs of tools/e2e_bam_bench.py).  Prints the time of every
+step of both paths -- host: candidate search (clair_host_evc_*), pileup (clair_host_pileup_*); device: packing (clair_host_sampack_*),
+copy + tally (clair_frontend_add_reads), candidate filter, second pass + assembly -- checks that the two produce the same candidates and
+the same windows bit for bit, and prints the per-kernel rates.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import frontend_cases as fc  # noqa: E402
+from clair_amd import _capi, _hostapi  # noqa: E402
+
+
+def main():
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    ref_len = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+    t0 = time.time()
+    case = fc.synth(5, ref_len=ref_len, n_reads=n_reads, read_len=(2000, 9000), cand_step=(5, 40), iupac=False, second_ctg=False)
+    sam = case["sam"]
+    print("inputs: %.1f MB of SAM text, %d alignments over %d bases (%.0f s to generate)" % (len(sam) / 1e6, sam.count(b"\n"), ref_len, time.time() - t0))
+
+    # ---- sequential host stages (one thread each, as callVarBam runs them) ----
+    t0 = time.time()
+    finder = _hostapi.CandidateFinder(case["ctg"], case["ref"], case["ref0"], min_coverage=4, threshold=0.125)
+    finder.feed(sam)
+    finder.finish()
+    want_pos = finder.take_positions()
+    t_evc = time.time() - t0
+    t0 = time.time()
+    b = _hostapi.PileupBuilder(case["ctg"], case["ref"], case["ref0"], want_pos)
+    b.feed(sam)
+    b.finish()
+    hc, hs, hcounts = b.take_columns()
+    t_pile = time.time() - t0
+    slots_left = b.stats()["slots_left"] if "slots_left" in b.stats() else None
+    print("host  : candidate search %.3f s (%.0f MB/s), pileup %.3f s (%.0f windows/s)  -> %d candidates, %d windows%s"
+          % (t_evc, len(sam) / 1e6 / t_evc, t_pile, len(hc) / t_pile, len(want_pos), len(hc), "" if slots_left is None else ", %d slots left" % slots_left))
+
+    # ---- device front end ----
+    _capi.Frontend(0, "ACGT" * 64, 0, -64, 320).close()          # context creation is not the front end's time
+    for rep in range(2):
+        t0 = time.time()
+        f = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+        t_create = time.time() - t0
+        p = _hostapi.SamPacker(case["ctg"])
+        t_pack = t_add = 0.0
+        step = 64 << 20
+        for at in range(0, len(sam), step):
+            t0 = time.time()
+            tail = p.feed(sam[at:at + step], final=at + step >= len(sam))
+            assert tail == b"" or at + step < len(sam)
+            t_pack += time.time() - t0
+            if tail:
+                raise SystemExit("bench feeds whole lines only")
+            t0 = time.time()
+            f.add_slab(p)
+            t_add += time.time() - t0
+        st = f.stats()
+        t0 = time.time()
+        n_cand = f.find_candidates(min_coverage=4, threshold=0.125)
+        t_cand = time.time() - t0
+        t0 = time.time()
+        n_win = f.build_windows(min_coverage=0, drop_non_iupac_centre=False)
+        t_win = time.time() - t0
+        t0 = time.time()
+        binds = f.budget_binds()
+        t_budget = time.time() - t0
+        total = t_pack + t_add + t_cand + t_win + t_budget
+        print("device: tables %.3f s | pack %.3f s (%.0f MB/s) | copy + tally %.3f s | candidates %.3f s | windows %.3f s | budget replay %.3f s  = %.3f s"
+              " -> %d candidates, %d windows, %d elements, anomalies %d, budget binds: %s"
+              % (t_create, t_pack, len(sam) / 1e6 / t_pack, t_add, t_cand, t_win, t_budget, total, n_cand, n_win, st["elements"], f.stats()["anomalies"], binds))
+        if rep == 0:
+            got_pos = f.candidates()
+            centres, seqs = f.window_info(0, n_win)
+            counts = f.window_counts(0, n_win)
+            same = (np.array_equal(got_pos, want_pos) and np.array_equal(centres, hc) and np.array_equal(seqs, hs) and np.array_equal(counts.astype(np.int32), hcounts))
+            print("device == host: %s (candidates, centres, reference windows, %d counts)" % (same, counts.size))
+            if not same and not binds:
+                return 1
+        f.close()
+    print("speed-up of the two stages: %.1fx (host %.3f s, device %.3f s with packing)" % ((t_evc + t_pile) / total, t_evc + t_pile, total))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
