@@ -13,6 +13,16 @@ arrays:
 The VCF is the one `extract_variant_candidates | create_tensor | call_var` produce through their text interfaces
 (tests/test_pileup.py pins that), which in turn are pinned against the reference scripts.  Like the reference, alignments
 are read twice (`samtools view` once per stage): the pileup needs the candidates ahead of the reads.
+
+--front_end device (the default where it applies) moves both stages to the GPU (include/clair_amd.h: clair_frontend_*):
+
+    samtools view  -> clair_host_sampack_* (ONE pass over the text) -> packed alignments, resident in HBM
+                   -> per-position tables -> candidate filter -> windows int16 [n,33,8,4] that never leave the device
+                   -> HIP forward pass + decode kernel -> call records -> VCF rows
+
+Same candidates, same windows, same VCF (tests/test_frontend_gpu.py, tests/test_e2e_gpu.py); where the input leaves the regime
+that formulation reproduces exactly (CLAIR_FE_* in include/clair_reads.h, a tuple budget that binds) the run falls back to the
+host stages above and says so.
 """
 import logging
 import os
@@ -185,6 +195,154 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
         sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
 
 
+SLAB_BYTES = 64 << 20      # SEQ bytes per slab of packed alignments sent to the device
+TABLE_MARGIN = 64          # positions the device tables extend beyond the region (a window reaches 17 beyond its centre)
+FE_REASONS = ((1, "alignments not sorted by position"), (2, "a zero-length insertion/deletion"), (4, "an alignment spanning > 100 kb more than its bases"),
+              (8, "a CIGAR longer than its SEQ"), (16, "a read base outside the IUPAC alphabet"), (32, "a reference base outside the IUPAC alphabet"),
+              (64, "a count beyond int16"), (128, "the reference's budget of 5 M outstanding tuples would run out"), (256, "candidate sites not strictly ascending"))
+
+
+class DeviceFrontEnd(object):
+    """Both pileup stages on the GPU for one contig / region.  run() -> number of windows, or None when the run has to take the host
+    path (reason logged); batches() then yields what tensor_batches yields, with the counts as clair_amd._capi.DeviceWindows."""
+
+    def __init__(self, args, device):
+        self.args, self.device = args, device
+        self.frontend = None
+        self.n_windows = 0
+
+    def close(self):
+        if self.frontend is not None:
+            self.frontend.close()
+            self.frontend = None
+
+    def _fallback(self, why):
+        """The input is outside the regime the device formulation reproduces bit for bit (never: the device or the library is missing --
+        that is an error).  --front_end device makes it an error too."""
+        self.close()
+        if self.args.front_end == "device":
+            sys.exit("[ERROR] --front_end device: %s; the sequential host stages (--front_end host) reproduce the reference there" % why)
+        logging.info("device front end not used (%s): running the candidate search and the pileup on the host" % why)
+        return None
+
+    def run(self):
+        from . import _capi, _hostapi
+        args = self.args
+        if args.stop_consider_left_edge:
+            return self._fallback("--stop_consider_left_edge")
+        have_range = args.ctgStart is not None and args.ctgEnd is not None
+        given = None
+        if args.vcf_fn is not None:
+            given = positions_from_vcf(args.vcf_fn, args.ctgName, args.ctgStart, args.ctgEnd)
+            if have_range:
+                given = given[(given >= args.ctgStart) & (given <= args.ctgEnd)]
+            if len(given) > 1 and not (np.diff(given) > 0).all():
+                return self._fallback(FE_REASONS[8][1])
+        elif not os.path.isfile("%s.fai" % args.ref_fn):
+            sys.exit("Fasta index %s.fai doesn't exist." % args.ref_fn)
+        # one reference slice serves both stages: they load the same region (ExtractVariantCandidates.py:228-236, CreateTensor.py:113-156)
+        seq, ref_start = ct.reference_sequence_from(args.samtools, args.ref_fn, args.ctgName, args.ctgStart, args.ctgEnd)
+        if not seq:
+            sys.exit("Failed to load reference seqeunce. Please check if the provided reference fasta %s and the ctgName %s are correct."
+                     % (args.ref_fn, args.ctgName))
+        ref0 = 0 if ref_start is None else ref_start - 1
+        bed = None
+        if given is None:
+            tree = evc.bed_regions_from(args.bed_fn)
+            if tree is not None and args.ctgName not in tree:
+                sys.exit("[ERROR] ctg_name(%s) not exists in bed file(%s)." % (args.ctgName, args.bed_fn))
+            bed = None if tree is None else tree[args.ctgName]
+        if have_range:
+            lo, hi = args.ctgStart - 1 - TABLE_MARGIN, args.ctgEnd + TABLE_MARGIN
+            # the candidate search reads the widened region, the pileup the plain one (callVarBam.py:124-199); an alignment can only
+            # matter to a position of [ctgStart, ctgEnd] if it reaches within one base of it -- the packer marks which of the two
+            # stages would have been given it
+            region = "%s:%d-%d" % (args.ctgName, max(1, args.ctgStart - 2), args.ctgEnd + 2)
+        else:
+            lo, hi = ref0 - TABLE_MARGIN, ref0 + len(seq) + TABLE_MARGIN
+            region = args.ctgName
+        try:
+            f = self.frontend = _capi.Frontend(self.device, seq, ref0, lo, hi)
+        except _capi.EngineError as exc:
+            sys.exit("[ERROR] %s" % exc)
+        packer = _hostapi.SamPacker(args.ctgName, dcov=args.dcov, evc_min_mq=0, pile_min_mq=0,
+                                    pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
+        view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+                                   text=False)
+        from time import time
+        t_start, t_pack, t_dev = time(), 0.0, 0.0
+        tail = None
+        while True:
+            chunk = view.stdout.read(1 << 23)
+            if not chunk:
+                break
+            t0 = time()
+            tail = packer.feed(chunk if tail is None else tail + chunk)
+            t_pack += time() - t0
+            if packer.stats()["seq_bytes"] >= SLAB_BYTES:
+                t0 = time()
+                f.add_slab(packer)
+                t_dev += time() - t0
+        t0 = time()
+        if tail:
+            packer.feed(tail, final=True)
+        t_pack += time() - t0
+        t0 = time()
+        f.add_slab(packer)
+        view.stdout.close()
+        view.wait()
+        if view.returncode != 0:
+            sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
+        pst = packer.stats()
+        if given is None:
+            if pst["evc_reads"] == 0:
+                print("No read has been process, either the genome region you specified has no read cover, or please check the correctness of your BAM input (%s)."
+                      % args.bam_fn, file=sys.stderr)
+            n_cand = f.find_candidates(min_coverage=int(args.minCoverage), threshold=args.threshold,     # callVarBam.py:75: int() before it reaches the extractor
+                                       ctg_start=args.ctgStart if have_range else None, ctg_end=args.ctgEnd if have_range else None, bed=bed)
+        else:
+            f.set_candidates(given)
+            n_cand = len(given)
+        n = f.build_windows(min_coverage=0, drop_non_iupac_centre=True)
+        bits = pst["anomalies"] | f.stats()["anomalies"]
+        if not bits and f.budget_binds():
+            bits = 128
+        if bits:
+            return self._fallback("; ".join(why for bit, why in FE_REASONS if bits & bit))
+        t_dev += time() - t0
+        logging.info("%d candidate sites" % n_cand)
+        logging.info("device front end: %d alignments, %d windows in %.2f s (packing the text %.2f s, device %.2f s, the rest waiting for `samtools view`)"
+                     % (f.stats()["reads"], n, time() - t_start, t_pack, t_dev))
+        self.n_windows = n
+        return n
+
+    def batches(self, batch_size, lean=True, progress=True):
+        """(X float32 or None, infos, counts) per batch.  lean: nobody on the host reads the tensor (decode on the device, no BAM open):
+        the counts stay in HBM (DeviceWindows) and X is None; otherwise both come back to the host, as from tensor_batches."""
+        from . import _capi, _hostapi
+        from .tensor_binary import MAX_CTG, InfoTable
+        f, ctg = self.frontend, self.args.ctgName.encode()
+        use_table = len(ctg) <= MAX_CTG
+        total = 0
+        for first in range(0, self.n_windows, batch_size):
+            n = min(batch_size, self.n_windows - first)
+            centres, seqs = f.window_info(first, n)
+            total += n
+            if progress:
+                print("Processed %d tensors" % total, file=sys.stderr)
+            if use_table:
+                infos = InfoTable(np.full(n, ctg, dtype="S%d" % MAX_CTG), np.full(n, len(ctg), dtype=np.uint8), centres,
+                                  np.ascontiguousarray(seqs[:, :33]).view("S33").ravel(), (seqs[:, :33] != 0).sum(axis=1).astype(np.uint8))
+            else:
+                raw = seqs.tobytes()
+                infos = [[self.args.ctgName, str(c), raw[i * 34:i * 34 + 34].split(b"\0", 1)[0].decode("latin-1")] for i, c in enumerate(centres.tolist())]
+            if lean:
+                yield None, infos, _capi.DeviceWindows(f, first, n)
+            else:
+                counts = f.window_counts(first, n)
+                yield _hostapi.counts_to_input(counts.astype(np.int32)), infos, counts
+
+
 WINDOW_FLANK = 33          # reads that touch only the flank of a sub-range's outermost windows (16 positions) must still be seen
 MIN_SPAN_PER_WORKER = 50000
 
@@ -300,17 +458,6 @@ def Run(args):
     logging.basicConfig(format="%(message)s", level=logging.INFO)
     cv.ingest.setup_environment()
 
-    workers, lo, hi = front_end_workers(args)
-    if workers > 1:
-        def source(batch):
-            return parallel_front_end(args, batch, workers, lo, hi)
-    else:
-        positions = candidate_positions(args)
-        logging.info("%d candidate sites" % len(positions))
-
-        def source(batch):
-            return tensor_batches(args, positions, batch)
-
     config = cv.OutputConfig(
         is_show_reference=False, is_debug=args.debug,
         is_haploid_precision_mode_enabled=args.haploid_precision,
@@ -330,9 +477,30 @@ def Run(args):
             m.restore_parameters(os.path.abspath(args.chkpnt_fn))
         except Exception as exc:
             sys.exit("[ERROR] %s" % exc)
+        device_fe = None
         try:
+            source = None
+            workers, lo, hi = front_end_workers(args)
+            if args.front_end != "host" and workers == 1:
+                # nobody on the host reads the tensors when the decode runs on the device and no BAM is consulted (cv.call_variants)
+                lean = decoder.native_applies() and lookup.sam is None and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0"
+                device_fe = DeviceFrontEnd(args, args.device)
+                if device_fe.run() is not None:
+                    def source(batch):
+                        return device_fe.batches(batch, lean=lean)
+            if source is None and workers > 1:
+                def source(batch):
+                    return parallel_front_end(args, batch, workers, lo, hi)
+            elif source is None:
+                positions = candidate_positions(args)
+                logging.info("%d candidate sites" % len(positions))
+
+                def source(batch):
+                    return tensor_batches(args, positions, batch)
             cv.call_variants(args, m, decoder, writer, batch, generator=source(batch))
         finally:
+            if device_fe is not None:
+                device_fe.close()
             m.close()
     finally:
         writer.close()
@@ -380,6 +548,10 @@ def build_parser():
              "0 = half the usable CPUs, at most 8; at least 50 kb per sub-range).  Default 1: the single pass.  The split run yields the single "
              "pass's candidates and windows EXCEPT where CreateTensor's 5 M-tuple budget runs out (candidates every few bases at high depth): every "
              "sub-range has its own budget, as every chunk of callVarBamParallel has")
+    add('--front_end', type=str, default="auto", choices=("auto", "device", "host"),
+        help="where the candidate search and the pileup run: on the GPU (one pass over the alignments; auto = device, falling back to the host "
+             "stages, with a message, where the device formulation does not reproduce the reference exactly) or on the host (two passes, the "
+             "sequential code).  --front_end_workers > 1 implies host")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
     add('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
         help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")

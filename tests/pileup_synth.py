@@ -16,7 +16,7 @@ def _mutate(rng, base):
 
 
 def synth_case(seed, ref_len=3000, n_reads=300, read_len=(40, 300), ctg="chrS", cand_step=(3, 40),
-               sub_rate=0.04, ins_rate=0.02, del_rate=0.02, dup_burst=0, iupac=True, second_ctg=True):
+               sub_rate=0.04, ins_rate=0.02, del_rate=0.02, dup_burst=0, iupac=True, second_ctg=True, skip_ops=True):
     rng = np.random.default_rng(seed)
     ref = "".join(BASES[i] for i in rng.integers(0, 4, ref_len))
     ref = list(ref)
@@ -56,7 +56,9 @@ def synth_case(seed, ref_len=3000, n_reads=300, read_len=(40, 300), ctg="chrS", 
                 n = int(rng.integers(1, 5)) if rng.random() < 0.9 else int(rng.integers(5, 40))
                 n = min(n, ref_len - rp - 1)
                 if n > 0:
-                    ops.append((n, "D" if rng.random() < 0.95 else "N"))
+                    # N moves neither cursor in the reference's loops: everything after it is walked n bases early (what real spliced
+                    # alignments would get too); skip_ops=False keeps the reads aligned end to end
+                    ops.append((n, "D" if rng.random() < 0.95 or not skip_ops else "N"))
                     rp += n
             else:
                 rb = ref[rp].upper()

@@ -40,16 +40,20 @@ def _rows(path):
     return [ln for ln in open(path).read().splitlines() if not ln.startswith("#")]
 
 
+@pytest.mark.parametrize("front_end", ["device", "host"])
 @pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
-def test_callVarBam_vcf_equals_the_three_stage_text_pipeline(tmp_path, region):
-    """clair_amd.callVarBam (one process, arrays handed between the stages, int16 counts to the GPU) writes byte for byte the VCF of
+def test_callVarBam_vcf_equals_the_three_stage_text_pipeline(tmp_path, region, front_end):
+    """clair_amd.callVarBam (one process; --front_end device: candidate search and pileup on the GPU, windows never leave HBM;
+    --front_end host: arrays handed between the host stages, int16 counts to the GPU) writes byte for byte the VCF of
     extract_variant_candidates | create_tensor | call_var over their text interfaces (clair/callVarBam.py:185-201)."""
     tmp = str(tmp_path)
     case, fa, sam = _bam_case(tmp)
     ck = _model(tmp)
     common = ["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS] + region
     one = os.path.join(tmp, "one.vcf")
-    _run(["clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", one, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64"] + common)
+    r = _run(["clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", one, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64",
+              "--front_end", front_end] + common)
+    assert "device front end not used" not in r.stderr and "candidate sites" in r.stderr
     r1 = _run(["clair_amd.extract_variant_candidates", "--threshold", "0.15", "--minCoverage", "5"] + common)
     tensors = os.path.join(tmp, "t.gz")
     _run(["clair_amd.create_tensor", "--tensor_fn", tensors] + common, input=r1.stdout)
@@ -75,10 +79,12 @@ def test_binary_tensor_records_give_the_same_vcf_as_text_records(tmp_path):
     assert open(outs["text"]).read() == open(outs["binary"]).read()
 
 
-def test_failing_upstream_stage_fails_the_run(tmp_path):
+@pytest.mark.parametrize("front_end", ["device", "host"])
+def test_failing_upstream_stage_fails_the_run(tmp_path, front_end):
     """A `samtools view` that dies in the middle of the pileup stage must fail callVarBam (the reference checks its stages' exit
     codes, clair/callVarBam.py:218-233) instead of ending the VCF early with status 0."""
     tmp = str(tmp_path)
+    first_bad = 0 if front_end == "device" else 1
     case, fa, sam = _bam_case(tmp)
     ck = _model(tmp)
     flaky = os.path.join(tmp, "flaky_samtools.py")
@@ -88,16 +94,17 @@ def test_failing_upstream_stage_fails_the_run(tmp_path):
         "if sys.argv[1] == 'view':\n"
         "    n = int(open(%r).read()) if os.path.exists(%r) else 0\n"
         "    open(%r, 'w').write(str(n + 1))\n"
-        "    if n >= 1:\n"                                   # the first view feeds the candidate finder, the second the pileup
+        "    if n >= %d:\n"                                  # host: the first view feeds the candidate finder, the second the pileup; device: there is one
         "        out = subprocess.run([sys.executable, %r] + sys.argv[1:], capture_output=True).stdout\n"
         "        sys.stdout.buffer.write(out[:len(out) // 2]); sys.stdout.flush(); sys.exit(3)\n"
         "sys.exit(subprocess.run([sys.executable, %r] + sys.argv[1:]).returncode)\n"
-        % (marker, marker, marker, os.path.join(HERE, "fake_samtools.py"), os.path.join(HERE, "fake_samtools.py")))
+        % (marker, marker, marker, first_bad, os.path.join(HERE, "fake_samtools.py"), os.path.join(HERE, "fake_samtools.py")))
     out = os.path.join(tmp, "o.vcf")
     r = subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--call_fn", out, "--bam_fn", sam, "--ref_fn", fa,
-                        "--ctgName", case["ctg"], "--samtools", "%s %s" % (sys.executable, flaky), "--batch_size", "64"],
+                        "--ctgName", case["ctg"], "--samtools", "%s %s" % (sys.executable, flaky), "--batch_size", "64", "--front_end", front_end],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0, "callVarBam returned 0 although samtools view failed: %s" % r.stderr[-500:]
+    assert "samtools view" in r.stderr
 
 
 def test_call_var_with_bam_lookups_through_fake_pysam(tmp_path):
@@ -175,3 +182,39 @@ def test_callVarBam_front_end_workers_write_the_single_pass_vcf(tmp_path, monkey
                              "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", FAKE_SAMTOOLS, "--front_end_workers", workers] + region)
             outs.append(open(out).read())
         assert len(outs[0].splitlines()) > 30 and outs[0] == outs[1]
+
+
+def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch, caplog):
+    """--vcf_fn sites, --bed_fn and a lifted --dcov through the device front end = the host stages' VCF; an input outside the device
+    formulation's regime (here: a tuple budget reported as binding) runs the host stages under `auto`, with a message, and is an
+    error under `device`."""
+    import gzip
+    import logging
+    from clair_amd import _capi, callVarBam
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp, seed=97, dup_burst=5)
+    ck = _model(tmp)
+    bed = os.path.join(tmp, "r.bed")
+    open(bed, "w").write("%s\t100\t1500\n%s\t1400\t2900\nchrOther\t1\t50\n" % (case["ctg"], case["ctg"]))
+    sites = os.path.join(tmp, "sites.vcf.gz")
+    with gzip.open(sites, "wt") as f:
+        for p in range(150, 2800, 37):
+            f.write("%s\t%d\t.\tA\tC\t.\t.\t.\n" % (case["ctg"], p))
+    base = ["--chkpnt_fn", ck, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"],
+            "--samtools", FAKE_SAMTOOLS]
+    for extra in (["--bed_fn", bed], ["--vcf_fn", sites], ["--dcov", "2", "--ctgStart", "200", "--ctgEnd", "2700"], ["--qual", "30"]):
+        outs = {}
+        for fe in ("device", "host"):
+            out = os.path.join(tmp, "%s.vcf" % fe)
+            callVarBam.main(base + ["--call_fn", out, "--front_end", fe] + extra)
+            outs[fe] = open(out).read()
+        assert outs["device"] == outs["host"] and len(outs["host"].splitlines()) > 30, extra
+    monkeypatch.setattr(_capi.Frontend, "budget_binds", lambda self, available_slots=5000000: True)
+    out = os.path.join(tmp, "fallback.vcf")
+    with caplog.at_level(logging.INFO):
+        callVarBam.main(base + ["--call_fn", out, "--front_end", "auto"])
+    assert "device front end not used (the reference's budget of 5 M outstanding tuples would run out)" in caplog.text
+    callVarBam.main(base + ["--call_fn", os.path.join(tmp, "h.vcf"), "--front_end", "host"])
+    assert open(out).read() == open(os.path.join(tmp, "h.vcf")).read()
+    with pytest.raises(SystemExit, match="--front_end device"):
+        callVarBam.main(base + ["--call_fn", out, "--front_end", "device"])

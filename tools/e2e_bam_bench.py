@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""End to end on one GPU: SAM text -> candidates -> pileup windows -> network -> VCF, one process (clair_amd.callVarBam).
+"""End to end on one GPU: SAM text -> candidates -> pileup windows -> network -> VCF, one process (clair_amd.callVarBam), with the
+candidate search and the pileup on the device (--front_end device) and on the host (--front_end host, 1 and 4 workers).
 
-    python tools/e2e_bam_bench.py [n_reads]
+    python tools/e2e_bam_bench.py [ref_len] [noisy_every] [depth]
 
-Synthetic 200 kb contig at ~50x with 2-9 kb reads (tests/pileup_synth.py; 4 % substitutions, so most covered positions pass the
-default 0.125 allele-frequency threshold: ~200 k candidates).  `samtools` is a shell stand-in that prints the SAM file
-(`view`) and a FASTA slice (`faidx`), so the time measured is this pipeline's, not BAM decompression.  Random-weights model.
+Synthetic contig at 50x with 2-9 kb reads (tools/fast_reads.py; one candidate site per ~2 x noisy_every bases).  `samtools` is a shell
+stand-in that prints the SAM file (`view`) and the contig (`faidx`), so the time measured is this pipeline's, not BAM decompression.
+Random-weights model.  The VCFs of the front ends are compared byte for byte.
 """
+import hashlib
 import os
 import stat
 import subprocess
@@ -16,35 +18,35 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import pileup_synth  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fast_reads  # noqa: E402
 from clair_amd import weights  # noqa: E402
 
 
 def main():
-    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+    noisy_every = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     tmp = tempfile.mkdtemp()
     t0 = time.time()
-    case = pileup_synth.synth_case(seed=5, ref_len=200000, n_reads=n_reads, read_len=(2000, 9000), cand_step=(5, 40), iupac=False,
-                                   second_ctg=False)
+    case = fast_reads.make(ref_len=ref_len, depth=depth, noisy_every=noisy_every, seed=5)
     fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
     open(fa, "w").write(case["fasta"])
     open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (case["ctg"], case["ref_len"]))
-    body = "".join(l + "\n" for l in case["sam"].splitlines() if not l.startswith("@") and not int(l.split("\t")[1]) & 2316)
-    open(sam, "w").write(body)
-    seq = "".join(case["fasta"].splitlines()[1:])
-    open(os.path.join(tmp, "seq.txt"), "w").write(">%s\n%s\n" % (case["ctg"], seq))
+    open(sam, "wb").write(case["sam"])
+    open(os.path.join(tmp, "seq.txt"), "w").write(">%s\n%s\n" % (case["ctg"], case["ref"]))
     fake = os.path.join(tmp, "samtools")
     open(fake, "w").write("#!/bin/sh\nif [ \"$1\" = view ]; then exec cat %s; fi\nexec cat %s\n" % (sam, os.path.join(tmp, "seq.txt")))
     os.chmod(fake, os.stat(fake).st_mode | stat.S_IEXEC)
     ck = weights.save_weights(os.path.join(tmp, "model"), weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1))[:-4]
-    print("inputs: %.1f MB SAM, %d reads (%.0f s to generate)" % (len(body) / 1e6, body.count("\n"), time.time() - t0))
-    out = os.path.join(tmp, "out.vcf")
-    for batch, workers in ((1024, 1), (4096, 1), (4096, 4)):
+    print("inputs: %.1f MB SAM, %d reads over %d bases at %dx (%.0f s to generate)" % (len(case["sam"]) / 1e6, case["n_reads"], ref_len, depth, time.time() - t0))
+    digests = {}
+    for front_end, batch, workers in (("device", 4096, 1), ("device", 4096, 1), ("host", 4096, 1), ("host", 4096, 4)):
+        out = os.path.join(tmp, "out_%s_%d.vcf" % (front_end, workers))
         t0 = time.time()
         r = subprocess.run([sys.executable, "-m", "clair_amd.callVarBam", "--chkpnt_fn", ck, "--bam_fn", sam, "--ref_fn", fa, "--ctgName",
-                            case["ctg"], "--samtools", fake, "--call_fn", out, "--batch_size", str(batch), "--front_end_workers", str(workers)],
-                           cwd=ROOT, capture_output=True, text=True)
+                            case["ctg"], "--samtools", fake, "--call_fn", out, "--batch_size", str(batch), "--front_end", front_end,
+                            "--front_end_workers", str(workers)], cwd=ROOT, capture_output=True, text=True)
         dt = time.time() - t0
         if r.returncode != 0:
             print(r.stderr[-2000:])
@@ -52,12 +54,15 @@ def main():
         tensors = [l for l in r.stderr.splitlines() if l.startswith("Processed")]
         n = int(tensors[-1].split()[1]) if tensors else 0
         rows = sum(1 for l in open(out) if not l.startswith("#"))
-        print("callVarBam, batch %d, %d front-end worker(s): %.2f s wall for %d candidate windows -> %d VCF rows: %.0f candidates/s end to end (one process, one GPU)"
-              % (batch, workers, dt, n, rows, n / dt))
+        digests[(front_end, workers)] = hashlib.sha256(open(out, "rb").read()).hexdigest()[:16]
+        print("callVarBam --front_end %s, batch %d, %d front-end worker(s): %.2f s wall for %d windows -> %d VCF rows: %.0f candidates/s, %.1f MB/s of SAM end to end"
+              % (front_end, batch, workers, dt, n, rows, n / dt, len(case["sam"]) / 1e6 / dt))
         for l in r.stderr.splitlines():
-            if "candidate sites" in l or "Total time" in l:
+            if "candidate sites" in l or "Total time" in l or "front end" in l:
                 print("   ", l)
-    return 0
+    same = len(set(digests.values())) == 1
+    print("VCFs byte-identical across the front ends: %s %s" % (same, sorted(set(digests.values()))))
+    return 0 if same else 1
 
 
 if __name__ == "__main__":

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """The device front end against the sequential host stages on the same alignments (run on the GPU box):
 
-    python tools/gpu/frontend_bench.py [n_reads] [ref_len]
+    python tools/gpu/frontend_bench.py [ref_len] [noisy_every] [depth]
 
-Synthetic contig at ~50x with 2-9 kb reads (tests/pileup_synth.py, the inputs of tools/e2e_bam_bench.py).  Prints the time of every
+Synthetic contig at 50x with 2-9 kb reads (tools/fast_reads.py, the inputs of tools/e2e_bam_bench.py; one candidate site per
+~2 x noisy_every bases).  Prints the time of every
 step of both paths -- host: candidate search (clair_host_evc_*), pileup (clair_host_pileup_*); device: packing (clair_host_sampack_*),
 copy + tally (clair_frontend_add_reads), candidate filter, second pass + assembly -- checks that the two produce the same candidates and
 the same windows bit for bit, and prints the per-kernel rates.
@@ -16,16 +17,18 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import frontend_cases as fc  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fast_reads  # noqa: E402
 from clair_amd import _capi, _hostapi  # noqa: E402
 
 
 def main():
-    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-    ref_len = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+    ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    noisy_every = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+    depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     t0 = time.time()
-    case = fc.synth(5, ref_len=ref_len, n_reads=n_reads, read_len=(2000, 9000), cand_step=(5, 40), iupac=False, second_ctg=False)
+    case = fast_reads.make(ref_len=ref_len, depth=depth, noisy_every=noisy_every, seed=5)
+    case["ref0"] = 0
     sam = case["sam"]
     print("inputs: %.1f MB of SAM text, %d alignments over %d bases (%.0f s to generate)" % (len(sam) / 1e6, sam.count(b"\n"), ref_len, time.time() - t0))
 
