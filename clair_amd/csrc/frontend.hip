@@ -295,7 +295,18 @@ __global__ __launch_bounds__(256) void fe_windows_per_base_kernel(Region g, Slab
             }
         }
     }
-    if (nc) atomicAdd((unsigned long long *)&s.tuples[read], (unsigned long long)nc);
+    // one atomic per run of equal reads in the wave (64 consecutive bases are nearly always one alignment's): 64 lanes adding to one
+    // address serialise at the memory side, which made this pass four times the first one
+    unsigned long long todo = __ballot(nc != 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t r = __shfl(read, leader, 64);
+        const bool mine = nc != 0 && read == r;
+        unsigned long long v = mine ? nc : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned long long *)&s.tuples[r], v);
+        todo &= ~__ballot(mine);
+    }
 }
 
 // ---- per candidate: was its window ever opened, how many tuples did it hold, does it survive -----------------------------------

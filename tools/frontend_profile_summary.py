@@ -7,6 +7,7 @@ trace and the FETCH_SIZE / WRITE_SIZE counter passes (each in its own run, never
 Counters per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): KiB per dispatch, FETCH_SIZE doubled on gfx950.  The bench runs
 the front end twice: launches are averaged.  "algorithmic" = bytes a launch has to move at least once.
 """
+import re
 import sqlite3
 import sys
 
@@ -41,7 +42,7 @@ def main():
     }
     print("%-34s %8s %10s %10s %12s %12s %12s %14s %10s" % ("kernel", "launches", "mean_us", "grid", "fetch_MB(x2)", "write_MB", "GB/s moved", "algorithmic_MB", "GB/s alg."))
     for name in sorted(dur, key=lambda k: -sum(d for d, _ in dur[k])):
-        short = name.split("(")[0].split("::")[-1]
+        short = re.search(r"fe_\w+", name).group(0)
         d = [x for x, _ in dur[name]]
         big = max(d)
         sel = [x for x in d if x > 0.25 * big]              # the bench's full-size launches (drop the tiny warm-up front end)
@@ -54,8 +55,11 @@ def main():
         print("%-34s %8d %10.1f %10d %12.1f %12.1f %12.0f %14.1f %10.0f"
               % (short, len(sel), mean, max(g for _, g in dur[name]), fmb, wmb, (fmb + wmb) / mean * 1e3 if mean else 0, alg, alg / mean * 1e3 if mean else 0))
     if elements:
-        tally = [x for k in dur for x, _ in dur[k] if "fe_tally" in k]
-        print("# pass 1: %.0f M elements in %.0f us = %.1f G read bases/s; %d positions, %d windows" % (elements / 1e6, max(tally), elements / max(tally) / 1e3, positions, windows))
+        for key, label in (("fe_tally", "pass 1"), ("fe_windows_per_base", "pass 2")):
+            d = [x for k in dur for x, _ in dur[k] if key in k]
+            per_run = sum(d) / 2.0                      # the bench builds the front end twice
+            print("# %s: %.0f M read bases in %.0f us over %d launches = %.1f G read bases/s" % (label, elements / 1e6, per_run, len(d) // 2, elements / per_run / 1e3))
+        print("# %d positions, %d windows" % (positions, windows))
 
 
 if __name__ == "__main__":
