@@ -199,3 +199,30 @@ def test_columns_flag_bases_the_reference_would_trip_over():
     assert col.anomalies & fe.A_SEQ_OVERRUN
     col, _ = columns_of(dict(case, ref=case["ref"][:300] + "-" + case["ref"][301:]))
     assert col.anomalies & fe.A_BAD_REF
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_differential_fuzz_of_the_column_formulation(block):
+    """Random alignments x random options of both stages: the restatement = the sequential host code, candidates then windows."""
+    for seed in range(block * 8, block * 8 + 8):
+        case, pile_kw, evc_kw, region = fc.fuzz_case(seed)
+        rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
+        want_pos = fc.host_candidates(case, **rng, **evc_kw)
+        col, _ = columns_of(case, dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
+        bed = None
+        if evc_kw["bed"] is not None:
+            st, en = [], []
+            for a, b in sorted((a, b + 1 if b == a else b) for a, b in evc_kw["bed"]):
+                if st and a <= en[-1]:
+                    en[-1] = max(en[-1], b)
+                else:
+                    st.append(a)
+                    en.append(b)
+            bed = (np.array(st, np.int64), np.array(en, np.int64))
+        got_pos = col.candidates(min_depth=evc_kw["min_coverage"], min_af=evc_kw["threshold"], ctg_range=region, bed=bed)
+        assert np.array_equal(want_pos, got_pos), seed
+        hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
+                                          min_coverage=pile_kw["min_coverage"])
+        w = col.windows(want_pos, min_cov=pile_kw["min_coverage"])
+        assert col.anomalies == 0, seed
+        assert np.array_equal(hc, w["centres"]) and np.array_equal(hs, w["refseq"]) and np.array_equal(hcounts, w["counts"]), seed

@@ -181,3 +181,27 @@ def test_windows_go_to_the_engine_without_leaving_the_device():
         from_host = e.wait(1)
         assert on_device.tobytes() == from_host.tobytes() and (on_device["status"] != 0).any()
     e.close()
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_differential_fuzz_against_the_sequential_stages(block):
+    """Random alignments x random options of both stages (dcov, mapping-quality floors, depth floors, thresholds, regions, bed
+    intervals, slab cuts): the device front end = the finder followed by the builder, candidates then windows, bit for bit."""
+    done = 0
+    for seed in range(block * 12, block * 12 + 12):
+        case, pile_kw, evc_kw, region = fc.fuzz_case(seed)
+        rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
+        want_pos = fc.host_candidates(case, **rng, **evc_kw)
+        hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
+                                          min_coverage=pile_kw["min_coverage"])
+        f = device_frontend(case, slabs=1 + seed % 4, dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
+        n = f.find_candidates(min_coverage=evc_kw["min_coverage"], threshold=evc_kw["threshold"], ctg_start=rng.get("ctg_start"), ctg_end=rng.get("ctg_end"),
+                              bed=evc_kw["bed"])
+        assert n == len(want_pos) and np.array_equal(f.candidates(), want_pos), seed
+        f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False)
+        assert f.stats()["anomalies"] == 0 and f.host_anomalies == 0 and not f.budget_binds(), seed
+        centres, seqs, counts = windows_of(f)
+        assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts), seed
+        done += len(hc)
+        f.close()
+    assert done > 300
