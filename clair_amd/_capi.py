@@ -26,7 +26,7 @@ SYMBOLS = (
     "clair_frontend_create", "clair_frontend_destroy", "clair_frontend_last_error", "clair_frontend_add_reads",
     "clair_frontend_find_candidates", "clair_frontend_set_candidates", "clair_frontend_get_candidates", "clair_frontend_build_windows",
     "clair_frontend_window_info", "clair_frontend_window_counts", "clair_frontend_counts_device", "clair_frontend_budget_inputs",
-    "clair_frontend_stats",
+    "clair_frontend_stats", "clair_frontend_text_options", "clair_frontend_add_text", "clair_frontend_text_stats", "clair_frontend_slab_reads",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail", "decode")
 
@@ -115,6 +115,10 @@ def load(path=None):
         lib.clair_frontend_counts_device.restype = c_vp
         lib.clair_frontend_budget_inputs.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp]
         lib.clair_frontend_stats.argtypes = [c_vp, c_vp]
+        lib.clair_frontend_text_options.argtypes = [c_vp, ctypes.c_char_p, c_int, c_int, c_int, c_i64, c_i64]
+        lib.clair_frontend_add_text.argtypes = [c_vp, c_vp, c_i64]
+        lib.clair_frontend_text_stats.argtypes = [c_vp, c_vp]
+        lib.clair_frontend_slab_reads.argtypes = [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64)]
     for name in SYMBOLS:
         if older_ok and not hasattr(lib, name):
             continue
@@ -340,6 +344,10 @@ def split_outputs(packed):
     return [np.ascontiguousarray(packed[:, a:b]) for a, b in ((0, 21), (21, 24), (24, 57), (57, 90))]
 
 
+class MalformedText(EngineError):
+    pass
+
+
 class DeviceWindows(object):
     """n pileup windows [33][8][4] int16 in device memory (clair_frontend_counts_device): what Engine.submit_calls takes in place of a
     host array.  Keeps its Frontend alive; host() copies the counts back (the decode needs them only when a BAM is consulted)."""
@@ -405,6 +413,37 @@ class Frontend(object):
             self._check(self._lib.clair_frontend_add_reads(self._h, _ptr(reads), len(reads), _ptr(ops), len(ops), _ptr(op_elem), _ptr(seq), len(seq)),
                         "clair_frontend_add_reads")
             self.slab_reads.append(reads.copy())
+
+    def text_options(self, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=None):
+        """What clair_amd._hostapi.SamPacker takes: from here on add_text() does the packing on the device."""
+        a, b = (-1, -1) if pile_region is None else (int(pile_region[0]), int(pile_region[1]))
+        self._check(self._lib.clair_frontend_text_options(self._h, ctg_name.encode(), int(dcov), int(evc_min_mq), int(pile_min_mq), a, b),
+                    "clair_frontend_text_options")
+
+    def add_text(self, sam, length=None):
+        """`samtools view` text, whole lines: bytes, or (address, length) of a buffer -- e.g. a page-locked one of the engine the pipe was
+        read into.  Raises MalformedText when a line is not an alignment line (the host packer on the same text says which and why)."""
+        if length is None:
+            address, length = ctypes.cast(ctypes.c_char_p(sam), ctypes.c_void_p).value, len(sam)
+        else:
+            address = int(sam)
+        before = self.stats()["slabs"]
+        rc = self._lib.clair_frontend_add_text(self._h, address, int(length))
+        if rc == 2:
+            raise MalformedText(self._lib.clair_frontend_last_error(self._h).decode())
+        self._check(rc, "clair_frontend_add_text")
+        if self.stats()["slabs"] > before:
+            from clair_amd._hostapi import READ_DTYPE
+            n = ctypes.c_int64(0)
+            self._check(self._lib.clair_frontend_slab_reads(self._h, before, None, 0, ctypes.byref(n)), "clair_frontend_slab_reads")
+            reads = np.empty(n.value, dtype=READ_DTYPE)
+            self._check(self._lib.clair_frontend_slab_reads(self._h, before, _ptr(reads), n.value, ctypes.byref(n)), "clair_frontend_slab_reads")
+            self.slab_reads.append(reads)
+
+    def text_stats(self):
+        v = (ctypes.c_int64 * 4)()
+        self._check(self._lib.clair_frontend_text_stats(self._h, v), "clair_frontend_text_stats")
+        return dict(zip(("lines", "evc_reads", "pile_reads", "anomalies"), [int(x) for x in v]))
 
     def find_candidates(self, min_coverage=4, threshold=0.125, ctg_start=None, ctg_end=None, bed=None):
         have_range = ctg_start is not None and ctg_end is not None

@@ -45,6 +45,8 @@ struct BaseTables {
             evc[(unsigned char)keys[i]] = (uint8_t)(acgt[i] == 'A' ? 0 : acgt[i] == 'C' ? 1 : acgt[i] == 'G' ? 2 : 3);
         }
         evc[(unsigned char)'N'] = 6;
+        // both scripts upper-case SEQ first (EVC :301, CT :262): a slab parsed on the device keeps the text as samtools printed it
+        for (int c = 'a'; c <= 'z'; ++c) { pile[c] = pile[c - 32]; evc[c] = evc[c - 32]; }
     }
 };
 __constant__ BaseTables BASES = BaseTables();
@@ -216,10 +218,14 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *total) {  
     return before + x - v;
 }
 
+// NEWLINES: the "flags" are text and a line feed is a set flag
+template <bool NEWLINES> __device__ inline uint8_t flag_of(const uint8_t *flags, int64_t i) { return NEWLINES ? (uint8_t)(flags[i] == '\n') : flags[i]; }
+
+template <bool NEWLINES>
 __global__ __launch_bounds__(256) void fe_block_count_kernel(const uint8_t *flags, int64_t n, uint32_t *block_sum) {
     const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t c = 0;
-    for (int i = 0; i < SCAN_ITEMS; ++i) if (at + i < n) c += flags[at + i];
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (at + i < n) c += flag_of<NEWLINES>(flags, at + i);
     uint32_t total;
     (void)block_exclusive_scan(c, &total);
     if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
@@ -238,12 +244,13 @@ __global__ __launch_bounds__(256) void fe_scan_block_sums_kernel(uint32_t *block
     if (threadIdx.x == 0) *grand_total = carry;
 }
 
+template <bool NEWLINES>
 __global__ __launch_bounds__(256) void fe_scan_write_kernel(const uint8_t *flags, int64_t n, const uint32_t *block_sum, uint32_t *prefix,
                                                             int64_t *list, int64_t list_base) {
     const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint8_t f[SCAN_ITEMS];
     uint32_t c = 0;
-    for (int i = 0; i < SCAN_ITEMS; ++i) { f[i] = at + i < n ? flags[at + i] : 0; c += f[i]; }
+    for (int i = 0; i < SCAN_ITEMS; ++i) { f[i] = at + i < n ? flag_of<NEWLINES>(flags, at + i) : 0; c += f[i]; }
     uint32_t total;
     uint32_t run = block_sum[blockIdx.x] + block_exclusive_scan(c, &total);
     for (int i = 0; i < SCAN_ITEMS; ++i) {
@@ -371,6 +378,247 @@ __global__ __launch_bounds__(256) void fe_assemble_kernel(Region g, const int64_
     }
 }
 
+// ---- `samtools view` text parsed on the device: the line handling of clair_host_sampack_* (hostsrc/host_sampack.cpp), one thread per line ---
+// What the host packer does per line -- split on whitespace, FLAG / RNAME / POS / MAPQ / CIGAR / SEQ, the two stages' filters, the CIGAR
+// reduced to M / I / D operations -- with the text left where it is: a read's bases are addressed inside the text slab (seq0 = offset of
+// SEQ), so nothing is copied and the host only moves bytes from the pipe to the device.  The per-read state the scripts carry from line
+// to line (--dcov, sortedness) is recovered from the sorted start positions (a read's rank among the pileup reads of its start
+// position is its index minus the lower bound of that position) and carried from chunk to chunk by the host.
+struct TextOptions {
+    const uint8_t *ctg;
+    int ctg_len;
+    int dcov, evc_min_mq, pile_min_mq;
+    int64_t pile_start, pile_end;        // 1-based inclusive, -1 -1: none
+};
+
+struct TextLine {                        // what pass A learns about a line
+    int64_t pos0;
+    uint32_t cigar_off, cigar_len, seq_off, seq_len;
+    uint32_t n_ops, n_elem;
+    uint32_t flags;                      // CLAIR_READ_REVERSE | CLAIR_READ_EVC | TL_CANDIDATE | TL_ZERO_INDEL | TL_LONG_SPAN
+    uint32_t pad;
+};
+enum { TL_CANDIDATE = 16, TL_ZERO_INDEL = 32, TL_LONG_SPAN = 64 };
+
+struct TextState {                       // carried from chunk to chunk (host copy in clair_frontend)
+    int64_t prev_pos, depth_cap;         // CreateTensor.py:249-250, 277-287
+    int64_t last_pos, have_last;         // sortedness of the kept alignments
+    int64_t lines, evc_reads, pile_reads;
+    uint32_t anomalies, malformed;       // malformed: 1 + index of the first line the host packer would reject
+};
+
+__device__ inline bool text_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+
+// walks a CIGAR; EMIT writes the kept operations
+template <bool EMIT>
+__device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
+                                  int64_t *o_rp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
+    int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
+    uint32_t n_ops = 0;
+    uint64_t elems = 0;
+    bool zero = false;
+    for (uint32_t i = 0; i < cl; ++i) {
+        const uint8_t ch = cg[i];
+        if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); if (adv > ((int64_t)1 << 40)) adv = (int64_t)1 << 40; continue; }
+        int code = -1;
+        switch (ch) {
+        case 'S': soft += adv; qp += adv; break;
+        case 'M': case '=': case 'X': code = CLAIR_OP_M; break;
+        case 'I': code = CLAIR_OP_I; break;
+        case 'D': code = CLAIR_OP_D; break;
+        case 'N': rlen += adv; break;
+        default: break;
+        }
+        if (code >= 0) {
+            if (adv > 0) {
+                const int64_t len = adv > 0x3fffffff ? 0x3fffffff : adv;
+                if (EMIT) {
+                    ops[n_ops] = clair_op_t{read, (uint32_t)len << 2 | (uint32_t)code, (int32_t)rp, (uint32_t)qp};
+                    op_elem[n_ops] = elem0 + (uint32_t)elems;
+                }
+                ++n_ops;
+                elems += (uint64_t)len;
+            } else if (code != CLAIR_OP_M) {
+                zero = true;
+            }
+            if (code != CLAIR_OP_I) { rp += adv; rlen += adv; }
+            if (code != CLAIR_OP_D) qp += adv;
+        }
+        total += adv;
+        adv = 0;
+    }
+    if (!EMIT) { *o_rp = rp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; }
+}
+
+__device__ inline bool text_int(const uint8_t *s, uint32_t len, int64_t *out) {     // [+-]digits, at most 18 of them (host_sampack.cpp)
+    uint32_t i = 0;
+    bool neg = false;
+    if (i < len && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; ++i; }
+    if (i == len || len - i > 18) return false;
+    int64_t x = 0;
+    for (; i < len; ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        x = x * 10 + (s[i] - '0');
+    }
+    *out = neg ? -x : x;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text, const int64_t *newline, int64_t n_lines, TextOptions opt, TextLine *lines,
+                                                            uint8_t *is_candidate, TextState *state) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_lines) return;
+    TextLine out{};
+    is_candidate[k] = 0;
+    const int64_t begin = k == 0 ? 0 : newline[k - 1] + 1, end = newline[k];
+    uint32_t col[10], len[10];
+    int n = 0;
+    int64_t p = begin;
+    while (p < end && n < 10) {
+        while (p < end && text_space(text[p])) ++p;
+        if (p >= end) break;
+        int64_t q = p;
+        while (q < end && !text_space(text[q])) ++q;
+        col[n] = (uint32_t)p;
+        len[n] = (uint32_t)(q - p);
+        ++n;
+        p = q;
+    }
+    bool bad = n == 0;
+    if (!bad && text[col[0]] == '@') { lines[k] = out; return; }            // header line
+    bad = bad || n < 10;
+    int64_t flag = 0, pos1 = 0, mq = 0;
+    bad = bad || !text_int(text + col[1], len[1], &flag) || !text_int(text + col[3], len[3], &pos1) || !text_int(text + col[4], len[4], &mq);
+    if (bad) {                                                                // the host packer names the line and the column
+        atomicMin(&state->malformed, (uint32_t)(k + 1));
+        lines[k] = out;
+        return;
+    }
+    bool same_ctg = (int)len[2] == opt.ctg_len;
+    for (int i = 0; same_ctg && i < opt.ctg_len; ++i) same_ctg = text[col[2] + i] == opt.ctg[i];
+    int64_t rp, soft, total, rlen;
+    uint32_t n_ops;
+    uint64_t elems;
+    bool zero;
+    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &soft, &total, &rlen, &n_ops, &elems, &zero);
+    const bool evc_ok = same_ctg && mq >= opt.evc_min_mq && !(len[5] == 1 && text[col[5]] == '*') && !(1.0 - (double)soft / (double)(total + 1) < 0.55);
+    bool in_region = true;
+    if (opt.pile_start >= 0 && opt.pile_end >= 0) {
+        const int64_t end1 = pos1 + (rlen > 0 ? rlen : 1) - 1;                // bam_endpos
+        in_region = same_ctg && pos1 <= opt.pile_end && end1 >= opt.pile_start;
+    }
+    const bool candidate = in_region && mq >= opt.pile_min_mq;
+    out.pos0 = pos1 - 1;
+    out.cigar_off = col[5]; out.cigar_len = len[5];
+    out.seq_off = col[9]; out.seq_len = len[9];
+    out.n_ops = n_ops;
+    out.n_elem = elems > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)elems;
+    out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0)
+                | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00) ? TL_LONG_SPAN : 0);
+    lines[k] = out;
+    is_candidate[k] = candidate ? 1 : 0;
+}
+
+// --dcov: the rank of a pileup read among those of its start position = its index among the candidates minus the lower bound of its
+// position (start positions ascend; where they do not, CLAIR_FE_UNSORTED sends the run to the host anyway)
+__global__ __launch_bounds__(256) void fe_text_dcov_kernel(TextLine *lines, const int64_t *cand, int64_t n_cand, int dcov, TextState carry) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_cand) return;
+    TextLine &ln = lines[cand[j]];
+    const int64_t pos = ln.pos0;
+    int64_t a = 0, b = j;                                                     // first candidate with this start position
+    while (a < b) { const int64_t mid = (a + b) >> 1; if (lines[cand[mid]].pos0 < pos) a = mid + 1; else b = mid; }
+    int64_t depth_cap = j - a;
+    if (a == 0 && pos == carry.prev_pos) depth_cap += carry.depth_cap + 1;   // the run began in an earlier chunk (or is the scripts' initial previous_position = 0)
+    uint32_t fl = ln.flags;
+    if (depth_cap < dcov) fl |= CLAIR_READ_PILE | (depth_cap == 0 ? CLAIR_READ_FLUSH : 0);
+    ln.flags = fl;
+}
+
+__global__ __launch_bounds__(256) void fe_text_keep_kernel(const TextLine *lines, int64_t n_lines, uint8_t *keep) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_lines) return;
+    keep[k] = (lines[k].flags & (CLAIR_READ_EVC | CLAIR_READ_PILE)) ? 1 : 0;
+}
+
+// one workgroup: exclusive sums of the kept lines' operation and element counts, sortedness, counters, the state for the next chunk
+__global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *lines, int64_t n_lines, const int64_t *kept, int64_t n_kept, const int64_t *cand, int64_t n_cand,
+                                                              uint32_t *op0, uint32_t *elem0, uint64_t *totals, TextState carry, TextState *state) {
+    __shared__ uint64_t s_ops, s_elems;
+    __shared__ uint32_t s_anom;
+    __shared__ unsigned long long s_evc, s_pile;
+    if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_evc = 0; s_pile = 0; }
+    __syncthreads();
+    uint64_t carry_ops = 0, carry_elems = 0;
+    uint32_t anom = 0;
+    unsigned long long evc = 0, pile = 0;
+    for (int64_t at = 0; at < n_kept; at += 256) {
+        const int64_t i = at + threadIdx.x;
+        uint32_t a = 0, b = 0;
+        if (i < n_kept) {
+            const TextLine ln = lines[kept[i]];
+            a = ln.n_ops;
+            b = ln.n_elem;
+            const int64_t before = i > 0 ? lines[kept[i - 1]].pos0 : (carry.have_last ? carry.last_pos : ln.pos0);
+            if (ln.pos0 < before) anom |= CLAIR_FE_UNSORTED;
+            if ((ln.flags & TL_ZERO_INDEL) && (ln.flags & CLAIR_READ_EVC)) anom |= CLAIR_FE_ZERO_INDEL;
+            if (ln.flags & TL_LONG_SPAN) anom |= CLAIR_FE_LONG_SPAN;
+            evc += (ln.flags & CLAIR_READ_EVC) ? 1 : 0;
+            pile += (ln.flags & CLAIR_READ_PILE) ? 1 : 0;
+        }
+        uint32_t ta, tb;
+        const uint32_t ea = block_exclusive_scan(a, &ta);
+        const uint32_t eb = block_exclusive_scan(b, &tb);
+        if (i < n_kept) { op0[i] = (uint32_t)(carry_ops + ea); elem0[i] = (uint32_t)(carry_elems + eb); }
+        carry_ops += ta;
+        carry_elems += tb;
+    }
+    atomicOr(&s_anom, anom);
+    atomicAdd(&s_evc, evc);
+    atomicAdd(&s_pile, pile);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[0] = carry_ops;
+        totals[1] = carry_elems;
+        TextState st = carry;
+        st.anomalies = carry.anomalies | s_anom;
+        st.malformed = state->malformed;
+        st.lines = carry.lines + n_lines;
+        st.evc_reads = carry.evc_reads + (int64_t)s_evc;
+        st.pile_reads = carry.pile_reads + (int64_t)s_pile;
+        if (n_kept) { st.last_pos = lines[kept[n_kept - 1]].pos0; st.have_last = 1; }
+        if (n_cand) {                                                         // previous_position / depthCap after the last pileup candidate
+            const int64_t pos = lines[cand[n_cand - 1]].pos0;
+            int64_t a = 0, b = n_cand - 1;
+            while (a < b) { const int64_t mid = (a + b) >> 1; if (lines[cand[mid]].pos0 < pos) a = mid + 1; else b = mid; }
+            int64_t depth_cap = n_cand - 1 - a;
+            if (a == 0 && pos == carry.prev_pos) depth_cap += carry.depth_cap + 1;
+            st.prev_pos = pos;
+            st.depth_cap = depth_cap;
+        }
+        *state = st;
+    }
+}
+
+__global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, const TextLine *lines, const int64_t *kept, int64_t n_kept, const uint32_t *op0,
+                                                           const uint32_t *elem0, clair_read_t *reads, clair_op_t *ops, uint32_t *op_elem, uint64_t total_ops,
+                                                           uint64_t total_elems) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) op_elem[total_ops] = (uint32_t)total_elems;
+    if (i >= n_kept) return;
+    const TextLine ln = lines[kept[i]];
+    walk_cigar<true>(text + ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    clair_read_t r;
+    r.pos0 = ln.pos0;
+    r.seq0 = ln.seq_off;
+    r.seq_len = ln.seq_len;
+    r.op0 = op0[i];
+    r.n_ops = ln.n_ops;
+    r.flags = ln.flags & (CLAIR_READ_REVERSE | CLAIR_READ_EVC | CLAIR_READ_PILE | CLAIR_READ_FLUSH);
+    r.reserved = 0;
+    reads[i] = r;
+}
+
 int fe_fail(clair_frontend *f, const char *fmt, ...);
 
 }  // namespace
@@ -399,6 +647,12 @@ struct clair_frontend {
     int64_t *d_out_centre = nullptr;
     uint8_t *d_out_refseq = nullptr;
     int64_t n_windows = -1;
+    // text parsed on the device (clair_frontend_text_options / _add_text)
+    bool text_ready = false;
+    TextOptions text_opt{};
+    uint8_t *d_ctg = nullptr;
+    TextState text_state{};
+    TextState *d_text_state = nullptr;
     std::string error;
 
     SlabView view(const Slab &s) const {
@@ -428,9 +682,10 @@ int fe_fail(clair_frontend *f, const char *fmt, ...) {
 inline unsigned blocks_for(int64_t n, int64_t per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 // flags[n] -> how many are set (block sums left scanned in block_sum for scan_write)
-int scan_count(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *block_sum, uint32_t *d_count, int64_t *count) {
+int scan_count(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *block_sum, uint32_t *d_count, int64_t *count, bool newlines = false) {
     const unsigned nb = blocks_for(n, SCAN_BLOCK);
-    if (n > 0) hipLaunchKernelGGL(fe_block_count_kernel, dim3(nb), dim3(256), 0, f->stream, flags, n, block_sum);
+    if (n > 0 && newlines) hipLaunchKernelGGL(fe_block_count_kernel<true>, dim3(nb), dim3(256), 0, f->stream, flags, n, block_sum);
+    else if (n > 0) hipLaunchKernelGGL(fe_block_count_kernel<false>, dim3(nb), dim3(256), 0, f->stream, flags, n, block_sum);
     hipLaunchKernelGGL(fe_scan_block_sums_kernel, dim3(1), dim3(256), 0, f->stream, block_sum, (int64_t)nb, d_count);
     FE_TRY(f, hipGetLastError());
     uint32_t total = 0;
@@ -442,11 +697,12 @@ int scan_count(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *blo
 
 // after scan_count: prefix[n + 1] (optional) and the list of flagged indices (+ list_base)
 int scan_write(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *block_sum, const uint32_t *d_count, uint32_t *prefix, int64_t *list,
-               int64_t list_base) {
+               int64_t list_base, bool newlines = false) {
     // entry n of the prefix is written by the thread that owns index n: cover it with one more (empty) item
     const unsigned nb = blocks_for(n, SCAN_BLOCK), nbw = blocks_for(n + 1, SCAN_BLOCK);
     if (nbw > nb) FE_TRY(f, hipMemcpyAsync(block_sum + nb, d_count, sizeof(uint32_t), hipMemcpyDeviceToDevice, f->stream));
-    hipLaunchKernelGGL(fe_scan_write_kernel, dim3(nbw), dim3(256), 0, f->stream, flags, n, (const uint32_t *)block_sum, prefix, list, list_base);
+    if (newlines) hipLaunchKernelGGL(fe_scan_write_kernel<true>, dim3(nbw), dim3(256), 0, f->stream, flags, n, (const uint32_t *)block_sum, prefix, list, list_base);
+    else hipLaunchKernelGGL(fe_scan_write_kernel<false>, dim3(nbw), dim3(256), 0, f->stream, flags, n, (const uint32_t *)block_sum, prefix, list, list_base);
     FE_TRY(f, hipGetLastError());
     return 0;
 }
@@ -540,6 +796,7 @@ void clair_frontend_destroy(clair_frontend_t *f) {
     free_candidates(f);
     (void)hipFree(f->d_ref); (void)hipFree(f->g.ev); (void)hipFree(f->g.q); (void)hipFree(f->g.misc); (void)hipFree(f->g.anomalies);
     (void)hipFree(f->d_flags); (void)hipFree(f->d_before); (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_bed);
+    (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
@@ -571,6 +828,137 @@ int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int
     FE_TRY(f, hipGetLastError());
     // the caller's arrays may be reused as soon as this returns (the packer's slab is reset): wait for the copies
     FE_TRY(f, hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int clair_frontend_text_options(clair_frontend_t *f, const char *ctg_name, int dcov, int evc_min_mq, int pile_min_mq, int64_t pile_start, int64_t pile_end) {
+    if (!f) return fe_fail(nullptr, "front end is NULL");
+    if (!ctg_name) return fe_fail(f, "contig name missing");
+    if (!f->slabs.empty() && f->text_ready) return fe_fail(f, "text options cannot change once text was added");
+    FE_TRY(f, hipSetDevice(f->device));
+    const size_t n = strlen(ctg_name);
+    (void)hipFree(f->d_ctg); f->d_ctg = nullptr;
+    FE_TRY(f, hipMalloc((void **)&f->d_ctg, std::max<size_t>(n, 1)));
+    if (n) FE_TRY(f, hipMemcpy(f->d_ctg, ctg_name, n, hipMemcpyHostToDevice));
+    if (!f->d_text_state) FE_TRY(f, hipMalloc((void **)&f->d_text_state, sizeof(TextState)));
+    const bool have_region = pile_start >= 0 && pile_end >= 0;
+    f->text_opt = TextOptions{f->d_ctg, (int)n, dcov, evc_min_mq, pile_min_mq, have_region ? pile_start : -1, have_region ? pile_end : -1};
+    f->text_state = TextState{};
+    f->text_ready = true;
+    return 0;
+}
+
+// returns 2 (not 1) when a line of the text is malformed: clair_host_sampack_feed on the same text names the line and the column
+int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
+    if (!f) return fe_fail(nullptr, "front end is NULL");
+    if (!f->text_ready) return fe_fail(f, "call clair_frontend_text_options first");
+    if (len < 0 || (len > 0 && !sam)) return fe_fail(f, "bad text");
+    if (len == 0) return 0;
+    if (len > 0x7ffffff0ll) return fe_fail(f, "text chunk of %lld bytes: at most 2 GB at a time", (long long)len);
+    if (sam[len - 1] != '\n') return fe_fail(f, "the text must end at a line end");
+    if (f->n_candidates >= 0) return fe_fail(f, "reads cannot be added after the candidates were fixed");
+    FE_TRY(f, hipSetDevice(f->device));
+    struct Temp {           // freed on every way out
+        std::vector<void *> p;
+        ~Temp() { for (void *x : p) (void)hipFree(x); }
+        hipError_t get(void **out, size_t bytes) { hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16)); if (e == hipSuccess) p.push_back(*out); return e; }
+        void keep(void *x) { p.erase(std::remove(p.begin(), p.end(), x), p.end()); }
+    } tmp;
+    uint8_t *d_text = nullptr;
+    uint32_t *block_sum = nullptr, *d_count = nullptr;
+    FE_TRY(f, tmp.get((void **)&d_text, (size_t)len));
+    FE_TRY(f, tmp.get((void **)&block_sum, ((size_t)blocks_for(len + 1, SCAN_BLOCK) + 2) * sizeof(uint32_t)));
+    FE_TRY(f, tmp.get((void **)&d_count, 4 * sizeof(uint32_t)));
+    FE_TRY(f, hipMemcpyAsync(d_text, sam, (size_t)len, hipMemcpyHostToDevice, f->stream));
+    int64_t n_lines = 0;
+    if (scan_count(f, d_text, len, block_sum, d_count, &n_lines, true)) return 1;
+    int64_t *newline = nullptr, *cand = nullptr, *kept = nullptr;
+    TextLine *lines = nullptr;
+    uint8_t *is_cand = nullptr, *keep = nullptr;
+    uint32_t *line_sum = nullptr;
+    FE_TRY(f, tmp.get((void **)&newline, (size_t)n_lines * sizeof(int64_t)));
+    if (scan_write(f, d_text, len, block_sum, d_count, nullptr, newline, 0, true)) return 1;
+    FE_TRY(f, tmp.get((void **)&lines, (size_t)n_lines * sizeof(TextLine)));
+    FE_TRY(f, tmp.get((void **)&is_cand, (size_t)n_lines + 1));
+    FE_TRY(f, tmp.get((void **)&keep, (size_t)n_lines + 1));
+    FE_TRY(f, tmp.get((void **)&line_sum, ((size_t)blocks_for(n_lines + 1, SCAN_BLOCK) + 2) * sizeof(uint32_t)));
+    TextState carry = f->text_state;
+    carry.malformed = 0xffffffffu;
+    FE_TRY(f, hipMemcpyAsync(f->d_text_state, &carry, sizeof carry, hipMemcpyHostToDevice, f->stream));
+    hipLaunchKernelGGL(fe_text_lines_kernel, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
+                       f->text_opt, lines, is_cand, f->d_text_state);
+    FE_TRY(f, hipGetLastError());
+    int64_t n_cand = 0, n_kept = 0;
+    if (scan_count(f, is_cand, n_lines, line_sum, d_count + 1, &n_cand)) return 1;
+    FE_TRY(f, tmp.get((void **)&cand, (size_t)n_cand * sizeof(int64_t)));
+    if (scan_write(f, is_cand, n_lines, line_sum, d_count + 1, nullptr, cand, 0)) return 1;
+    if (n_cand) hipLaunchKernelGGL(fe_text_dcov_kernel, dim3(blocks_for(n_cand, 256)), dim3(256), 0, f->stream, lines, (const int64_t *)cand, n_cand, f->text_opt.dcov, carry);
+    hipLaunchKernelGGL(fe_text_keep_kernel, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const TextLine *)lines, n_lines, keep);
+    FE_TRY(f, hipGetLastError());
+    if (scan_count(f, keep, n_lines, line_sum, d_count + 2, &n_kept)) return 1;
+    FE_TRY(f, tmp.get((void **)&kept, (size_t)n_kept * sizeof(int64_t)));
+    if (scan_write(f, keep, n_lines, line_sum, d_count + 2, nullptr, kept, 0)) return 1;
+    uint32_t *op0 = nullptr, *elem0 = nullptr;
+    uint64_t *d_totals = nullptr;
+    FE_TRY(f, tmp.get((void **)&op0, (size_t)n_kept * sizeof(uint32_t)));
+    FE_TRY(f, tmp.get((void **)&elem0, (size_t)n_kept * sizeof(uint32_t)));
+    FE_TRY(f, tmp.get((void **)&d_totals, 2 * sizeof(uint64_t)));
+    hipLaunchKernelGGL(fe_text_offsets_kernel, dim3(1), dim3(256), 0, f->stream, (const TextLine *)lines, n_lines, (const int64_t *)kept, n_kept, (const int64_t *)cand, n_cand,
+                       op0, elem0, d_totals, carry, f->d_text_state);
+    FE_TRY(f, hipGetLastError());
+    uint64_t totals[2] = {0, 0};
+    TextState after{};
+    FE_TRY(f, hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, f->stream));
+    FE_TRY(f, hipMemcpyAsync(&after, f->d_text_state, sizeof after, hipMemcpyDeviceToHost, f->stream));
+    FE_TRY(f, hipStreamSynchronize(f->stream));
+    if (after.malformed != 0xffffffffu) {
+        fe_fail(f, "line %u of this chunk (%lld lines before it) is not an alignment line the scripts accept: clair_host_sampack_feed on the same text names "
+                   "the column", after.malformed - 1, (long long)f->text_state.lines);
+        return 2;
+    }
+    if (totals[0] > 0xfffffff0ull || totals[1] > 0xfffffff0ull) return fe_fail(f, "text chunk too dense for 32-bit offsets: feed smaller chunks");
+    after.malformed = 0;
+    f->text_state = after;
+    if (n_kept == 0 || totals[0] == 0) return 0;
+    Slab s;
+    s.n_reads = n_kept; s.n_ops = (int64_t)totals[0]; s.n_elem = (int64_t)totals[1]; s.seq_bytes = len;
+    FE_TRY(f, hipMalloc((void **)&s.reads, (size_t)n_kept * sizeof(clair_read_t)));
+    f->slabs.push_back(s);
+    Slab &d = f->slabs.back();
+    FE_TRY(f, hipMalloc((void **)&d.ops, (size_t)d.n_ops * sizeof(clair_op_t)));
+    FE_TRY(f, hipMalloc((void **)&d.op_elem, ((size_t)d.n_ops + 1) * sizeof(uint32_t)));
+    FE_TRY(f, hipMalloc((void **)&d.tuples, (size_t)n_kept * sizeof(uint64_t)));
+    d.seq = d_text;                     // the bases stay where samtools printed them
+    tmp.keep(d_text);
+    FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
+    hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
+                       (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+    if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
+    FE_TRY(f, hipGetLastError());
+    FE_TRY(f, hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int clair_frontend_text_stats(clair_frontend_t *f, int64_t *stats) {
+    if (!f) return fe_fail(nullptr, "front end is NULL");
+    if (!stats) return fe_fail(f, "stats is NULL");
+    stats[0] = f->text_state.lines;
+    stats[1] = f->text_state.evc_reads;
+    stats[2] = f->text_state.pile_reads;
+    stats[3] = (int64_t)f->text_state.anomalies;
+    return 0;
+}
+
+int clair_frontend_slab_reads(clair_frontend_t *f, int64_t slab, struct clair_read *reads, int64_t capacity, int64_t *n_reads) {
+    if (!f) return fe_fail(nullptr, "front end is NULL");
+    if (slab < 0 || slab >= (int64_t)f->slabs.size()) return fe_fail(f, "slab %lld out of range [0, %lld)", (long long)slab, (long long)f->slabs.size());
+    if (!n_reads) return fe_fail(f, "n_reads is NULL");
+    const Slab &s = f->slabs[(size_t)slab];
+    *n_reads = s.n_reads;
+    if (!reads) return 0;
+    if (capacity < s.n_reads) return fe_fail(f, "room for %lld alignments, the slab holds %lld", (long long)capacity, (long long)s.n_reads);
+    FE_TRY(f, hipSetDevice(f->device));
+    FE_TRY(f, hipMemcpy(reads, s.reads, (size_t)s.n_reads * sizeof(clair_read_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -736,7 +1124,7 @@ int clair_frontend_stats(clair_frontend_t *f, int64_t *stats) {
     FE_TRY(f, hipMemcpy(&bits, f->g.anomalies, sizeof bits, hipMemcpyDeviceToHost));
     int64_t reads = 0, elems = 0;
     for (const Slab &s : f->slabs) { reads += s.n_reads; elems += s.n_elem; }
-    stats[0] = (int64_t)bits;
+    stats[0] = (int64_t)(bits | f->text_state.anomalies);
     stats[1] = (int64_t)f->slabs.size();
     stats[2] = reads;
     stats[3] = elems;

@@ -250,6 +250,18 @@ const char *clair_frontend_last_error(const clair_frontend_t *f);      /* f may 
 /* Copy one slab to the device (it stays there) and add its bases to the per-position tables.  The arrays may be reused on return. */
 int clair_frontend_add_reads(clair_frontend_t *f, const struct clair_read *reads, int64_t n_reads, const struct clair_op *ops, int64_t n_ops,
                              const uint32_t *op_elem, const uint8_t *seq, int64_t seq_bytes);
+/* ... or hand over the `samtools view` TEXT and let the device do the packing as well: the line handling of both scripts
+ * (ExtractVariantCandidates.py:266-295, CreateTensor.py:251-287) one thread per line, exactly what clair_host_sampack_* produces
+ * (arguments of _text_options as clair_host_sampack_create), with the bases left where samtools printed them.  `sam` holds whole
+ * lines (the caller keeps an unfinished last line for the next call), at most 2 GB at a time; the --dcov and sortedness state runs on
+ * across calls.  Returns 2 when a line is malformed (too few columns, a non-integer FLAG / POS / MAPQ): clair_host_sampack_feed on
+ * the same text reports it the way the host path does.  _text_stats: stats[0..3] = lines, candidate-search alignments, pileup
+ * alignments since _text_options, CLAIR_FE_* bits of the line handling (also folded into clair_frontend_stats).  _slab_reads copies
+ * a slab's alignment records back (the budget replay walks them); reads == NULL only asks for the count. */
+int clair_frontend_text_options(clair_frontend_t *f, const char *ctg_name, int dcov, int evc_min_mq, int pile_min_mq, int64_t pile_start, int64_t pile_end);
+int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len);
+int clair_frontend_text_stats(clair_frontend_t *f, int64_t *stats);
+int clair_frontend_slab_reads(clair_frontend_t *f, int64_t slab, struct clair_read *reads, int64_t capacity, int64_t *n_reads);
 /* The candidate filter over the tallies: arguments as clair_host_evc_create (include/clair_host.h). */
 int clair_frontend_find_candidates(clair_frontend_t *f, double min_coverage, double threshold, int64_t ctg_start, int64_t ctg_end,
                                    const int64_t *bed_start, const int64_t *bed_end, int64_t n_bed, int64_t *n_candidates);

@@ -209,6 +209,12 @@ def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch
             callVarBam.main(base + ["--call_fn", out, "--front_end", fe] + extra)
             outs[fe] = open(out).read()
         assert outs["device"] == outs["host"] and len(outs["host"].splitlines()) > 30, extra
+    # many small slabs instead of one
+    monkeypatch.setattr(callVarBam, "SLAB_BYTES", 3000)
+    out = os.path.join(tmp, "slabs.vcf")
+    callVarBam.main(base + ["--call_fn", out, "--front_end", "device"])
+    callVarBam.main(base + ["--call_fn", os.path.join(tmp, "h0.vcf"), "--front_end", "host"])
+    assert open(out).read() == open(os.path.join(tmp, "h0.vcf")).read()
     monkeypatch.setattr(_capi.Frontend, "budget_binds", lambda self, available_slots=5000000: True)
     out = os.path.join(tmp, "fallback.vcf")
     with caplog.at_level(logging.INFO):

@@ -205,3 +205,138 @@ def test_differential_fuzz_against_the_sequential_stages(block):
         done += len(hc)
         f.close()
     assert done > 300
+
+
+def test_span_of_a_whole_chromosome():
+    """Tables over 260 M positions (chr1-sized: 25 GB of tables, 64-bit indexing, 63 k scan blocks) with alignments at both ends."""
+    rng = np.random.default_rng(1)
+    n = 260_000_000
+    ref = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n, dtype=np.uint8)]
+    offset = n - 5000
+    a = fc.synth(61, n_reads=300, ref_len=3000, iupac=False)
+    b = fc.synth(62, n_reads=300, ref_len=3000, iupac=False)
+    ref[:3000] = np.frombuffer(a["ref"].encode(), np.uint8)
+    ref[offset:offset + 3000] = np.frombuffer(b["ref"].encode(), np.uint8)
+    shifted = []
+    for line in b["sam"].decode().splitlines():
+        col = line.split("\t")
+        col[3] = str(int(col[3]) + offset)
+        shifted.append("\t".join(col))
+    case = dict(ctg=a["ctg"], ref=ref.tobytes().decode(), ref0=0, sam=a["sam"] + ("\n".join(shifted) + "\n").encode())
+    del ref
+    want_pos = fc.host_candidates(case, min_coverage=4, threshold=0.125)
+    hc, hs, hcounts = fc.host_windows(case, candidates=want_pos)
+    assert (want_pos > offset).sum() > 50 and (want_pos < 3000).sum() > 50
+    f = device_frontend(case, slabs=2)
+    assert f.find_candidates(min_coverage=4, threshold=0.125) == len(want_pos) and np.array_equal(f.candidates(), want_pos)
+    f.build_windows(drop_non_iupac_centre=False)
+    assert f.stats()["anomalies"] == 0 and not f.budget_binds()
+    centres, seqs, counts = windows_of(f)
+    assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts)
+    f.close()
+
+
+# ---- the same with the text parsed on the device (clair_frontend_add_text) -------------------------------------------------------------
+def device_frontend_text(case, chunks=1, margin=64, **pack_kw):
+    f = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - margin, case["ref0"] + len(case["ref"]) + margin)
+    f.text_options(case["ctg"], **pack_kw)
+    sam, at = case["sam"], 0
+    for k in range(chunks):
+        cut = len(sam) if k == chunks - 1 else sam.index(b"\n", len(sam) * (k + 1) // chunks) + 1
+        f.add_text(sam[at:cut])
+        at = cut
+    return f
+
+
+def host_packed(case, **pack_kw):
+    p = _hostapi.SamPacker(case["ctg"], **pack_kw)
+    assert p.feed(case["sam"], final=True) == b""
+    return p.slab_arrays(), p.stats()
+
+
+@pytest.mark.parametrize("chunks", [1, 7])
+@pytest.mark.parametrize("opt", range(5))
+def test_text_parsed_on_the_device_gives_the_host_packers_alignments(opt, chunks):
+    kw = [dict(), dict(dcov=3), dict(evc_min_mq=20, pile_min_mq=30), dict(pile_region=(500, 1500)), dict(pile_region=(1, 40), dcov=2)][opt]
+    case = fc.synth(seed=40 + opt, n_reads=400, ref_len=3000, dup_burst=8)
+    (r, o, e, q), st = host_packed(case, **kw)
+    f = device_frontend_text(case, chunks=chunks, **kw)
+    got = np.concatenate(f.slab_reads)
+    ts = f.text_stats()
+    assert ts == dict(lines=st["lines"], evc_reads=st["evc_reads"], pile_reads=st["pile_reads"], anomalies=st["anomalies"])
+    assert len(got) == len(r) and np.array_equal(got["pos0"], r["pos0"]) and np.array_equal(got["flags"], r["flags"])
+    assert np.array_equal(got["seq_len"], r["seq_len"]) and np.array_equal(got["n_ops"], r["n_ops"])
+    # ... and everything downstream of them: tallies -> candidates, windows, tuple counts
+    g = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+    g.add_arrays(r, o, e, q)
+    for x in (f, g):
+        x.find_candidates(min_coverage=3, threshold=0.1)
+        x.build_windows(drop_non_iupac_centre=False)
+    assert np.array_equal(f.candidates(), g.candidates()) and f.stats()["windows"] == g.stats()["windows"] > 20
+    for a, b in zip(windows_of(f), windows_of(g)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(np.concatenate([f.read_tuples(k) for k in range(f.stats()["slabs"])]), g.read_tuples(0))
+    assert f.stats()["anomalies"] == g.stats()["anomalies"] == 0 and f.budget_binds() == g.budget_binds()
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_differential_fuzz_with_the_text_parsed_on_the_device(block):
+    done = 0
+    for seed in range(100 + block * 12, 100 + block * 12 + 12):
+        case, pile_kw, evc_kw, region = fc.fuzz_case(seed)
+        rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
+        want_pos = fc.host_candidates(case, **rng, **evc_kw)
+        hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
+                                          min_coverage=pile_kw["min_coverage"])
+        f = device_frontend_text(case, chunks=1 + seed % 5, dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
+        n = f.find_candidates(min_coverage=evc_kw["min_coverage"], threshold=evc_kw["threshold"], ctg_start=rng.get("ctg_start"), ctg_end=rng.get("ctg_end"),
+                              bed=evc_kw["bed"])
+        assert n == len(want_pos) and np.array_equal(f.candidates(), want_pos), seed
+        f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False)
+        assert f.stats()["anomalies"] == 0 and not f.budget_binds(), seed
+        centres, seqs, counts = windows_of(f)
+        assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts), seed
+        done += len(hc)
+        f.close()
+    assert done > 300
+
+
+def test_text_on_the_device_reports_what_the_host_packer_reports():
+    ok = b"r1\t0\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n"
+    ref = "ACGT" * 100
+
+    def fresh(**kw):
+        f = _capi.Frontend(0, ref, 0, -64, 464)
+        f.text_options("chrS", **kw)
+        return f
+    f = fresh()
+    f.add_text(ok + b"r2\t0\tchrS\t5\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n")
+    assert f.text_stats()["anomalies"] == fe.A_UNSORTED and f.stats()["anomalies"] & fe.A_UNSORTED
+    f = fresh()
+    f.add_text(ok)
+    f.add_text(b"r2\t0\tchrS\t5\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n")              # ... across two calls
+    assert f.text_stats()["anomalies"] == fe.A_UNSORTED
+    f = fresh()
+    f.add_text(b"r1\t0\tchrS\t10\t60\t3M0I2M\t*\t0\t0\tACGTA\tIIIII\n")
+    assert f.text_stats()["anomalies"] == fe.A_ZERO_INDEL
+    f = fresh()
+    f.add_text(b"r1\t0\tchrS\t10\t60\t2M200000D3M\t*\t0\t0\tACGTA\tIIIII\n")
+    assert f.text_stats()["anomalies"] == fe.A_LONG_SPAN
+    for bad in (b"r1\t0\tchrS\n", b"r1\tx\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n", b"\n", ok + b"  \n" + ok):
+        with pytest.raises(_capi.MalformedText):
+            fresh().add_text(bad)
+    f = fresh(evc_min_mq=10, pile_min_mq=10)
+    f.add_text(b"@HD\tVN:1.6\n" + b"r1\t0\tchrS\t10\t5\t5M\t*\t0\t0\tACGTA\tIIIII\n" + ok)
+    assert f.text_stats() == dict(lines=3, evc_reads=1, pile_reads=1, anomalies=0) and f.stats()["reads"] == 1
+    with pytest.raises(_capi.EngineError, match="line end"):
+        fresh().add_text(ok[:-1])
+    # lower-case bases stay lower-case in the slab and count as their upper-case selves (both scripts upper-case SEQ first)
+    f, g = fresh(), fresh()
+    f.add_text(b"r1\t0\tchrS\t10\t60\t5M\t*\t0\t0\tacgta\tIIIII\n" * 6)
+    g.add_text(ok * 6)
+    for x in (f, g):
+        x.find_candidates(min_coverage=1, threshold=0.0)
+        x.build_windows(drop_non_iupac_centre=False)
+    assert f.stats()["windows"] == g.stats()["windows"] > 0
+    for a, b in zip(windows_of(f), windows_of(g)):
+        assert np.array_equal(a, b)
