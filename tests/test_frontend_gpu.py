@@ -332,8 +332,8 @@ def test_text_on_the_device_reports_what_the_host_packer_reports():
         fresh().add_text(ok[:-1])
     # lower-case bases stay lower-case in the slab and count as their upper-case selves (both scripts upper-case SEQ first)
     f, g = fresh(), fresh()
-    f.add_text(b"r1\t0\tchrS\t10\t60\t5M\t*\t0\t0\tacgta\tIIIII\n" * 6)
-    g.add_text(ok * 6)
+    f.add_text(b"r1\t0\tchrS\t100\t60\t5M\t*\t0\t0\tacgta\tIIIII\n" * 6)
+    g.add_text(ok.replace(b"\t10\t", b"\t100\t") * 6)
     for x in (f, g):
         x.find_candidates(min_coverage=1, threshold=0.0)
         x.build_windows(drop_non_iupac_centre=False)
