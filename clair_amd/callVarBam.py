@@ -195,7 +195,8 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
         sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
 
 
-SLAB_BYTES = 64 << 20      # SEQ bytes per slab of packed alignments sent to the device
+SLAB_BYTES = 64 << 20      # SEQ bytes per slab of packed alignments sent to the device (host packer)
+TEXT_CHUNK = 256 << 20     # bytes of `samtools view` text handed to the device at a time (device parser)
 TABLE_MARGIN = 64          # positions the device tables extend beyond the region (a window reaches 17 beyond its centre)
 FE_REASONS = ((1, "alignments not sorted by position"), (2, "a zero-length insertion/deletion"), (4, "an alignment spanning > 100 kb more than its bases"),
               (8, "a CIGAR longer than its SEQ"), (16, "a read base outside the IUPAC alphabet"), (32, "a reference base outside the IUPAC alphabet"),
@@ -206,8 +207,10 @@ class DeviceFrontEnd(object):
     """Both pileup stages on the GPU for one contig / region.  run() -> number of windows, or None when the run has to take the host
     path (reason logged); batches() then yields what tensor_batches yields, with the counts as clair_amd._capi.DeviceWindows."""
 
-    def __init__(self, args, device):
-        self.args, self.device = args, device
+    def __init__(self, args, device, pinned=None):
+        """pinned: nbytes -> page-locked uint8 array (Clair.pinned_buffer): the text is then read straight into it and parsed on the
+        device; without it (or with CLAIR_AMD_FE_PACK=host) the host packer (clair_host_sampack_*) makes the slabs."""
+        self.args, self.device, self.pinned = args, device, pinned
         self.frontend = None
         self.n_windows = 0
 
@@ -265,35 +268,76 @@ class DeviceFrontEnd(object):
             f = self.frontend = _capi.Frontend(self.device, seq, ref0, lo, hi)
         except _capi.EngineError as exc:
             sys.exit("[ERROR] %s" % exc)
-        packer = _hostapi.SamPacker(args.ctgName, dcov=args.dcov, evc_min_mq=0, pile_min_mq=0,
-                                    pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
+        pack_kw = dict(dcov=args.dcov, evc_min_mq=0, pile_min_mq=0, pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
         view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
                                    text=False)
         from time import time
         t_start, t_pack, t_dev = time(), 0.0, 0.0
-        tail = None
-        while True:
-            chunk = view.stdout.read(1 << 23)
-            if not chunk:
-                break
-            t0 = time()
-            tail = packer.feed(chunk if tail is None else tail + chunk)
-            t_pack += time() - t0
-            if packer.stats()["seq_bytes"] >= SLAB_BYTES:
+        if self.pinned is not None and os.environ.get("CLAIR_AMD_FE_PACK", "device") != "host":
+            # the text goes to the GPU as it comes out of the pipe (read into a page-locked buffer, whole lines at a time) and is
+            # parsed there: the host touches no byte of it but the last megabyte of each chunk, looking for the line end
+            f.text_options(args.ctgName, **pack_kw)
+            buf = self.pinned(TEXT_CHUNK + 16)
+            mv = memoryview(buf)
+            fill, eof = 0, False
+            while not eof:
+                while fill < TEXT_CHUNK:
+                    n = view.stdout.readinto(mv[fill:TEXT_CHUNK])
+                    if not n:
+                        eof = True
+                        break
+                    fill += n
+                cut = fill
+                if not eof:
+                    cut, span = -1, 1 << 20
+                    while cut < 0 and span <= 2 * fill:
+                        lo_ = max(0, fill - span)
+                        k = bytes(mv[lo_:fill]).rfind(b"\n")
+                        cut = lo_ + k + 1 if k >= 0 else -1
+                        span *= 4
+                    if cut <= 0:
+                        sys.exit("[ERROR] an alignment line longer than %d bytes" % TEXT_CHUNK)
+                elif fill and buf[fill - 1] != 10:             # the stream ended without a line end
+                    buf[fill] = 10
+                    fill = cut = fill + 1
+                if cut:
+                    t0 = time()
+                    try:
+                        f.add_text(buf.ctypes.data, cut)
+                    except _capi.MalformedText:
+                        _hostapi.SamPacker(args.ctgName, **pack_kw).feed(bytes(mv[:cut]), final=True)     # raises with the line and the column
+                        raise
+                    t_dev += time() - t0
+                buf[:fill - cut] = buf[cut:fill]
+                fill -= cut
+            pst = f.text_stats()
+        else:
+            packer = _hostapi.SamPacker(args.ctgName, **pack_kw)
+            tail = None
+            while True:
+                chunk = view.stdout.read(1 << 23)
+                if not chunk:
+                    break
                 t0 = time()
-                f.add_slab(packer)
-                t_dev += time() - t0
+                tail = packer.feed(chunk if tail is None else tail + chunk)
+                t_pack += time() - t0
+                if packer.stats()["seq_bytes"] >= SLAB_BYTES:
+                    t0 = time()
+                    f.add_slab(packer)
+                    t_dev += time() - t0
+            t0 = time()
+            if tail:
+                packer.feed(tail, final=True)
+            t_pack += time() - t0
+            t0 = time()
+            f.add_slab(packer)
+            t_dev += time() - t0
+            pst = packer.stats()
         t0 = time()
-        if tail:
-            packer.feed(tail, final=True)
-        t_pack += time() - t0
-        t0 = time()
-        f.add_slab(packer)
         view.stdout.close()
         view.wait()
         if view.returncode != 0:
             sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
-        pst = packer.stats()
         if given is None:
             if pst["evc_reads"] == 0:
                 print("No read has been process, either the genome region you specified has no read cover, or please check the correctness of your BAM input (%s)."
@@ -311,8 +355,8 @@ class DeviceFrontEnd(object):
             return self._fallback("; ".join(why for bit, why in FE_REASONS if bits & bit))
         t_dev += time() - t0
         logging.info("%d candidate sites" % n_cand)
-        logging.info("device front end: %d alignments, %d windows in %.2f s (packing the text %.2f s, device %.2f s, the rest waiting for `samtools view`)"
-                     % (f.stats()["reads"], n, time() - t_start, t_pack, t_dev))
+        logging.info("device front end: %d alignments, %d windows in %.2f s (%s, device %.2f s, the rest waiting for `samtools view`)"
+                     % (f.stats()["reads"], n, time() - t_start, "packing the text on the host %.2f s" % t_pack if t_pack else "text parsed on the device", t_dev))
         self.n_windows = n
         return n
 
@@ -484,7 +528,7 @@ def Run(args):
             if args.front_end != "host" and workers == 1:
                 # nobody on the host reads the tensors when the decode runs on the device and no BAM is consulted (cv.call_variants)
                 lean = decoder.native_applies() and lookup.sam is None and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0"
-                device_fe = DeviceFrontEnd(args, args.device)
+                device_fe = DeviceFrontEnd(args, args.device, pinned=getattr(m, "pinned_buffer", None))
                 if device_fe.run() is not None:
                     def source(batch):
                         return device_fe.batches(batch, lean=lean)

@@ -209,12 +209,19 @@ def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch
             callVarBam.main(base + ["--call_fn", out, "--front_end", fe] + extra)
             outs[fe] = open(out).read()
         assert outs["device"] == outs["host"] and len(outs["host"].splitlines()) > 30, extra
-    # many small slabs instead of one
-    monkeypatch.setattr(callVarBam, "SLAB_BYTES", 3000)
-    out = os.path.join(tmp, "slabs.vcf")
-    callVarBam.main(base + ["--call_fn", out, "--front_end", "device"])
+    # the text in many small chunks (parsed on the device), then packed on the host in many small slabs
     callVarBam.main(base + ["--call_fn", os.path.join(tmp, "h0.vcf"), "--front_end", "host"])
-    assert open(out).read() == open(os.path.join(tmp, "h0.vcf")).read()
+    monkeypatch.setattr(callVarBam, "TEXT_CHUNK", 20000)
+    monkeypatch.setattr(callVarBam, "SLAB_BYTES", 3000)
+    for pack in ("device", "host"):
+        monkeypatch.setenv("CLAIR_AMD_FE_PACK", pack)
+        out = os.path.join(tmp, "slabs_%s.vcf" % pack)
+        with caplog.at_level(logging.INFO):
+            caplog.clear()
+            callVarBam.main(base + ["--call_fn", out, "--front_end", "device"])
+        assert ("text parsed on the device" in caplog.text) == (pack == "device")
+        assert open(out).read() == open(os.path.join(tmp, "h0.vcf")).read()
+    monkeypatch.delenv("CLAIR_AMD_FE_PACK")
     monkeypatch.setattr(_capi.Frontend, "budget_binds", lambda self, available_slots=5000000: True)
     out = os.path.join(tmp, "fallback.vcf")
     with caplog.at_level(logging.INFO):
