@@ -290,10 +290,12 @@ class DeviceFrontEnd(object):
                 cut = fill
                 if not eof:
                     cut, span = -1, 1 << 20
-                    while cut < 0 and span <= 2 * fill:
+                    while cut < 0:
                         lo_ = max(0, fill - span)
                         k = bytes(mv[lo_:fill]).rfind(b"\n")
                         cut = lo_ + k + 1 if k >= 0 else -1
+                        if lo_ == 0:
+                            break
                         span *= 4
                     if cut <= 0:
                         sys.exit("[ERROR] an alignment line longer than %d bytes" % TEXT_CHUNK)
