@@ -5,7 +5,7 @@ trace and the FETCH_SIZE / WRITE_SIZE counter passes (each in its own run, never
     tools/frontend_profile_summary.py <trace.db> <fetch.db> <write.db> --elements N --positions P --windows W
 
 Counters per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): KiB per dispatch, FETCH_SIZE doubled on gfx950.  The bench runs
-the front end twice: launches are averaged.  "algorithmic" = bytes a launch has to move at least once.
+the front end four times (host-packed and device-parsed, twice each): launches are averaged.  "algorithmic" = bytes a launch has to move at least once.
 """
 import re
 import sqlite3
@@ -39,6 +39,8 @@ def main():
         "fe_scan_write_kernel": positions * (1 + 4),
         "fe_window_flags_kernel": windows * 35 * 32,
         "fe_assemble_kernel": windows * (2112 + 33 * (32 + 8) + 1056),
+        "fe_text_lines_kernel": elements * 2.03,             # every byte of the text once (SEQ + QUAL + the rest ~ 2 bytes per aligned base)
+        "fe_text_emit_kernel": elements * (16 + 4) / 8.0,     # the operations written
     }
     print("%-34s %8s %10s %10s %12s %12s %12s %14s %10s" % ("kernel", "launches", "mean_us", "grid", "fetch_MB(x2)", "write_MB", "GB/s moved", "algorithmic_MB", "GB/s alg."))
     for name in sorted(dur, key=lambda k: -sum(d for d, _ in dur[k])):
@@ -57,8 +59,9 @@ def main():
     if elements:
         for key, label in (("fe_tally", "pass 1"), ("fe_windows_per_base", "pass 2")):
             d = [x for k in dur for x, _ in dur[k] if key in k]
-            per_run = sum(d) / 2.0                      # the bench builds the front end twice
-            print("# %s: %.0f M read bases in %.0f us over %d launches = %.1f G read bases/s" % (label, elements / 1e6, per_run, len(d) // 2, elements / per_run / 1e3))
+            runs = arg("--runs", 4)                     # the bench builds the front end four times (twice per packing path)
+            per_run = sum(d) / runs
+            print("# %s: %.0f M read bases in %.0f us over %d launches = %.1f G read bases/s" % (label, elements / 1e6, per_run, len(d) // runs, elements / per_run / 1e3))
         print("# %d positions, %d windows" % (positions, windows))
 
 

@@ -91,6 +91,43 @@ def main():
                 return 1
         f.close()
     print("speed-up of the two stages: %.1fx (host %.3f s, device %.3f s with packing)" % ((t_evc + t_pile) / total, t_evc + t_pile, total))
+
+    # ---- the same with the text parsed on the device, out of a page-locked buffer (what callVarBam does with the pipe) ----
+    engine = _capi.Engine(0, 64, 1)
+    step = 256 << 20
+    pinned = engine.pinned_buffer(min(len(sam), step) + 16)
+    for rep in range(2):
+        f = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+        f.text_options(case["ctg"])
+        t_copy = t_text = 0.0
+        at = 0
+        while at < len(sam):
+            cut = len(sam) if at + step >= len(sam) else sam.rindex(b"\n", at, at + step) + 1
+            t0 = time.time()
+            pinned[:cut - at] = np.frombuffer(sam, np.uint8, cut - at, at)       # stands in for the pipe read
+            t_copy += time.time() - t0
+            t0 = time.time()
+            f.add_text(pinned.ctypes.data, cut - at)
+            t_text += time.time() - t0
+            at = cut
+        t0 = time.time()
+        n_cand = f.find_candidates(min_coverage=4, threshold=0.125)
+        n_win = f.build_windows(min_coverage=0, drop_non_iupac_centre=False)
+        binds = f.budget_binds()
+        t_rest = time.time() - t0
+        print("device, text parsed on the device: copy + parse + tally %.3f s (%.0f MB/s of text) | candidates + windows + budget replay %.3f s  = %.3f s -> %d candidates, "
+              "%d windows, anomalies %d, budget binds: %s   (filling the page-locked buffer, the pipe read's stand-in: %.3f s)"
+              % (t_text, len(sam) / 1e6 / t_text, t_rest, t_text + t_rest, n_cand, n_win, f.stats()["anomalies"], binds, t_copy))
+        if rep == 0:
+            centres, seqs = f.window_info(0, n_win)
+            same = (np.array_equal(f.candidates(), want_pos) and np.array_equal(centres, hc) and np.array_equal(seqs, hs)
+                    and np.array_equal(f.window_counts(0, n_win).astype(np.int32), hcounts))
+            print("device (text) == host: %s" % same)
+            if not same and not binds:
+                return 1
+        f.close()
+    print("speed-up of the two stages with the text parsed on the device: %.1fx (host %.3f s, device %.3f s)" % ((t_evc + t_pile) / (t_text + t_rest), t_evc + t_pile, t_text + t_rest))
+    engine.close()
     return 0
 
 
