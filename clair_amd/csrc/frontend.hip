@@ -409,6 +409,20 @@ struct TextState {                       // carried from chunk to chunk (host co
 
 __device__ inline bool text_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
 
+// end of the token that starts at q: 16 bytes at a time while none of them is below 0x21 (every white-space character is; SEQ and QUAL
+// bytes are not), byte by byte from the first word that holds one
+__device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
+    while (q < end && (q & 15)) { if (text_space(t[q])) return q; ++q; }
+    while (q + 16 <= end) {
+        const uint4 w = *(const uint4 *)(t + q);
+        const uint32_t low = ((w.x - 0x21212121u) & ~w.x) | ((w.y - 0x21212121u) & ~w.y) | ((w.z - 0x21212121u) & ~w.z) | ((w.w - 0x21212121u) & ~w.w);
+        if (low & 0x80808080u) break;
+        q += 16;
+    }
+    while (q < end && !text_space(t[q])) ++q;
+    return q;
+}
+
 // walks a CIGAR; EMIT writes the kept operations
 template <bool EMIT>
 __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
@@ -477,8 +491,7 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     while (p < end && n < 10) {
         while (p < end && text_space(text[p])) ++p;
         if (p >= end) break;
-        int64_t q = p;
-        while (q < end && !text_space(text[q])) ++q;
+        const int64_t q = token_end(text, p, end);
         col[n] = (uint32_t)p;
         len[n] = (uint32_t)(q - p);
         ++n;
