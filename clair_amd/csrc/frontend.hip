@@ -55,11 +55,17 @@ struct Region {          // what every kernel needs to know about the tables and
     int64_t lo, n;       // tables cover 0-based positions [lo, lo + n)
     const uint8_t *ref;  // upper-cased reference bytes for [ref0, ref0 + ref_len)
     int64_t ref0, ref_len;
-    uint32_t *ev;        // [n][8]  A C G T I D N -          candidate-search tallies
-    uint32_t *q;         // [n][8]  read-base row + 4 * strand, M of pileup reads
-    uint32_t *misc;      // [n][8]  0,1 M per strand | 2,3 D per strand (rp > POS) | 4 D at rp == POS | 5 inserted bases (rp > POS) | 6 M at rp == POS
+    // Per position and base row b (A C G T, IUPAC codes mapped as the scripts map them) ONE 64-bit word of three 21-bit counters, so that
+    // a matched base costs one atomic: bits 0-20 pileup reads on the forward strand with read base b, 21-41 the same on the reverse
+    // strand, 42-62 the candidate search's tally of b.  (Matched bases per strand = the sum over the four rows.)
+    unsigned long long *pq;   // [n][4]
+    uint32_t *misc;      // [n][8]  0,1 D per strand (rp > POS) | 2 D at rp == POS | 3 inserted bases (rp > POS) | 4 M at rp == POS | 5,6,7 the search's I, D, N tallies
     uint32_t *anomalies;
 };
+
+constexpr int PQ_BITS = 21;
+constexpr unsigned long long PQ_MASK = (1ull << PQ_BITS) - 1;
+__device__ inline uint32_t pq_field(unsigned long long w, int field) { return (uint32_t)((w >> (field * PQ_BITS)) & PQ_MASK); }
 
 struct Slab {
     clair_read_t *reads = nullptr;
@@ -127,25 +133,30 @@ __global__ __launch_bounds__(256) void fe_tally_kernel(Region g, SlabView s) {
         const uint8_t ei = BASES.evc[base];
         if (ei == 255) { flag(g, CLAIR_FE_BAD_BASE); return; }
         if (!inside) return;
-        if (evc) atomicAdd(&g.ev[t * 8 + ei], 1u);
-        if (pile) {
-            atomicAdd(&g.q[t * 8 + BASES.pile[base] + 4 * so], 1u);
-            atomicAdd(&g.misc[t * 8 + so], 1u);
-            if (el.rp == el.r.pos0) atomicAdd(&g.misc[t * 8 + 6], 1u);
+        // the search's base index and the pileup's row agree for every code but N (tally N, row of A)
+        const int row = BASES.pile[base];
+        unsigned long long add = pile ? 1ull << (so * PQ_BITS) : 0;
+        if (evc && ei < 4) add += 1ull << (2 * PQ_BITS);
+        if (add) {
+            const unsigned long long before = atomicAdd(&g.pq[t * 4 + row], add);
+            if ((pile && pq_field(before, so) == PQ_MASK) || (evc && ei < 4 && pq_field(before, 2) == PQ_MASK))
+                flag(g, CLAIR_FE_OVERFLOW);                     // a counter was full: 2 097 151 reads over one position
         }
+        if (evc && ei >= 4) atomicAdd(&g.misc[t * 8 + 7], 1u);
+        if (pile && el.rp == el.r.pos0) atomicAdd(&g.misc[t * 8 + 4], 1u);
     } else if (el.code == CLAIR_OP_I) {
-        if (el.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) atomicAdd(&g.ev[(t - 1) * 8 + 4], 1u);   // once per operation, at the base before it
+        if (el.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) atomicAdd(&g.misc[(t - 1) * 8 + 5], 1u);   // once per operation, at the base before it
         if (!pile) return;
         if (el.qp >= el.r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); return; }
         if (el.rp <= el.r.pos0) return;                                                              // no window is open yet (CreateTensor.py:326-341)
         if (BASES.pile[s.seq[el.r.seq0 + el.qp]] == 255) flag(g, CLAIR_FE_BAD_BASE);
-        if (inside) atomicAdd(&g.misc[t * 8 + 5], 1u);
+        if (inside) atomicAdd(&g.misc[t * 8 + 3], 1u);
     } else {
-        if (el.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) atomicAdd(&g.ev[(t - 1) * 8 + 5], 1u);
+        if (el.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) atomicAdd(&g.misc[(t - 1) * 8 + 6], 1u);
         if (!pile || !inside) return;
         if (ref_row(g, el.rp) == 255) flag(g, CLAIR_FE_BAD_REF);
-        if (el.rp > el.r.pos0) atomicAdd(&g.misc[t * 8 + 2 + so], 1u);
-        else atomicAdd(&g.misc[t * 8 + 4], 1u);
+        if (el.rp > el.r.pos0) atomicAdd(&g.misc[t * 8 + so], 1u);
+        else atomicAdd(&g.misc[t * 8 + 2], 1u);
     }
 }
 
@@ -160,8 +171,9 @@ struct CandidateRule {
 __global__ __launch_bounds__(256) void fe_candidate_flags_kernel(Region g, CandidateRule rule, uint8_t *flags) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= g.n) return;
-    const uint4 lo4 = *(const uint4 *)(g.ev + t * 8), hi4 = *(const uint4 *)(g.ev + t * 8 + 4);
-    const uint32_t n[7] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z};
+    const ulonglong2 w01 = *(const ulonglong2 *)(g.pq + t * 4), w23 = *(const ulonglong2 *)(g.pq + t * 4 + 2);
+    const uint4 hi4 = *(const uint4 *)(g.misc + t * 8 + 4);
+    const uint32_t n[7] = {pq_field(w01.x, 2), pq_field(w01.y, 2), pq_field(w23.x, 2), pq_field(w23.y, 2), hi4.y, hi4.z, hi4.w};
     uint8_t keep = 0;
     do {
         if (!(n[0] | n[1] | n[2] | n[3] | n[4] | n[5] | n[6])) break;       // not a key of the reference's dict
@@ -332,12 +344,16 @@ __global__ __launch_bounds__(256) void fe_window_flags_kernel(Region g, const in
     for (int64_t rp = c - 17; rp <= c + 17; ++rp) {
         const int64_t t = rp - g.lo;
         if (t < 0 || t >= g.n) continue;
-        const uint4 a = *(const uint4 *)(g.misc + t * 8), b = *(const uint4 *)(g.misc + t * 8 + 4);
-        const uint64_t m = (uint64_t)a.x + a.y, d = (uint64_t)a.z + a.w;
-        if (rp <= c + 16) walked += m + d + b.x;                    // M or D (incl. a read's first D) opens the window
+        const ulonglong2 w01 = *(const ulonglong2 *)(g.pq + t * 4), w23 = *(const ulonglong2 *)(g.pq + t * 4 + 2);
+        const uint4 a = *(const uint4 *)(g.misc + t * 8);
+        const uint32_t start_m = g.misc[t * 8 + 4];
+        uint64_t m = 0;
+        for (int field = 0; field < 2; ++field) m += (uint64_t)pq_field(w01.x, field) + pq_field(w01.y, field) + pq_field(w23.x, field) + pq_field(w23.y, field);
+        const uint64_t d = (uint64_t)a.x + a.y;
+        if (rp <= c + 16) walked += m + d + a.z;                    // M or D (incl. a read's first D) opens the window
         tuples += m;
-        if (rp == c + 17) tuples -= b.z;                            // a read that STARTS there never opened this window
-        if (rp >= c - 16) tuples += d + b.y;
+        if (rp == c + 17) tuples -= start_m;                        // a read that STARTS there never opened this window
+        if (rp >= c - 16) tuples += d + a.w;
         if (rp == c - 1) depth_centre = (uint32_t)m;
     }
     const bool opened = walked > 0;
@@ -362,9 +378,11 @@ __global__ __launch_bounds__(256) void fe_assemble_kernel(Region g, const int64_
     const int64_t rp = c - 17 + idx, t = rp - g.lo;
     uint32_t qv = 0, mw = 0, dw = 0;
     if (t >= 0 && t < g.n) {
-        qv = g.q[t * 8 + row];
-        mw = g.misc[t * 8 + so];
-        dw = g.misc[t * 8 + 2 + so];
+        const ulonglong2 w01 = *(const ulonglong2 *)(g.pq + t * 4), w23 = *(const ulonglong2 *)(g.pq + t * 4 + 2);
+        const unsigned long long w[4] = {w01.x, w01.y, w23.x, w23.y};
+        qv = pq_field(w[b], so);
+        mw = pq_field(w[0], so) + pq_field(w[1], so) + pq_field(w[2], so) + pq_field(w[3], so);
+        dw = g.misc[t * 8 + so];
     }
     const bool is_ref = ref_row(g, rp) == b;
     const uint32_t ch0 = is_ref ? mw : 0, ch1 = qv + ins[((size_t)ci * N_POS + idx) * N_ROW + row];
@@ -781,17 +799,15 @@ int clair_frontend_create(int device, const char *ref_seq, int64_t ref_len, int6
     if ((err = hipMalloc((void **)&f->d_ref, (size_t)std::max<int64_t>(ref_len, 1))) != hipSuccess) return bail("hipMalloc(reference)", err);
     if ((err = hipMemcpy(f->d_ref, ref_seq, (size_t)ref_len, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(reference)", err);
     g.ref = f->d_ref;
-    const size_t table = (size_t)g.n * 8 * sizeof(uint32_t);
-    if ((err = hipMalloc((void **)&g.ev, table)) != hipSuccess) return bail("hipMalloc(tallies)", err);
-    if ((err = hipMalloc((void **)&g.q, table)) != hipSuccess) return bail("hipMalloc(read-base rows)", err);
+    const size_t table = (size_t)g.n * 32;
+    if ((err = hipMalloc((void **)&g.pq, table)) != hipSuccess) return bail("hipMalloc(read-base counters)", err);
     if ((err = hipMalloc((void **)&g.misc, table)) != hipSuccess) return bail("hipMalloc(counts)", err);
     if ((err = hipMalloc((void **)&g.anomalies, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void **)&f->d_flags, (size_t)g.n + 1)) != hipSuccess) return bail("hipMalloc(flags)", err);
     if ((err = hipMalloc((void **)&f->d_before, ((size_t)g.n + 1) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(prefix)", err);
     if ((err = hipMalloc((void **)&f->d_block_sum, ((size_t)blocks_for(g.n + 1, SCAN_BLOCK) + 1) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", err);
     if ((err = hipMalloc((void **)&f->d_total, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", err);
-    (void)hipMemsetAsync(g.ev, 0, table, f->stream);
-    (void)hipMemsetAsync(g.q, 0, table, f->stream);
+    (void)hipMemsetAsync(g.pq, 0, table, f->stream);
     (void)hipMemsetAsync(g.misc, 0, table, f->stream);
     (void)hipMemsetAsync(g.anomalies, 0, sizeof(uint32_t), f->stream);
     if ((err = hipStreamSynchronize(f->stream)) != hipSuccess) return bail("hipMemset", err);
@@ -807,7 +823,7 @@ void clair_frontend_destroy(clair_frontend_t *f) {
         (void)hipFree(s.reads); (void)hipFree(s.ops); (void)hipFree(s.op_elem); (void)hipFree(s.seq); (void)hipFree(s.tuples);
     }
     free_candidates(f);
-    (void)hipFree(f->d_ref); (void)hipFree(f->g.ev); (void)hipFree(f->g.q); (void)hipFree(f->g.misc); (void)hipFree(f->g.anomalies);
+    (void)hipFree(f->d_ref); (void)hipFree(f->g.pq); (void)hipFree(f->g.misc); (void)hipFree(f->g.anomalies);
     (void)hipFree(f->d_flags); (void)hipFree(f->d_before); (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_bed);
     (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state);
     if (f->stream) (void)hipStreamDestroy(f->stream);
