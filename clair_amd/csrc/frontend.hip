@@ -10,7 +10,7 @@
 // code) -- is in oracle/frontend_np.py, the NumPy restatement these kernels are tested against, and in DESIGN.md 6b.
 //
 // All integer work, HBM/atomic bound: nothing here is a matrix product.  Tables are sized for the whole region and the packed reads
-// stay resident (a 10 Mb region at 50x: ~1 GB of tables, ~1.3 GB of reads; a whole chromosome fits the 288 GB many times over), so
+// stay resident (a 10 Mb region at 50x: ~0.7 GB of tables, 1.3 - 2.1 GB of reads; a whole chromosome fits the 288 GB many times over), so
 // there is no streaming window to manage and pass 2 re-reads the reads from HBM instead of from the host.
 #include "../../include/clair_amd.h"
 #include "../../include/clair_reads.h"
