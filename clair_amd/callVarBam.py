@@ -196,7 +196,7 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
 
 
 SLAB_BYTES = 64 << 20      # SEQ bytes per slab of packed alignments sent to the device (host packer)
-TEXT_CHUNK = 256 << 20     # bytes of `samtools view` text handed to the device at a time (device parser)
+TEXT_CHUNK = 64 << 20      # bytes of `samtools view` text handed to the device at a time (device parser; the page-locked buffer it is read into)
 TABLE_MARGIN = 64          # positions the device tables extend beyond the region (a window reaches 17 beyond its centre)
 FE_REASONS = ((1, "alignments not sorted by position"), (2, "a zero-length insertion/deletion"), (4, "an alignment spanning > 100 kb more than its bases"),
               (8, "a CIGAR longer than its SEQ"), (16, "a read base outside the IUPAC alphabet"), (32, "a reference base outside the IUPAC alphabet"),

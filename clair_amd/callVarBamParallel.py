@@ -60,6 +60,7 @@ def commands(args):
         _flag("stop_consider_left_edge", args.stop_consider_left_edge), _flag("debug", args.debug),
         _flag("pysam_for_all_indel_bases", args.pysam_for_all_indel_bases), _flag("haploid_precision", args.haploid_precision),
         _flag("haploid_sensitive", args.haploid_sensitive), _flag("output_for_ensemble", args.output_for_ensemble),
+        _opt("front_end", args.front_end), _opt("batch_size", args.batch_size),
     ] if x is not None)
     out, k = [], 0
     with open(fai_fn) as fai:
@@ -118,6 +119,8 @@ def build_parser():
     # additions of this implementation
     add('--devices', type=int, default=1, help="deal the chunks round-robin over this many GPUs (--device k)")
     add('--python', type=str, default=None, help="interpreter to put in the commands, default: the running one")
+    add('--front_end', type=str, default=None, choices=("auto", "device", "host"), help="passed on (callVarBam: where the candidate search and the pileup run)")
+    add('--batch_size', type=int, default=None, help="passed on (callVarBam: candidates per forward pass)")
     return parser
 
 

@@ -226,3 +226,101 @@ def test_differential_fuzz_of_the_column_formulation(block):
         w = col.windows(want_pos, min_cov=pile_kw["min_coverage"])
         assert col.anomalies == 0, seed
         assert np.array_equal(hc, w["centres"]) and np.array_equal(hs, w["refseq"]) and np.array_equal(hcounts, w["counts"]), seed
+
+
+# ---- callVarBam's device front end driver with a stand-in for the device (the restatement behind the Frontend interface) ---------------
+class _StandInFrontend(object):
+    """What clair_amd.callVarBam.DeviceFrontEnd uses of clair_amd._capi.Frontend, computed by oracle/frontend_np.py."""
+
+    def __init__(self, device, ref, ref0, lo, hi):
+        self.ref, self.ref0, self.lo, self.hi = ref, ref0, lo, hi
+        self.text, self.chunks, self.col, self.w = [], [], None, None
+        self.slab_reads = []
+
+    def text_options(self, ctg, **kw):
+        self.ctg, self.kw = ctg, kw
+
+    def add_text(self, address, length):
+        import ctypes
+        piece = ctypes.string_at(address, length)
+        assert piece.endswith(b"\n") and length > 0
+        self.chunks.append(length)
+        self.text.append(piece)
+
+    def _columns(self):
+        if self.col is None:
+            self.packed = fe.pack_sam(b"".join(self.text), self.ctg, **self.kw)
+            self.col = fe.Columns(self.ref, self.ref0, self.lo, self.hi)
+            self.col.add_reads(self.packed)
+        return self.col
+
+    def text_stats(self):
+        self._columns()
+        fl = self.packed["flags"]
+        return dict(lines=self.packed["lines"], evc_reads=int(((fl & fe.F_EVC) != 0).sum()), pile_reads=int(((fl & fe.F_PILE) != 0).sum()), anomalies=self.packed["anomalies"])
+
+    def find_candidates(self, min_coverage=4, threshold=0.125, ctg_start=None, ctg_end=None, bed=None):
+        assert bed is None
+        self.pos = self._columns().candidates(min_depth=min_coverage, min_af=threshold, ctg_range=(ctg_start, ctg_end) if ctg_start is not None else None)
+        return len(self.pos)
+
+    def set_candidates(self, positions):
+        self.pos = np.asarray(positions, np.int64)
+        return len(self.pos)
+
+    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True):
+        w = self._columns().windows(self.pos, min_cov=min_coverage)
+        keep = w["centre_ok"] if drop_non_iupac_centre else np.ones(len(w["centres"]), bool)
+        self.w = {k: w[k][keep] for k in ("centres", "refseq", "counts")}
+        return len(self.w["centres"])
+
+    def stats(self):
+        return dict(anomalies=self._columns().anomalies & ~fe.A_BUDGET, slabs=1, reads=len(self.packed["pos0"]), elements=0,
+                    candidates=len(self.pos), windows=-1 if self.w is None else len(self.w["centres"]))
+
+    def budget_binds(self, available_slots=5000000):
+        return bool(self._columns().anomalies & fe.A_BUDGET)
+
+    def window_info(self, first, n):
+        return self.w["centres"][first:first + n], self.w["refseq"][first:first + n]
+
+    def window_counts(self, first, n):
+        return self.w["counts"][first:first + n].astype(np.int16)
+
+    def counts_address(self, first):
+        return 1
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
+@pytest.mark.parametrize("chunk", [3000, 1 << 20])
+def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, region, chunk):
+    """clair_amd.callVarBam.DeviceFrontEnd: the pipe read into a "page-locked" buffer in chunks, whole lines handed on, the unfinished
+    line carried over, a stream that ends without a line end -- the batches it yields = those of the host stages (tensor_batches)."""
+    import pileup_synth
+    from clair_amd import _capi, callVarBam
+    tmp = str(tmp_path)
+    case = pileup_synth.synth_case(seed=301)
+    fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\nchrOther\t120\t3100\t120\t121\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"].rstrip("\n"))                       # no line end after the last alignment
+    fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
+    args = callVarBam.build_parser().parse_args(["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", fake, "--threshold", "0.15",
+                                                 "--minCoverage", "5"] + region)
+    positions = callVarBam.candidate_positions(args, quiet=True)
+    want = list(callVarBam.tensor_batches(args, positions, 64, progress=False))
+    monkeypatch.setattr(_capi, "Frontend", _StandInFrontend)
+    monkeypatch.setattr(callVarBam, "TEXT_CHUNK", chunk)
+    d = callVarBam.DeviceFrontEnd(args, 0, pinned=lambda n: np.zeros(n, np.uint8))
+    assert d.run() == sum(len(b[1]) for b in want) > 100
+    assert len(d.frontend.chunks) == (1 if chunk > 100000 else len(d.frontend.chunks)) and (chunk > 100000 or len(d.frontend.chunks) > 10)
+    got = list(d.batches(64, lean=False, progress=False))
+    assert len(got) == len(want)
+    for (gx, ginfo, gc), (wx, winfo, wc) in zip(got, want):
+        assert np.array_equal(gx, wx) and np.array_equal(gc, wc)
+        assert [list(map(str, r)) for r in ginfo] == [list(map(str, r)) for r in winfo]
+    lean = list(d.batches(64, lean=True, progress=False))
+    assert all(x is None and isinstance(c, _capi.DeviceWindows) and len(c) == len(i) for x, i, c in lean)

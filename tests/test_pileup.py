@@ -367,6 +367,8 @@ def test_callVarBamParallel_commands_match_reference():
             assert got == want, name
             dealt = par.commands(par.build_parser().parse_args(argv + ["--devices", "8"]))
             assert [l.rsplit(" ", 2)[1:] for l in dealt] == [["--device", '"%d"' % (i % 8)] for i in range(len(dealt))]
+            passed = par.commands(par.build_parser().parse_args(argv + ["--front_end", "host", "--batch_size", "4096"]))
+            assert all(' --front_end "host" --batch_size "4096" ' in l for l in passed) and len(passed) == len(got)
 
 
 def test_binary_tensor_records_equal_the_text_records(tmp_path):
