@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The device front end against the sequential host stages on the same alignments (run on the GPU box):
 
-    python tools/gpu/frontend_bench.py [ref_len] [noisy_every] [depth]
+    python tools/gpu/frontend_bench.py [ref_len] [noisy_every] [depth] [read_len_min read_len_max]
 
 Synthetic contig at 50x with 2-9 kb reads (tools/fast_reads.py, the inputs of tools/e2e_bam_bench.py; one candidate site per
 ~2 x noisy_every bases).  Prints the time of every
@@ -26,8 +26,9 @@ def main():
     ref_len = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     noisy_every = int(sys.argv[2]) if len(sys.argv) > 2 else 25
     depth = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    read_len = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (2000, 9000)
     t0 = time.time()
-    case = fast_reads.make(ref_len=ref_len, depth=depth, noisy_every=noisy_every, seed=5)
+    case = fast_reads.make(ref_len=ref_len, depth=depth, noisy_every=noisy_every, seed=5, read_len=read_len)
     case["ref0"] = 0
     sam = case["sam"]
     print("inputs: %.1f MB of SAM text, %d alignments over %d bases (%.0f s to generate)" % (len(sam) / 1e6, sam.count(b"\n"), ref_len, time.time() - t0))
