@@ -25,7 +25,7 @@ SYMBOLS = (
     "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
     "clair_frontend_create", "clair_frontend_destroy", "clair_frontend_last_error", "clair_frontend_add_reads",
     "clair_frontend_find_candidates", "clair_frontend_set_candidates", "clair_frontend_get_candidates", "clair_frontend_build_windows",
-    "clair_frontend_window_info", "clair_frontend_window_counts", "clair_frontend_counts_device", "clair_frontend_budget_inputs",
+    "clair_frontend_build_windows_ex", "clair_frontend_window_info", "clair_frontend_window_counts", "clair_frontend_counts_device", "clair_frontend_budget_inputs",
     "clair_frontend_stats", "clair_frontend_text_options", "clair_frontend_add_text", "clair_frontend_text_stats", "clair_frontend_slab_reads",
 )
 KERNEL_NAMES = ("proj1", "lstm1", "proj2", "lstm2", "l3", "l4", "tail", "decode")
@@ -109,6 +109,7 @@ def load(path=None):
         lib.clair_frontend_set_candidates.argtypes = [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)]
         lib.clair_frontend_get_candidates.argtypes = [c_vp, c_vp]
         lib.clair_frontend_build_windows.argtypes = [c_vp, c_int, c_int, ctypes.POINTER(c_i64)]
+        lib.clair_frontend_build_windows_ex.argtypes = [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_i64)]
         lib.clair_frontend_window_info.argtypes = [c_vp, c_i64, c_i64, c_vp, c_vp]
         lib.clair_frontend_window_counts.argtypes = [c_vp, c_i64, c_i64, c_vp]
         lib.clair_frontend_counts_device.argtypes = [c_vp, c_i64]
@@ -471,10 +472,10 @@ class Frontend(object):
         self._check(self._lib.clair_frontend_get_candidates(self._h, _ptr(out)), "clair_frontend_get_candidates")
         return out
 
-    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True):
+    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True, consider_left_edge=True):
         n = ctypes.c_int64(0)
-        self._check(self._lib.clair_frontend_build_windows(self._h, int(min_coverage), int(bool(drop_non_iupac_centre)), ctypes.byref(n)),
-                    "clair_frontend_build_windows")
+        self._check(self._lib.clair_frontend_build_windows_ex(self._h, int(min_coverage), int(bool(drop_non_iupac_centre)), int(bool(consider_left_edge)),
+                                                              ctypes.byref(n)), "clair_frontend_build_windows")
         return int(n.value)
 
     def window_info(self, first, n):

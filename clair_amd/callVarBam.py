@@ -231,8 +231,6 @@ class DeviceFrontEnd(object):
     def run(self):
         from . import _capi, _hostapi
         args = self.args
-        if args.stop_consider_left_edge:
-            return self._fallback("--stop_consider_left_edge")
         have_range = args.ctgStart is not None and args.ctgEnd is not None
         given = None
         if args.vcf_fn is not None:
@@ -349,7 +347,7 @@ class DeviceFrontEnd(object):
         else:
             f.set_candidates(given)
             n_cand = len(given)
-        n = f.build_windows(min_coverage=0, drop_non_iupac_centre=True)
+        n = f.build_windows(min_coverage=0, drop_non_iupac_centre=True, consider_left_edge=not args.stop_consider_left_edge)
         bits = pst["anomalies"] | f.stats()["anomalies"]
         if not bits and f.budget_binds():
             bits = 128

@@ -277,7 +277,12 @@ struct Candidates {
     const int64_t *centre;       // 1-based, ascending
     const uint32_t *before;      // before[t] = candidates with centre - 1 - lo < t; n + 1 entries
     uint32_t *ins;               // [n_candidates][33][8]
+    // --stop_consider_left_edge only (NULL otherwise): what reads that START inside a window added to the tables under it -- per
+    // window and column 8 read-base rows, M per strand, D per strand -- and the tuples per window as range additions over the index
+    uint32_t *late;              // [n_candidates][33][12]
+    int *tuple_diff;             // [n_candidates + 1]
 };
+constexpr int LATE_ROW = 12;
 
 __device__ inline uint32_t before_at(const Region &g, const Candidates &c, int64_t t) {
     return c.before[t < 0 ? 0 : (t > g.n ? g.n : t)];
@@ -291,6 +296,8 @@ __global__ __launch_bounds__(256) void fe_windows_per_base_kernel(Region g, Slab
         const Element el = element_of(s, e);
         if (el.r.flags & CLAIR_READ_PILE) {
             // centres whose window is open while this base is offered (CreateTensor.py:296-361)
+            const bool left_edge = c.late == nullptr;
+            const int so = (el.r.flags & CLAIR_READ_REVERSE) ? 4 : 0;
             int64_t a = -1, b = -2;
             if (el.code == CLAIR_OP_M) {
                 a = el.rp > el.r.pos0 ? el.rp - 17 : el.r.pos0 - 16;
@@ -299,13 +306,32 @@ __global__ __launch_bounds__(256) void fe_windows_per_base_kernel(Region g, Slab
                 a = el.rp - 17;
                 b = el.rp + 16;
             }
-            if (b >= a) nc = before_at(g, c, b - g.lo) - before_at(g, c, a - 1 - g.lo);
+            // without left-edge windows a read opens only the windows whose first column it walks: centres from POS + 17 on
+            if (!left_edge && a < el.r.pos0 + 17) a = el.r.pos0 + 17;
+            if (b >= a) {
+                const uint32_t i0 = before_at(g, c, a - 1 - g.lo), i1 = before_at(g, c, b - g.lo);
+                nc = i1 - i0;
+                if (!left_edge && nc) { atomicAdd(&c.tuple_diff[i0], 1); atomicSub(&c.tuple_diff[i1], 1); }
+            }
             read = el.read;
+            if (!left_edge && el.rp - el.r.pos0 <= 31 && (el.code == CLAIR_OP_M || (el.code == CLAIR_OP_D && el.rp > el.r.pos0))) {
+                // ... and what this base put into the tables belongs to none of the windows it starts inside: centres rp - 15 .. POS + 16
+                const uint8_t row = el.code == CLAIR_OP_M && el.qp < el.r.seq_len ? BASES.pile[s.seq[el.r.seq0 + el.qp]] : (uint8_t)255;
+                if (el.code == CLAIR_OP_D || row != 255) {
+                    const uint32_t j0 = before_at(g, c, el.rp - 15 - 1 - g.lo), j1 = before_at(g, c, el.r.pos0 + 16 - g.lo);
+                    for (uint32_t j = j0; j < j1; ++j) {
+                        uint32_t *cell = c.late + ((size_t)j * N_POS + (el.rp - c.centre[j] + 17)) * LATE_ROW;
+                        if (el.code == CLAIR_OP_M) { atomicAdd(cell + row + so, 1u); atomicAdd(cell + 8 + (so >> 2), 1u); }
+                        else atomicAdd(cell + 10 + (so >> 2), 1u);
+                    }
+                }
+            }
             if (el.code == CLAIR_OP_I && el.rp > el.r.pos0 && el.qp < el.r.seq_len) {
                 const uint8_t row = BASES.pile[s.seq[el.r.seq0 + el.qp]];
                 if (row != 255) {
-                    const int so = (el.r.flags & CLAIR_READ_REVERSE) ? 4 : 0;
-                    const uint32_t i0 = before_at(g, c, el.rp - 15 - 1 - g.lo), i1 = before_at(g, c, el.rp + 16 - g.lo);
+                    int64_t first = el.rp - 15;
+                    if (!left_edge && first < el.r.pos0 + 17) first = el.r.pos0 + 17;
+                    const uint32_t i0 = before_at(g, c, first - 1 - g.lo), i1 = before_at(g, c, el.rp + 16 - g.lo);
                     for (uint32_t i = i0; i < i1; ++i) {       // generate_tensor :51-53: column min(idx + k, 32), channel 1
                         const int64_t col = el.rp - c.centre[i] + 17 + (int64_t)el.k;
                         atomicAdd(&c.ins[((size_t)i * N_POS + (col < N_POS - 1 ? col : N_POS - 1)) * N_ROW + row + so], 1u);
@@ -332,7 +358,23 @@ __global__ __launch_bounds__(256) void fe_windows_per_base_kernel(Region g, Slab
 struct WindowRule {
     int min_coverage;
     int drop_non_iupac_centre;   // clair/utils.py:90-91
+    const uint32_t *late;        // --stop_consider_left_edge: see Candidates; window_tuples then comes in filled (fe_window_totals_kernel)
 };
+
+// --stop_consider_left_edge: tuples per window = running sum of the range additions of pass 2
+__global__ __launch_bounds__(256) void fe_window_totals_kernel(const int *diff, int64_t n_candidates, uint64_t *window_tuples) {
+    long long carry = 0;
+    for (int64_t at = 0; at < n_candidates; at += 256) {
+        const int64_t i = at + threadIdx.x;
+        const int v = i < n_candidates ? diff[i] : 0;
+        // signed values: scan the positive and the negative parts apart (the exclusive scan is unsigned)
+        uint32_t tp, tn;
+        const uint32_t ep = block_exclusive_scan(v > 0 ? (uint32_t)v : 0u, &tp);
+        const uint32_t en = block_exclusive_scan(v < 0 ? (uint32_t)(-v) : 0u, &tn);
+        if (i < n_candidates) window_tuples[i] = (uint64_t)(carry + (long long)ep - (long long)en + v);
+        carry += (long long)tp - (long long)tn;
+    }
+}
 
 __global__ __launch_bounds__(256) void fe_window_flags_kernel(Region g, const int64_t *centre, int64_t n_candidates, WindowRule rule,
                                                               uint8_t *keep, uint64_t *window_tuples) {
@@ -350,13 +392,18 @@ __global__ __launch_bounds__(256) void fe_window_flags_kernel(Region g, const in
         uint64_t m = 0;
         for (int field = 0; field < 2; ++field) m += (uint64_t)pq_field(w01.x, field) + pq_field(w01.y, field) + pq_field(w23.x, field) + pq_field(w23.y, field);
         const uint64_t d = (uint64_t)a.x + a.y;
-        if (rp <= c + 16) walked += m + d + a.z;                    // M or D (incl. a read's first D) opens the window
+        if (rule.late ? rp == c - 17 : rp <= c + 16) walked += m + d + a.z;   // M or D (incl. a read's first D) opens the window
         tuples += m;
         if (rp == c + 17) tuples -= start_m;                        // a read that STARTS there never opened this window
         if (rp >= c - 16) tuples += d + a.w;
         if (rp == c - 1) depth_centre = (uint32_t)m;
     }
     const bool opened = walked > 0;
+    if (rule.late) {
+        const uint32_t *cell = rule.late + ((size_t)i * N_POS + 16) * LATE_ROW;
+        depth_centre -= cell[8] + cell[9];
+        tuples = window_tuples[i];
+    }
     const int64_t nrp = c - g.ref0;
     bool ok = opened && nrp - 17 >= 0 && (int64_t)depth_centre >= (int64_t)rule.min_coverage;
     if (ok && rule.drop_non_iupac_centre) {
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(256) void fe_window_flags_kernel(Region g, const in
 
 // ---- assembly: 264 (position, row) quads per kept window ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fe_assemble_kernel(Region g, const int64_t *centre, const int64_t *kept, int64_t n_kept, const uint32_t *ins,
-                                                          short4 *counts, int64_t *out_centre, uint8_t *out_refseq) {
+                                                          const uint32_t *late, short4 *counts, int64_t *out_centre, uint8_t *out_refseq) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t o = id / N_QUAD;
     if (o >= n_kept) return;
@@ -383,6 +430,12 @@ __global__ __launch_bounds__(256) void fe_assemble_kernel(Region g, const int64_
         qv = pq_field(w[b], so);
         mw = pq_field(w[0], so) + pq_field(w[1], so) + pq_field(w[2], so) + pq_field(w[3], so);
         dw = g.misc[t * 8 + so];
+    }
+    if (late) {
+        const uint32_t *cell = late + ((size_t)ci * N_POS + idx) * LATE_ROW;
+        qv -= cell[row];
+        mw -= cell[8 + so];
+        dw -= cell[10 + so];
     }
     const bool is_ref = ref_row(g, rp) == b;
     const uint32_t ch0 = is_ref ? mw : 0, ch1 = qv + ins[((size_t)ci * N_POS + idx) * N_ROW + row];
@@ -670,6 +723,8 @@ struct clair_frontend {
     int64_t *d_bed = nullptr;
     // windows
     uint32_t *d_ins = nullptr;
+    uint32_t *d_late = nullptr;          // --stop_consider_left_edge only
+    int *d_tuple_diff = nullptr;
     uint8_t *d_keep = nullptr;
     uint64_t *d_window_tuples = nullptr;
     int64_t *d_kept = nullptr;
@@ -741,6 +796,8 @@ int scan_write(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *blo
 void free_candidates(clair_frontend *f) {
     (void)hipFree(f->d_centre); f->d_centre = nullptr;
     (void)hipFree(f->d_ins); f->d_ins = nullptr;
+    (void)hipFree(f->d_late); f->d_late = nullptr;
+    (void)hipFree(f->d_tuple_diff); f->d_tuple_diff = nullptr;
     (void)hipFree(f->d_keep); f->d_keep = nullptr;
     (void)hipFree(f->d_window_tuples); f->d_window_tuples = nullptr;
     (void)hipFree(f->d_kept); f->d_kept = nullptr;
@@ -1061,6 +1118,10 @@ int clair_frontend_get_candidates(clair_frontend_t *f, int64_t *positions) {
 }
 
 int clair_frontend_build_windows(clair_frontend_t *f, int min_coverage, int drop_non_iupac_centre, int64_t *n_windows) {
+    return clair_frontend_build_windows_ex(f, min_coverage, drop_non_iupac_centre, 1, n_windows);
+}
+
+int clair_frontend_build_windows_ex(clair_frontend_t *f, int min_coverage, int drop_non_iupac_centre, int consider_left_edge, int64_t *n_windows) {
     if (!f) return fe_fail(nullptr, "front end is NULL");
     if (!n_windows) return fe_fail(f, "n_windows is NULL");
     if (f->n_candidates < 0) return fe_fail(f, "no candidates yet: call clair_frontend_find_candidates / _set_candidates first");
@@ -1074,12 +1135,22 @@ int clair_frontend_build_windows(clair_frontend_t *f, int min_coverage, int drop
         FE_TRY(f, hipMalloc((void **)&f->d_cand_block_sum, ((size_t)blocks_for(room + 1, SCAN_BLOCK) + 1) * sizeof(uint32_t)));
     }
     FE_TRY(f, hipMemsetAsync(f->d_ins, 0, (size_t)room * N_QUAD * sizeof(uint32_t), f->stream));
-    Candidates c{f->d_centre, f->d_before, f->d_ins};
+    if (!consider_left_edge) {
+        if (!f->d_late) {
+            FE_TRY(f, hipMalloc((void **)&f->d_late, (size_t)room * N_POS * LATE_ROW * sizeof(uint32_t)));
+            FE_TRY(f, hipMalloc((void **)&f->d_tuple_diff, ((size_t)room + 1) * sizeof(int)));
+        }
+        FE_TRY(f, hipMemsetAsync(f->d_late, 0, (size_t)room * N_POS * LATE_ROW * sizeof(uint32_t), f->stream));
+        FE_TRY(f, hipMemsetAsync(f->d_tuple_diff, 0, ((size_t)room + 1) * sizeof(int), f->stream));
+    }
+    uint32_t *late = consider_left_edge ? nullptr : f->d_late;
+    Candidates c{f->d_centre, f->d_before, f->d_ins, late, consider_left_edge ? nullptr : f->d_tuple_diff};
     for (Slab &s : f->slabs) {
         FE_TRY(f, hipMemsetAsync(s.tuples, 0, (size_t)s.n_reads * sizeof(uint64_t), f->stream));
         if (s.n_elem && nc) hipLaunchKernelGGL(fe_windows_per_base_kernel, dim3(blocks_for(s.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
     }
-    WindowRule rule{min_coverage, drop_non_iupac_centre};
+    WindowRule rule{min_coverage, drop_non_iupac_centre, late};
+    if (nc && late) hipLaunchKernelGGL(fe_window_totals_kernel, dim3(1), dim3(256), 0, f->stream, (const int *)f->d_tuple_diff, nc, f->d_window_tuples);
     if (nc) hipLaunchKernelGGL(fe_window_flags_kernel, dim3(blocks_for(nc, 256)), dim3(256), 0, f->stream, f->g, (const int64_t *)f->d_centre, nc, rule, f->d_keep, f->d_window_tuples);
     FE_TRY(f, hipGetLastError());
     int64_t kept = 0;
@@ -1094,7 +1165,7 @@ int clair_frontend_build_windows(clair_frontend_t *f, int min_coverage, int drop
     FE_TRY(f, hipMalloc((void **)&f->d_out_refseq, (size_t)std::max<int64_t>(kept, 1) * 34));
     if (kept)
         hipLaunchKernelGGL(fe_assemble_kernel, dim3(blocks_for(kept * N_QUAD, 256)), dim3(256), 0, f->stream, f->g, (const int64_t *)f->d_centre,
-                           (const int64_t *)f->d_kept, kept, (const uint32_t *)f->d_ins, f->d_counts, f->d_out_centre, f->d_out_refseq);
+                           (const int64_t *)f->d_kept, kept, (const uint32_t *)f->d_ins, (const uint32_t *)late, f->d_counts, f->d_out_centre, f->d_out_refseq);
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
     f->n_windows = kept;

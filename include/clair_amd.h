@@ -238,7 +238,7 @@ int clair_comm_allgather_device(clair_comm_t *c, const void *send_dev, void *rec
  * reference bases under them.  Windows are the ones the sequential stages write, in ascending order, bit for bit, PROVIDED no
  * CLAIR_FE_* bit (clair_reads.h) is set in stats[0] and the tuple budget did not bind (clair_frontend_budget_inputs ->
  * clair_host_tuple_budget_binds); otherwise the caller runs clair_host_evc_* / clair_host_pileup_*, which reproduce the reference
- * in every regime.  Left-edge windows only (CreateTensor's default; --stop_consider_left_edge stays on the host path).
+ * in every regime.
  * Calls on one handle are not concurrent; all are synchronous. */
 typedef struct clair_frontend clair_frontend_t;
 struct clair_read;
@@ -271,6 +271,10 @@ int clair_frontend_get_candidates(clair_frontend_t *f, int64_t *positions /*[n_c
 /* Second pass over the resident alignments + assembly.  min_coverage: CreateTensor's --minCoverage (depth at the centre);
  * drop_non_iupac_centre != 0 applies clair/utils.py:90-91 as well. */
 int clair_frontend_build_windows(clair_frontend_t *f, int min_coverage, int drop_non_iupac_centre, int64_t *n_windows);
+/* The same with CreateTensor's --stop_consider_left_edge (consider_left_edge = 0, CreateTensor.py:103-104): a read opens a window only
+ * by walking its first column, so a read that starts inside a window adds nothing to it; the per-position tables hold such reads too
+ * and what they added is collected per window and taken out again. */
+int clair_frontend_build_windows_ex(clair_frontend_t *f, int min_coverage, int drop_non_iupac_centre, int consider_left_edge, int64_t *n_windows);
 int clair_frontend_window_info(clair_frontend_t *f, int64_t first, int64_t n, int64_t *centres, char *refseq /*[n][34], NUL-padded*/);
 int clair_frontend_window_counts(clair_frontend_t *f, int64_t first, int64_t n, int16_t *counts /*[n][33][8][4], host*/);
 const int16_t *clair_frontend_counts_device(clair_frontend_t *f, int64_t first);   /* device address of window `first`; NULL before build_windows */

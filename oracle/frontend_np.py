@@ -279,9 +279,14 @@ class Columns(object):
         keep = (depth.astype(np.float64) >= min_depth) & ((order[:, 0] != rb) | (second.astype(np.float64) / denom.astype(np.float64) >= min_af))
         return (p0[keep] + 1).astype(np.int64)
 
-    def windows(self, cands, min_cov=0, slots=SLOTS):
+    def windows(self, cands, min_cov=0, slots=SLOTS, left_edge=True):
         """second pass + assembly.  cands: 1-based, strictly ascending.  -> dict(centres, refseq [n,34] uint8, counts int32 [n,33,8,4],
-        tuples per read (per slab), per-candidate totals, anomalies)."""
+        tuples per read (per slab), per-candidate totals, anomalies).
+
+        left_edge=False (--stop_consider_left_edge, CreateTensor.py:103-104): a read opens the window of centre c only by walking
+        position c - 17 itself, so a read that STARTS inside a window (c - 17 < POS) adds nothing to it.  The position tables hold such
+        reads too: what they added -- only the first 32 walked positions of a read can be "late" for some window -- is collected per
+        window and taken out again."""
         cands = np.asarray(cands, np.int64)
         if len(cands) > 1 and not (np.diff(cands) > 0).all():
             self.anomalies |= A_CANDIDATES
@@ -297,6 +302,10 @@ class Columns(object):
             return np.where(b > a, cpre[b - lo] - cpre[a - lo], 0)
 
         ins = np.zeros((len(cands), N_POS, 8), np.int64)
+        late_q = np.zeros((len(cands), N_POS, 8), np.int64)          # left_edge=False: what reads starting inside a window put into the tables
+        late_mw = np.zeros((len(cands), N_POS, 2), np.int64)
+        late_dw = np.zeros((len(cands), N_POS, 2), np.int64)
+        diff = np.zeros(len(cands) + 1, np.int64)                    # left_edge=False: tuples per window as range additions over the candidate index
         tuples = []
         for s in self.slabs:
             e_op, k, code, read, rp, qp = self._elements(s)
@@ -306,13 +315,31 @@ class Columns(object):
             m = (code == OP_M) & pile
             other = (code != OP_M) & pile & (rp > pos0)
             nc = np.zeros(len(rp), np.int64)
-            nc[m] = n_between(np.where(rp > pos0, rp - 17, pos0 - 16)[m], rp[m] + 17)
-            nc[other] = n_between(rp[other] - 17, rp[other] + 16)
+            first = np.where(rp > pos0, rp - 17, pos0 - 16) if left_edge else np.maximum(rp - 17, pos0 + 17)
+            nc[m] = n_between(first[m], rp[m] + 17)
+            nc[other] = n_between(first[other], rp[other] + 16)
             tuples.append(np.bincount(read, weights=nc, minlength=len(s["pos0"])).astype(np.int64))
+            if not left_edge:
+                sel = np.nonzero(nc > 0)[0]
+                a = np.searchsorted(cands, first[sel])
+                np.add.at(diff, a, 1)
+                np.add.at(diff, a + nc[sel], -1)
+                for e in np.nonzero(pile & (rp - pos0 <= 31) & ((code == OP_M) | ((code == OP_D) & (rp > pos0))))[0]:
+                    a, b = np.searchsorted(cands, [rp[e] - 15, pos0[e] + 17])
+                    if a >= b:
+                        continue
+                    ci = np.arange(a, b)
+                    col = rp[e] - cands[a:b] + 17
+                    if code[e] == OP_M:
+                        if qp[e] < s["seq_len"][read[e]] and PILE_ROW[s["seq"][s["seq0"][read[e]] + qp[e]]] != 255:
+                            late_q[ci, col, PILE_ROW[s["seq"][s["seq0"][read[e]] + qp[e]]] + 4 * so[e]] += 1
+                            late_mw[ci, col, so[e]] += 1
+                    else:
+                        late_dw[ci, col, so[e]] += 1
             # insertion bases into the windows of centres rp-15 .. rp+16
             gi = np.nonzero((code == OP_I) & pile & (rp > pos0) & (qp < s["seq_len"][read]))[0]
             for e in gi:
-                a, b = np.searchsorted(cands, [rp[e] - 15, rp[e] + 17])
+                a, b = np.searchsorted(cands, [rp[e] - 15 if left_edge else max(rp[e] - 15, pos0[e] + 17), rp[e] + 17])
                 if a == b:
                     continue
                 row = PILE_ROW[s["seq"][s["seq0"][read[e]] + qp[e]]]
@@ -331,8 +358,8 @@ class Columns(object):
 
         idx = np.arange(N_POS)
         rp = cands[:, None] - 17 + idx[None, :]                       # [n,33]
-        q = tab(self.q, rp)                                           # [n,33,8]
-        mw, dw = tab(self.mw, rp), tab(self.dw, rp)                   # [n,33,2]
+        q = tab(self.q, rp) - late_q                                  # [n,33,8]
+        mw, dw = tab(self.mw, rp) - late_mw, tab(self.dw, rp) - late_dw   # [n,33,2]
         rrow = self.ref_row(rp)                                       # [n,33]
         counts = np.zeros((len(cands), N_POS, 8, 4), np.int64)
         counts[..., 1] = q + ins
@@ -354,9 +381,13 @@ class Columns(object):
             b = np.clip(b + 1, lo, hi)
             return np.where(b > a, pre[b - lo] - pre[a - lo], 0)
 
-        opened = between(wpre, cands - 17, cands + 16) > 0
-        totals = between(mpre, cands - 17, cands + 17) - tab(self.start_m, cands + 17) + between(dipre, cands - 16, cands + 17)
-        depth_centre = tab(self.mw, cands - 1).sum(axis=1)
+        if left_edge:
+            opened = between(wpre, cands - 17, cands + 16) > 0
+            totals = between(mpre, cands - 17, cands + 17) - tab(self.start_m, cands + 17) + between(dipre, cands - 16, cands + 17)
+        else:
+            opened = tab(walk, cands - 17) > 0
+            totals = np.cumsum(diff)[:len(cands)]
+        depth_centre = tab(self.mw, cands - 1).sum(axis=1) - late_mw[:, 16, :].sum(axis=1)
         nrp = cands - self.ref0
         a = np.minimum(np.maximum(nrp - 17, 0), len(self.ref))
         b = np.minimum(np.maximum(nrp + 16, 0), len(self.ref))

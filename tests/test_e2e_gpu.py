@@ -202,7 +202,8 @@ def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch
             f.write("%s\t%d\t.\tA\tC\t.\t.\t.\n" % (case["ctg"], p))
     base = ["--chkpnt_fn", ck, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"],
             "--samtools", FAKE_SAMTOOLS]
-    for extra in (["--bed_fn", bed], ["--vcf_fn", sites], ["--dcov", "2", "--ctgStart", "200", "--ctgEnd", "2700"], ["--qual", "30"]):
+    for extra in (["--bed_fn", bed], ["--vcf_fn", sites], ["--dcov", "2", "--ctgStart", "200", "--ctgEnd", "2700"], ["--qual", "30"],
+                  ["--stop_consider_left_edge"]):
         outs = {}
         for fe in ("device", "host"):
             out = os.path.join(tmp, "%s.vcf" % fe)

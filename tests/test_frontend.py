@@ -89,7 +89,7 @@ def test_columns_reproduce_reference_tensor_records(path):
         assert w is None and col.anomalies == fe.A_CANDIDATES          # list order matters to the reference: the host path's business
         return
     if not case["left_edge"]:
-        pytest.skip("--stop_consider_left_edge stays on the host path")
+        w = col.windows(case["candidates"], min_cov=case["min_coverage"], left_edge=False)
     assert col.anomalies == 0
     assert fc.text_of(case["ctg"], w["centres"], w["refseq"], w["counts"]) == case["expected"]
     assert sum(int(t.sum()) for t in w["tuples"]) == int(w["totals"][w["opened"]].sum()) > 0
@@ -126,13 +126,14 @@ SYNTH = [
 ]
 
 
+@pytest.mark.parametrize("left_edge", [True, False], ids=["left_edge", "no_left_edge"])
 @pytest.mark.parametrize("k", range(len(SYNTH)))
-def test_columns_equal_the_sequential_pileup(k):
+def test_columns_equal_the_sequential_pileup(k, left_edge):
     seed, synth_kw, kw = SYNTH[k]
     case = fc.synth(seed, **synth_kw)
-    hc, hs, hcounts = fc.host_windows(case, **kw)
+    hc, hs, hcounts = fc.host_windows(case, consider_left_edge=left_edge, **kw)
     col, _ = columns_of(case, dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
-    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0))
+    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0), left_edge=left_edge)
     assert col.anomalies == 0 and len(hc) > 50
     assert np.array_equal(hc, w["centres"]) and np.array_equal(hs, w["refseq"]) and np.array_equal(hcounts, w["counts"])
     assert sum(int(t.sum()) for t in w["tuples"]) == int(w["totals"][w["opened"]].sum())
@@ -157,6 +158,21 @@ def test_columns_equal_the_sequential_candidate_search(seed):
     col, _ = columns_of(case, evc_min_mq=5)
     got = col.candidates(min_depth=3, min_af=0.1, ctg_range=(200, 2300), bed=(np.array([0, 1800, 2000], np.int64), np.array([1200, 1801, 2600], np.int64)))
     assert np.array_equal(want, got) and len(want) > 30
+
+
+def test_budget_replay_is_safe_without_left_edge_windows():
+    case = fc.synth(33, n_reads=200, ref_len=1500, cand_step=(1, 4))
+    col, _ = columns_of(case)
+    w = col.windows(case["candidates"], left_edge=False)
+    free = fc.host_windows(case, consider_left_edge=False)
+    assert np.array_equal(free[2], w["counts"]) and sum(int(t.sum()) for t in w["tuples"]) == int(w["totals"].sum())
+    said_no = 0
+    for slots in (200, 1000, 3000, 6000, 10000, 20000, 40000, 80000):
+        binds = fe.budget_binds(col.slabs, w["tuples"], case["candidates"], np.where(w["opened"], w["totals"], 0), slots)
+        same = all(np.array_equal(a, b) for a, b in zip(free, fc.host_windows(case, consider_left_edge=False, available_slots=slots)))
+        assert binds or same, slots
+        said_no += not binds
+    assert 0 < said_no < 8
 
 
 def test_budget_replay_is_safe():
@@ -222,8 +238,8 @@ def test_differential_fuzz_of_the_column_formulation(block):
         got_pos = col.candidates(min_depth=evc_kw["min_coverage"], min_af=evc_kw["threshold"], ctg_range=region, bed=bed)
         assert np.array_equal(want_pos, got_pos), seed
         hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
-                                          min_coverage=pile_kw["min_coverage"])
-        w = col.windows(want_pos, min_cov=pile_kw["min_coverage"])
+                                          min_coverage=pile_kw["min_coverage"], consider_left_edge=seed % 3 != 0)
+        w = col.windows(want_pos, min_cov=pile_kw["min_coverage"], left_edge=seed % 3 != 0)
         assert col.anomalies == 0, seed
         assert np.array_equal(hc, w["centres"]) and np.array_equal(hs, w["refseq"]) and np.array_equal(hcounts, w["counts"]), seed
 
@@ -268,8 +284,8 @@ class _StandInFrontend(object):
         self.pos = np.asarray(positions, np.int64)
         return len(self.pos)
 
-    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True):
-        w = self._columns().windows(self.pos, min_cov=min_coverage)
+    def build_windows(self, min_coverage=0, drop_non_iupac_centre=True, consider_left_edge=True):
+        w = self._columns().windows(self.pos, min_cov=min_coverage, left_edge=consider_left_edge)
         keep = w["centre_ok"] if drop_non_iupac_centre else np.ones(len(w["centres"]), bool)
         self.w = {k: w[k][keep] for k in ("centres", "refseq", "counts")}
         return len(self.w["centres"])

@@ -38,13 +38,12 @@ def windows_of(f):
     return centres, seqs, f.window_counts(0, n).astype(np.int32)
 
 
-@pytest.mark.parametrize("path", [p for p in fc.CT_GOLDEN if "noleft" not in p and "unsorted" not in p],
-                         ids=lambda p: os.path.basename(p)[10:-8])
+@pytest.mark.parametrize("path", [p for p in fc.CT_GOLDEN if "unsorted" not in p], ids=lambda p: os.path.basename(p)[10:-8])
 def test_windows_reproduce_reference_tensor_records(path):
     case = fc.ct_golden_case(path)
     f = device_frontend(case, slabs=3, dcov=case["dcov"], pile_min_mq=case["min_mq"], pile_region=case["pile_region"])
     assert f.set_candidates(case["candidates"]) == len(case["candidates"])
-    n = f.build_windows(min_coverage=case["min_coverage"], drop_non_iupac_centre=False)
+    n = f.build_windows(min_coverage=case["min_coverage"], drop_non_iupac_centre=False, consider_left_edge=case["left_edge"])
     assert f.stats()["anomalies"] == 0 and f.host_anomalies == 0 and not f.budget_binds()
     centres, seqs, counts = windows_of(f)
     assert n == len(centres) > 20
@@ -72,14 +71,15 @@ SYNTH = [
 ]
 
 
+@pytest.mark.parametrize("left_edge", [True, False], ids=["left_edge", "no_left_edge"])
 @pytest.mark.parametrize("k", range(len(SYNTH)))
-def test_windows_equal_the_sequential_pileup_and_the_restatement(k):
+def test_windows_equal_the_sequential_pileup_and_the_restatement(k, left_edge):
     seed, synth_kw, kw, slabs = SYNTH[k]
     case = fc.synth(seed, **synth_kw)
-    hc, hs, hcounts = fc.host_windows(case, **kw)
+    hc, hs, hcounts = fc.host_windows(case, consider_left_edge=left_edge, **kw)
     f = device_frontend(case, slabs=slabs, dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
     f.set_candidates(case["candidates"])
-    f.build_windows(min_coverage=kw.get("min_coverage", 0), drop_non_iupac_centre=False)
+    f.build_windows(min_coverage=kw.get("min_coverage", 0), drop_non_iupac_centre=False, consider_left_edge=left_edge)
     assert f.stats()["anomalies"] == 0 and not f.budget_binds()
     centres, seqs, counts = windows_of(f)
     assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts) and len(hc) > 50
@@ -87,7 +87,7 @@ def test_windows_equal_the_sequential_pileup_and_the_restatement(k):
     packed = fe.pack_sam(case["sam"], case["ctg"], dcov=kw.get("dcov", 250), pile_min_mq=kw.get("min_mq", 0))
     col = fe.Columns(case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
     col.add_reads(packed)
-    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0))
+    w = col.windows(case["candidates"], min_cov=kw.get("min_coverage", 0), left_edge=left_edge)
     got = np.concatenate([f.read_tuples(s) for s in range(f.stats()["slabs"])])
     assert np.array_equal(got.astype(np.int64), w["tuples"][0])
     cc, wt = f.window_tuples()
@@ -193,12 +193,12 @@ def test_differential_fuzz_against_the_sequential_stages(block):
         rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
         want_pos = fc.host_candidates(case, **rng, **evc_kw)
         hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
-                                          min_coverage=pile_kw["min_coverage"])
+                                          min_coverage=pile_kw["min_coverage"], consider_left_edge=seed % 3 != 0)
         f = device_frontend(case, slabs=1 + seed % 4, dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
         n = f.find_candidates(min_coverage=evc_kw["min_coverage"], threshold=evc_kw["threshold"], ctg_start=rng.get("ctg_start"), ctg_end=rng.get("ctg_end"),
                               bed=evc_kw["bed"])
         assert n == len(want_pos) and np.array_equal(f.candidates(), want_pos), seed
-        f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False)
+        f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False, consider_left_edge=seed % 3 != 0)
         assert f.stats()["anomalies"] == 0 and f.host_anomalies == 0 and not f.budget_binds(), seed
         centres, seqs, counts = windows_of(f)
         assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts), seed

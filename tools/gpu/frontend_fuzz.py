@@ -5,7 +5,7 @@
 
 Every case is a fresh random set of alignments with random options of both pileup stages (tests/frontend_cases.py: fuzz_case -- read
 lengths, substitution / insertion / deletion rates, N operations, start-position bursts, --dcov, mapping-quality floors, depth floors,
-allele-frequency thresholds, regions, bed intervals).  Expected values: the sequential host stages (clair_host_evc_*, clair_host_pileup_*:
+allele-frequency thresholds, regions, bed intervals, left-edge windows on or off).  Expected values: the sequential host stages (clair_host_evc_*, clair_host_pileup_*:
 pinned byte for byte against records minted from the reference's own scripts).  Each case goes through the device front end twice --
 text packed on the host, text parsed on the device -- in a random number of slabs / chunks; candidates, window centres, reference
 windows and every count are compared, and the budget replay and the CLAIR_FE_* reports must stay silent.
@@ -40,8 +40,9 @@ def main():
         case, pile_kw, evc_kw, region = fc.fuzz_case(seed)
         rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
         want_pos = fc.host_candidates(case, **rng, **evc_kw)
+        left_edge = seed % 3 != 0
         hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
-                                          min_coverage=pile_kw["min_coverage"])
+                                          min_coverage=pile_kw["min_coverage"], consider_left_edge=left_edge)
         pack_kw = dict(dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
         span = (case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
         for path in ("host-packed", "device-parsed"):
@@ -61,7 +62,7 @@ def main():
             n = f.find_candidates(min_coverage=evc_kw["min_coverage"], threshold=evc_kw["threshold"], ctg_start=rng.get("ctg_start"), ctg_end=rng.get("ctg_end"),
                                   bed=evc_kw["bed"])
             ok = n == len(want_pos) and np.array_equal(f.candidates(), want_pos)
-            nw = f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False)
+            nw = f.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False, consider_left_edge=left_edge)
             centres, seqs = f.window_info(0, nw)
             got = f.window_counts(0, nw).astype(np.int32)
             ok = ok and np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, got)
