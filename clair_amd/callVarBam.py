@@ -489,7 +489,8 @@ def parallel_front_end(args, batch_size, workers, lo, hi):
         stop.set()
 
 
-def Run(args):
+def normalise(args):
+    """The argument checks of callVarBam.py:62-101."""
     if args.ctgName is None:
         sys.exit("--ctgName must be specified. You can call variants on multiple chromosomes simultaneously.")
     for path, suffix in ((args.bam_fn, ""), (args.ref_fn, "")):
@@ -499,9 +500,28 @@ def Run(args):
         args.ctgStart = args.ctgEnd = None          # callVarBam.py:97-101
     if (args.ctgStart is None) != (args.ctgEnd is None):
         args.ctgStart = args.ctgEnd = None
-    logging.basicConfig(format="%(message)s", level=logging.INFO)
-    cv.ingest.setup_environment()
+    return args
 
+
+def load_model(args):
+    from .model import Clair
+    batch = args.batch_size or param.predictBatchSize
+    try:
+        m = Clair(device=args.device, max_batch=batch, n_slots=2)
+        m.init()
+        m.restore_parameters(os.path.abspath(args.chkpnt_fn))
+    except Exception as exc:
+        sys.exit("[ERROR] %s" % exc)
+    return m
+
+
+def wants_device_front_end(args):
+    return args.front_end != "host" and front_end_workers(args)[0] == 1
+
+
+def call_region(args, m, prepared=None):
+    """One contig / region through an engine that is already up: front end, network, decode, VCF.  prepared: a DeviceFrontEnd whose run()
+    has been called (clair_amd.callVarBamParallel --run reads the next regions' alignments while this one is called); it is closed here."""
     config = cv.OutputConfig(
         is_show_reference=False, is_debug=args.debug,
         is_haploid_precision_mode_enabled=args.haploid_precision,
@@ -510,45 +530,49 @@ def Run(args):
     lookup = cv.AlignmentLookup(args.bam_fn, args.ref_fn)
     decoder = cv.VariantDecoder(config, lookup, always_use_bam=args.pysam_for_all_indel_bases, arith=args.arith)
     writer = cv.VcfWriter(args.call_fn, args.sampleName, args.ref_fn, args.output_for_ensemble)
+    device_fe = prepared
     try:
-        if args.activation_only:
-            return
-        from .model import Clair
         batch = args.batch_size or param.predictBatchSize
-        try:
-            m = Clair(device=args.device, max_batch=batch, n_slots=2)
-            m.init()
-            m.restore_parameters(os.path.abspath(args.chkpnt_fn))
-        except Exception as exc:
-            sys.exit("[ERROR] %s" % exc)
-        device_fe = None
-        try:
-            source = None
-            workers, lo, hi = front_end_workers(args)
-            if args.front_end != "host" and workers == 1:
-                # nobody on the host reads the tensors when the decode runs on the device and no BAM is consulted (cv.call_variants)
-                lean = decoder.native_applies() and lookup.sam is None and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0"
+        source = None
+        workers, lo, hi = front_end_workers(args)
+        if wants_device_front_end(args):
+            # nobody on the host reads the tensors when the decode runs on the device and no BAM is consulted (cv.call_variants)
+            lean = decoder.native_applies() and lookup.sam is None and os.environ.get("CLAIR_AMD_DEVICE_DECODE", "1") != "0"
+            if device_fe is None:
                 device_fe = DeviceFrontEnd(args, args.device, pinned=getattr(m, "pinned_buffer", None))
-                if device_fe.run() is not None:
-                    def source(batch):
-                        return device_fe.batches(batch, lean=lean)
-            if source is None and workers > 1:
+                device_fe.run()
+            if device_fe.frontend is not None:
                 def source(batch):
-                    return parallel_front_end(args, batch, workers, lo, hi)
-            elif source is None:
-                positions = candidate_positions(args)
-                logging.info("%d candidate sites" % len(positions))
+                    return device_fe.batches(batch, lean=lean)
+        if source is None and workers > 1:
+            def source(batch):
+                return parallel_front_end(args, batch, workers, lo, hi)
+        elif source is None:
+            positions = candidate_positions(args)
+            logging.info("%d candidate sites" % len(positions))
 
-                def source(batch):
-                    return tensor_batches(args, positions, batch)
-            cv.call_variants(args, m, decoder, writer, batch, generator=source(batch))
-        finally:
-            if device_fe is not None:
-                device_fe.close()
-            m.close()
+            def source(batch):
+                return tensor_batches(args, positions, batch)
+        cv.call_variants(args, m, decoder, writer, batch, generator=source(batch))
     finally:
+        if device_fe is not None:
+            device_fe.close()
         writer.close()
         lookup.close()
+
+
+def Run(args):
+    normalise(args)
+    logging.basicConfig(format="%(message)s", level=logging.INFO)
+    cv.ingest.setup_environment()
+    if args.activation_only:
+        cv.VcfWriter(args.call_fn, args.sampleName, args.ref_fn, args.output_for_ensemble).close()
+        return
+    m = load_model(args)
+    try:
+        call_region(args, m)
+    finally:
+        m.close()
 
 
 def build_parser():

@@ -5,6 +5,11 @@ Host-side mirror of the reference's clair/callVarBamParallel.py (:19-116): conti
 output `<prefix>.<contig>_<start>_<end>.vcf`.  This is also the multi-GPU front door: candidates are independent
 (SURVEY.md 8e), so chunks are dealt round-robin over --devices GPUs (addition; one process per chunk and GPU, no
 collective) and the per-chunk VCFs concatenate in order exactly as the reference's do (README: vcfcat + bcftools sort).
+
+--run (addition) executes the chunks instead of printing them: one worker process per GPU (--devices), which keeps ONE engine up for all
+of its chunks and reads the alignments of the next --readers chunks (`samtools view` into page-locked buffers, parsed and piled up on
+the device: clair_amd.callVarBam.DeviceFrontEnd) while the current one goes through the network -- the process start-up and the engine
+set-up are paid once per GPU instead of once per chunk, and the GPU is never waiting for a single samtools.  Same per-chunk VCFs.
 """
 import os
 import sys
@@ -63,6 +68,7 @@ def commands(args):
         _opt("front_end", args.front_end), _opt("batch_size", args.batch_size),
     ] if x is not None)
     out, k = [], 0
+    commands.chunks = []           # (device, output file) per command, for --run
     with open(fai_fn) as fai:
         for row in fai:
             col = row.strip().split("\t")
@@ -80,8 +86,92 @@ def commands(args):
                         _opt("bed_fn", bed_fn) if in_bed else None,
                         _opt("device", k % args.devices) if args.devices > 1 else None]
                 out.append(head + " " + " ".join(x for x in tail if x is not None))
+                commands.chunks.append((k % args.devices, "%s.%s_%d_%d.vcf" % (args.output_prefix, contig, start, end)))
                 k += 1
     return out
+
+
+def run_worker(command_lines, device, readers):
+    """All chunks of one GPU in this process: one engine, `readers` front ends reading ahead."""
+    import logging
+    import queue
+    import shlex
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from . import call_var as cv
+    from . import callVarBam
+    logging.basicConfig(format="%(message)s", level=logging.INFO)
+    cv.ingest.setup_environment()
+    parser = callVarBam.build_parser()
+    jobs = []
+    for line in command_lines:
+        argv = shlex.split(line)
+        jobs.append(callVarBam.normalise(parser.parse_args(argv[argv.index("clair_amd.callVarBam") + 1:] + ["--device", str(device)])))
+    if not jobs:
+        return 0
+    m = callVarBam.load_model(jobs[0])
+    try:
+        buffers = queue.Queue()
+        if hasattr(m, "pinned_buffer"):
+            for _ in range(readers):
+                buffers.put(m.pinned_buffer(callVarBam.TEXT_CHUNK + 16))
+        # a front end holds its region in HBM until it has been called: chunk i is read only once chunk i - readers has been called
+        turn = threading.Condition()
+        state = {"called": 0, "stop": False}
+
+        def prepare(i, args):
+            with turn:
+                turn.wait_for(lambda: state["stop"] or i < state["called"] + readers)
+                if state["stop"]:
+                    return None
+            if not callVarBam.wants_device_front_end(args):
+                return None
+            buf = buffers.get() if hasattr(m, "pinned_buffer") else None
+            try:
+                fe = callVarBam.DeviceFrontEnd(args, device, pinned=(lambda n: buf) if buf is not None else None)
+                fe.run()
+                return fe
+            finally:
+                if buf is not None:
+                    buffers.put(buf)
+
+        with ThreadPoolExecutor(max_workers=readers) as pool:
+            ahead = [pool.submit(prepare, i, a) for i, a in enumerate(jobs)]
+            try:
+                for args, fut in zip(jobs, ahead):
+                    callVarBam.call_region(args, m, prepared=fut.result())       # closes the front end
+                    with turn:
+                        state["called"] += 1
+                        turn.notify_all()
+            finally:
+                with turn:
+                    state["stop"] = True        # on an error: let the readers that wait for their turn run out
+                    turn.notify_all()
+    finally:
+        m.close()
+    return 0
+
+
+def run(args, lines):
+    """--run: the command lines dealt over --devices worker processes (this module, --worker)."""
+    import json
+    import subprocess
+    import tempfile
+    per_device = {}
+    for line, (device, _) in zip(lines, commands.chunks):
+        per_device.setdefault(device, []).append(line)
+    os.makedirs(os.path.dirname(os.path.abspath(args.output_prefix)) or ".", exist_ok=True)
+    procs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for device, mine in sorted(per_device.items()):
+            spec = os.path.join(tmp, "device_%d.json" % device)
+            with open(spec, "w") as f:
+                json.dump({"device": device, "readers": args.readers, "commands": mine}, f)
+            procs.append(subprocess.Popen([args.python or sys.executable, "-m", "clair_amd.callVarBamParallel", "--worker", spec]))
+        codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.exit("[ERROR] callVarBamParallel --run: worker exit codes %r" % codes)
+    return 0
 
 
 def build_parser():
@@ -119,6 +209,9 @@ def build_parser():
     # additions of this implementation
     add('--devices', type=int, default=1, help="deal the chunks round-robin over this many GPUs (--device k)")
     add('--python', type=str, default=None, help="interpreter to put in the commands, default: the running one")
+    add('--run', action='store_true', help="run the chunks instead of printing the commands: one worker process per GPU, its engine kept up for all of its chunks")
+    add('--readers', type=int, default=4, help="with --run: regions whose alignments are read ahead per GPU (one `samtools view` each), default: %(default)s")
+    add('--worker', type=str, default=None, help="internal: a job file written by --run")
     add('--front_end', type=str, default=None, choices=("auto", "device", "host"), help="passed on (callVarBam: where the candidate search and the pileup run)")
     add('--batch_size', type=int, default=None, help="passed on (callVarBam: candidates per forward pass)")
     return parser
@@ -131,6 +224,12 @@ def main(argv=None):
         parser.print_help()
         sys.exit(1)
     args = parser.parse_args(argv)
+    if args.worker is not None:
+        import json
+        spec = json.load(open(args.worker))
+        sys.exit(run_worker(spec["commands"], spec["device"], spec["readers"]))
+    if args.run:
+        sys.exit(run(args, commands(args)))
     if not args.includingAllContigs:
         print("echo \"[INFO] --includingAllContigs not enabled, use chr{1..22,X,Y,M,MT} and {1..22,X,Y,MT} by default\"\n")
     else:

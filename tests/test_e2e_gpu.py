@@ -232,3 +232,32 @@ def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch
     assert open(out).read() == open(os.path.join(tmp, "h.vcf")).read()
     with pytest.raises(SystemExit, match="--front_end device"):
         callVarBam.main(base + ["--call_fn", out, "--front_end", "device"])
+
+
+def test_callVarBamParallel_run_writes_the_vcfs_of_the_printed_commands(tmp_path):
+    """callVarBamParallel --run (one worker process per GPU, one engine for all of its chunks, the next chunks' alignments read ahead)
+    leaves the per-chunk VCFs that running the printed commands one by one leaves."""
+    import shlex
+    from clair_amd import callVarBamParallel as par
+    tmp = str(tmp_path)
+    case, fa, sam = _bam_case(tmp, seed=55)
+    ck = _model(tmp)
+    common = ["--chkpnt_fn", ck, "--bam_fn", sam, "--ref_fn", fa, "--samtools", FAKE_SAMTOOLS, "--includingAllContigs", "--refChunkSize", "700",
+              "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--python", sys.executable]
+    lines = par.commands(par.build_parser().parse_args(common + ["--output_prefix", os.path.join(tmp, "one", "var")]))
+    lines = [l for l in lines if '--ctgName "%s"' % case["ctg"] in l]
+    assert len(lines) == 5
+    os.makedirs(os.path.join(tmp, "one"))
+    for line in lines:
+        argv = shlex.split(line)
+        _run(argv[argv.index("-m") + 1:])
+    r = _run(["clair_amd.callVarBamParallel", "--run", "--readers", "2", "--output_prefix", os.path.join(tmp, "all", "var")] + common)
+    assert r.stderr.count("device front end:") >= 5
+    names = sorted(n for n in os.listdir(os.path.join(tmp, "one")) if case["ctg"] in n)
+    assert len(names) == 5 and sorted(n for n in os.listdir(os.path.join(tmp, "all")) if case["ctg"] in n) == names
+    rows = 0
+    for n in names:
+        a, b = open(os.path.join(tmp, "one", n)).read(), open(os.path.join(tmp, "all", n)).read()
+        assert a == b, n
+        rows += len([x for x in a.splitlines() if not x.startswith("#")])
+    assert rows > 30
