@@ -340,3 +340,49 @@ def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, 
         assert [list(map(str, r)) for r in ginfo] == [list(map(str, r)) for r in winfo]
     lean = list(d.batches(64, lean=True, progress=False))
     assert all(x is None and isinstance(c, _capi.DeviceWindows) and len(c) == len(i) for x, i, c in lean)
+
+
+def test_callVarBamParallel_worker_with_stand_ins(tmp_path, monkeypatch):
+    """callVarBamParallel's --run worker (one engine for all chunks, front ends read ahead on threads, chunks called in order) with the
+    restatement standing in for the device front end and the oracle for the network: the per-chunk VCFs of callVarBam --front_end host."""
+    import pileup_synth
+    from test_decode import _CallsModel
+    from clair_amd import _capi, callVarBam, callVarBamParallel as par, weights
+    tmp = str(tmp_path)
+    case = pileup_synth.synth_case(seed=77, n_reads=200)
+    fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"])
+    open(os.path.join(tmp, "model.npz"), "w").close()
+    fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+
+    class Model(_CallsModel):
+        def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
+            if isinstance(batch, _capi.DeviceWindows):
+                batch, counts = batch.host(), True
+            _CallsModel.submit_calls(self, slot, batch, centre, counts=counts, with_probabilities=with_probabilities)
+
+        def close(self):
+            pass
+    models = []
+    monkeypatch.setattr(callVarBam, "load_model", lambda args: models.append(Model(w)) or models[-1])
+    monkeypatch.setattr(_capi, "Frontend", _StandInFrontend)
+    monkeypatch.setattr(callVarBam, "TEXT_CHUNK", 50000)
+    common = ["--chkpnt_fn", os.path.join(tmp, "model"), "--bam_fn", sam, "--ref_fn", fa, "--samtools", fake, "--includingAllContigs", "--refChunkSize", "800",
+              "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--python", "PY"]
+    lines = par.commands(par.build_parser().parse_args(common + ["--output_prefix", os.path.join(tmp, "all", "var")]))
+    os.makedirs(os.path.join(tmp, "all"))
+    assert len(lines) == 4 and par.run_worker(lines, 0, 2) == 0 and len(models) == 1 and models[0].calls_submits > 4
+    os.makedirs(os.path.join(tmp, "one"))
+    import shlex
+    rows = 0
+    for line, (_, out) in zip(lines, par.commands.chunks):
+        argv = shlex.split(line.replace(os.path.join(tmp, "all"), os.path.join(tmp, "one")))
+        args = callVarBam.normalise(callVarBam.build_parser().parse_args(argv[argv.index("clair_amd.callVarBam") + 1:] + ["--front_end", "host"]))
+        callVarBam.call_region(args, Model(w))
+        a, b = open(out).read(), open(args.call_fn).read()
+        assert a == b, out
+        rows += len([x for x in a.splitlines() if not x.startswith("#")])
+    assert rows > 20
