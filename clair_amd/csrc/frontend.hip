@@ -1,5 +1,6 @@
-// Device front end of the C ABI (include/clair_amd.h, "front end"): packed alignments (include/clair_reads.h) -> candidate sites ->
-// pileup count windows [n][33][8][4] int16 that stay in HBM for clair_submit_ex.  SURVEY.md 8(f) N4, the GPU half.
+// Device front end of the C ABI (include/clair_amd.h, "front end"): `samtools view` text (or alignments already packed by the host,
+// include/clair_reads.h) -> candidate sites -> pileup count windows [n][33][8][4] int16 that stay in HBM for clair_submit_ex.
+// SURVEY.md 8(f) N4, the GPU half.
 //
 // What the reference does per read base in two interpreters (dataPrepScripts/ExtractVariantCandidates.py:296-316: a dict of
 // per-position tallies; CreateTensor.py:289-365 + :29-65: a tuple per (read base, open window), summed when the window is written)
