@@ -147,6 +147,20 @@ def test_reports_of_what_leaves_the_regime():
     assert f.stats()["anomalies"] & fe.A_OVERFLOW
 
 
+def test_counters_that_fill_up_are_reported():
+    """The per-position counters are 21 bits wide: 2 097 151 alignments over one position is the end of the road, and is said."""
+    case = fc.synth(3, n_reads=60, ref_len=900)
+    one = b"r\t0\tchrS\t100\t60\t8M\t*\t0\t0\t" + case["ref"][99:107].encode() + b"\t" + b"I" * 8 + b"\n"
+    f = _capi.Frontend(0, case["ref"], 0, -64, 964)
+    f.text_options("chrS", dcov=10 ** 7)
+    f.add_text(one * 1000000)
+    assert f.stats()["anomalies"] == 0
+    f.add_text(one * 1000000)
+    assert f.stats()["anomalies"] == 0            # 2 000 000: still fine
+    f.add_text(one * 200000)
+    assert f.stats()["anomalies"] & fe.A_OVERFLOW
+
+
 def test_error_paths():
     with pytest.raises(_capi.EngineError, match="empty span"):
         _capi.Frontend(0, "ACGT", 0, 10, 10)
