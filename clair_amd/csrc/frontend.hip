@@ -119,9 +119,6 @@ __device__ inline uint8_t ref_row(const Region &g, int64_t p) {
 __device__ inline void flag(const Region &g, uint32_t bit) { atomicOr(g.anomalies, bit); }
 
 // ---- pass 1: the per-position tables ------------------------------------------------------------------------------------------
-// CHECKED: the atomic returns the old word so that a full 21-bit counter can be reported; needed only once more than 2 097 150
-// alignments are on the device (a counter counts alignments over one position) -- the plain form does not wait for the reply
-template <bool CHECKED>
 __global__ __launch_bounds__(256) void fe_tally_kernel(Region g, SlabView s) {
     const uint32_t e = blockIdx.x * 256u + threadIdx.x;
     if (e >= s.n_elem) return;
@@ -141,12 +138,10 @@ __global__ __launch_bounds__(256) void fe_tally_kernel(Region g, SlabView s) {
         const int row = BASES.pile[base];
         unsigned long long add = pile ? 1ull << (so * PQ_BITS) : 0;
         if (evc && ei < 4) add += 1ull << (2 * PQ_BITS);
-        if (add && CHECKED) {
+        if (add) {      // (the reply costs nothing measurable: the atomic unit at the memory side is the bound either way)
             const unsigned long long before = atomicAdd(&g.pq[t * 4 + row], add);
             if ((pile && pq_field(before, so) == PQ_MASK) || (evc && ei < 4 && pq_field(before, 2) == PQ_MASK))
                 flag(g, CLAIR_FE_OVERFLOW);                     // a counter was full: 2 097 151 reads over one position
-        } else if (add) {
-            atomicAdd(&g.pq[t * 4 + row], add);
         }
         if (evc && ei >= 4) atomicAdd(&g.misc[t * 8 + 7], 1u);
         if (pile && el.rp == el.r.pos0) atomicAdd(&g.misc[t * 8 + 4], 1u);
@@ -773,15 +768,6 @@ int fe_fail(clair_frontend *f, const char *fmt, ...) {
 
 inline unsigned blocks_for(int64_t n, int64_t per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
-void launch_tally(clair_frontend *f, const Slab &d) {
-    int64_t alignments = 0;
-    for (const Slab &s : f->slabs) alignments += s.n_reads;          // d is among them
-    if (alignments >= (int64_t)PQ_MASK)
-        hipLaunchKernelGGL(fe_tally_kernel<true>, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
-    else
-        hipLaunchKernelGGL(fe_tally_kernel<false>, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
-}
-
 // flags[n] -> how many are set (block sums left scanned in block_sum for scan_write)
 int scan_count(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *block_sum, uint32_t *d_count, int64_t *count, bool newlines = false) {
     const unsigned nb = blocks_for(n, SCAN_BLOCK);
@@ -925,7 +911,7 @@ int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int
     FE_TRY(f, hipMemcpyAsync(d.op_elem, op_elem, ((size_t)n_ops + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, f->stream));
     if (seq_bytes) FE_TRY(f, hipMemcpyAsync(d.seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, f->stream));
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_reads * sizeof(uint64_t), f->stream));
-    if (d.n_elem) launch_tally(f, d);
+    if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
     FE_TRY(f, hipGetLastError());
     // the caller's arrays may be reused as soon as this returns (the packer's slab is reset): wait for the copies
     FE_TRY(f, hipStreamSynchronize(f->stream));
@@ -1034,7 +1020,7 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
     hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
                        (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
-    if (d.n_elem) launch_tally(f, d);
+    if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
     return 0;
