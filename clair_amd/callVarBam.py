@@ -229,6 +229,17 @@ class DeviceFrontEnd(object):
         return None
 
     def run(self):
+        """-> number of windows, or None after a logged hand-back to the host stages.  Errors of the device library (out of memory, a lost
+        device) end the run like the engine's do: a message and a non-zero exit."""
+        from . import _capi
+        try:
+            return self._run()
+        except _capi.MalformedText:
+            raise
+        except _capi.EngineError as exc:
+            sys.exit("[ERROR] %s" % exc)
+
+    def _run(self):
         from . import _capi, _hostapi
         args = self.args
         have_range = args.ctgStart is not None and args.ctgEnd is not None
