@@ -498,7 +498,7 @@ __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
 // walks a CIGAR; EMIT writes the kept operations
 template <bool EMIT>
 __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
-                                  int64_t *o_rp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
+                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
     int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
     uint32_t n_ops = 0;
     uint64_t elems = 0;
@@ -533,7 +533,7 @@ __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read,
         total += adv;
         adv = 0;
     }
-    if (!EMIT) { *o_rp = rp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; }
+    if (!EMIT) { *o_rp = rp; *o_qp = qp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; }
 }
 
 __device__ inline bool text_int(const uint8_t *s, uint32_t len, int64_t *out) {     // [+-]digits, at most 18 of them (host_sampack.cpp)
@@ -581,11 +581,11 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     }
     bool same_ctg = (int)len[2] == opt.ctg_len;
     for (int i = 0; same_ctg && i < opt.ctg_len; ++i) same_ctg = text[col[2] + i] == opt.ctg[i];
-    int64_t rp, soft, total, rlen;
+    int64_t rp, qp, soft, total, rlen;
     uint32_t n_ops;
     uint64_t elems;
     bool zero;
-    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &soft, &total, &rlen, &n_ops, &elems, &zero);
+    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &qp, &soft, &total, &rlen, &n_ops, &elems, &zero);
     const bool evc_ok = same_ctg && mq >= opt.evc_min_mq && !(len[5] == 1 && text[col[5]] == '*') && !(1.0 - (double)soft / (double)(total + 1) < 0.55);
     bool in_region = true;
     if (opt.pile_start >= 0 && opt.pile_end >= 0) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     out.n_ops = n_ops;
     out.n_elem = elems > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)elems;
     out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0)
-                | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00) ? TL_LONG_SPAN : 0);
+                | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) ? TL_LONG_SPAN : 0);
     lines[k] = out;
     is_candidate[k] = candidate ? 1 : 0;
 }
@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, 
     if (i == 0) op_elem[total_ops] = (uint32_t)total_elems;
     if (i >= n_kept) return;
     const TextLine ln = lines[kept[i]];
-    walk_cigar<true>(text + ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    walk_cigar<true>(text + ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr);
     clair_read_t r;
     r.pos0 = ln.pos0;
     r.seq0 = ln.seq_off;

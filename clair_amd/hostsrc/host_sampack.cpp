@@ -151,7 +151,7 @@ struct clair_sampack {
         have_last = true;
         last_pos = pos;
         if (zero_indel && evc_ok) anomalies |= CLAIR_FE_ZERO_INDEL;
-        if (rp > (int64_t)sl + LOOKAHEAD - 64 || rp > 0x7fffff00) anomalies |= CLAIR_FE_LONG_SPAN;
+        if (rp > (int64_t)sl + LOOKAHEAD - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) anomalies |= CLAIR_FE_LONG_SPAN;   // the last two: offsets beyond 32 bits
         if (elems > 0xfffffff0ull || seq.size() + sl > 0xfffffff0ull)
             return clair_host_fail("alignment line %lld: the slab is full (take it before feeding more)", (long long)line_no);
         clair_read_t r;

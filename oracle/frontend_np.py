@@ -143,7 +143,7 @@ def pack_sam(sam, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=N
         last_pos = pos
         if zero_indel and evc_ok:
             anomalies |= A_ZERO_INDEL
-        if rp > len(seq) + LOOKAHEAD - 64:
+        if rp > len(seq) + LOOKAHEAD - 64 or rp > 0x7fffff00 or qp > 0x7fffff00:
             anomalies |= A_LONG_SPAN
         r = len(pos0)
         pos0.append(pos)

@@ -66,9 +66,10 @@ def test_packer_reports_what_leaves_the_regime():
     p = _hostapi.SamPacker("chrS")
     p.feed(b"r1\t0\tchrS\t10\t60\t3M0I2M\t*\t0\t0\tACGTA\tIIIII\n", final=True)
     assert p.stats()["anomalies"] == fe.A_ZERO_INDEL
-    p = _hostapi.SamPacker("chrS")
-    p.feed(b"r1\t0\tchrS\t10\t60\t2M200000D3M\t*\t0\t0\tACGTA\tIIIII\n", final=True)
-    assert p.stats()["anomalies"] == fe.A_LONG_SPAN
+    for cigar in (b"2M200000D3M", b"3000000000S5M"):
+        p = _hostapi.SamPacker("chrS")
+        p.feed(b"r1\t0\tchrS\t10\t60\t" + cigar + b"\t*\t0\t0\tACGTA\tIIIII\n", final=True)
+        assert p.stats()["anomalies"] == fe.A_LONG_SPAN == fe.pack_sam(b"r1\t0\tchrS\t10\t60\t" + cigar + b"\t*\t0\t0\tACGTA\tIIIII\n", "chrS")["anomalies"]
     from clair_amd.create_tensor import PileupError
     for bad in (b"r1\t0\tchrS\n", b"r1\tx\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n", b"\n"):
         with pytest.raises(PileupError):

@@ -333,9 +333,10 @@ def test_text_on_the_device_reports_what_the_host_packer_reports():
     f = fresh()
     f.add_text(b"r1\t0\tchrS\t10\t60\t3M0I2M\t*\t0\t0\tACGTA\tIIIII\n")
     assert f.text_stats()["anomalies"] == fe.A_ZERO_INDEL
-    f = fresh()
-    f.add_text(b"r1\t0\tchrS\t10\t60\t2M200000D3M\t*\t0\t0\tACGTA\tIIIII\n")
-    assert f.text_stats()["anomalies"] == fe.A_LONG_SPAN
+    for cigar in (b"2M200000D3M", b"3000000000S5M"):
+        f = fresh()
+        f.add_text(b"r1\t0\tchrS\t10\t60\t" + cigar + b"\t*\t0\t0\tACGTA\tIIIII\n")
+        assert f.text_stats()["anomalies"] == fe.A_LONG_SPAN
     for bad in (b"r1\t0\tchrS\n", b"r1\tx\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n", b"\n", ok + b"  \n" + ok):
         with pytest.raises(_capi.MalformedText):
             fresh().add_text(bad)
