@@ -278,6 +278,7 @@ struct Candidates {
     const int64_t *centre;       // 1-based, ascending
     const uint32_t *before;      // before[t] = candidates with centre - 1 - lo < t; n + 1 entries
     uint32_t *ins;               // [n_candidates][33][8]
+    const unsigned long long *before_sum;   // before_sum[t] = before[0] + ... + before[t]: windows over a RUN of positions in four look-ups
     // --stop_consider_left_edge only (NULL otherwise): what reads that START inside a window added to the tables under it -- per
     // window and column 8 read-base rows, M per strand, D per strand -- and the tuples per window as range additions over the index
     uint32_t *late;              // [n_candidates][33][12]
@@ -353,6 +354,115 @@ __global__ __launch_bounds__(256) void fe_windows_per_base_kernel(Region g, Slab
         if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned long long *)&s.tuples[r], v);
         todo &= ~__ballot(mine);
     }
+}
+
+// ---- pass 2 with left-edge windows, per OPERATION: the windows open over a run of positions is a difference of sums of the prefix ----
+// F(x) = candidates with centre <= x (the prefix, clamped to the span); G(x) = F(lo) + ... + F(x).  A base at rp lies in F(rp + 17) -
+// F(rp - 18) open windows (rp + 16 for a deleted or inserted base), so an operation over rp = A..B lies in
+// [G(B + 17) - G(A + 16)] - [G(B - 18) - G(A - 19)]: no walk over its bases.  Only a read's very first matched base differs (its
+// windows start one centre later, CreateTensor.py:296-305), and the inserted bases still go to their windows one by one.
+__device__ inline unsigned long long prefix_sum_at(const Region &g, const Candidates &c, int64_t x) {
+    const int64_t i = x - g.lo;
+    if (i < 0) return 0;
+    if (i <= g.n) return c.before_sum[i];
+    return c.before_sum[g.n] + (unsigned long long)(i - g.n) * c.before[g.n];
+}
+
+__global__ __launch_bounds__(256) void fe_windows_per_op_kernel(Region g, SlabView s, Candidates c) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    uint32_t read = 0xffffffffu;
+    unsigned long long nc = 0;
+    if (j < s.n_ops) {
+        const clair_op_t op = s.ops[j];
+        const clair_read_t r = s.reads[op.read];
+        if (r.flags & CLAIR_READ_PILE) {
+            read = op.read;
+            const uint32_t code = op.code_len & 3u;
+            const int64_t len = op.code_len >> 2, pos0 = r.pos0;
+            int64_t a = pos0 + op.ref_off, b = a + len - 1;          // first and last reference position of the run (I: both the same)
+            if (code == CLAIR_OP_M) {
+                if (a == pos0) {                                       // the read's first base: windows of centres POS - 16 .. POS + 17
+                    nc += before_at(g, c, pos0 + 17 - g.lo) - before_at(g, c, pos0 - 17 - g.lo);
+                    ++a;
+                }
+                if (b >= a) nc += (prefix_sum_at(g, c, b + 17) - prefix_sum_at(g, c, a + 16)) - (prefix_sum_at(g, c, b - 18) - prefix_sum_at(g, c, a - 19));
+            } else if (code == CLAIR_OP_D) {
+                if (a == pos0) ++a;                                    // offered before any window is open
+                if (b >= a) nc += (prefix_sum_at(g, c, b + 16) - prefix_sum_at(g, c, a + 15)) - (prefix_sum_at(g, c, b - 18) - prefix_sum_at(g, c, a - 19));
+            } else if (a > pos0) {
+                nc += (unsigned long long)len * (before_at(g, c, a + 16 - g.lo) - before_at(g, c, a - 18 - g.lo));
+                const int so = (r.flags & CLAIR_READ_REVERSE) ? 4 : 0;
+                const uint32_t i0 = before_at(g, c, a - 15 - 1 - g.lo), i1 = before_at(g, c, a + 16 - g.lo);
+                for (int64_t k = 0; k < len && i1 > i0; ++k) {         // generate_tensor :51-53: column min(idx + k, 32), channel 1
+                    if (op.q_off + k >= r.seq_len) break;
+                    const uint8_t row = BASES.pile[s.seq[r.seq0 + op.q_off + k]];
+                    if (row == 255) continue;
+                    for (uint32_t i = i0; i < i1; ++i) {
+                        const int64_t col = a - c.centre[i] + 17 + k;
+                        atomicAdd(&c.ins[((size_t)i * N_POS + (col < N_POS - 1 ? col : N_POS - 1)) * N_ROW + row + so], 1u);
+                    }
+                }
+            }
+        }
+    }
+    unsigned long long todo = __ballot(nc != 0);                       // one atomic per run of equal reads in the wave
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t r = __shfl(read, leader, 64);
+        const bool mine = nc != 0 && read == r;
+        unsigned long long v = mine ? nc : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned long long *)&s.tuples[r], v);
+        todo &= ~__ballot(mine);
+    }
+}
+
+// before[0..n] -> before_sum (inclusive running sum, 64 bit): block sums, one workgroup over them, write
+__device__ inline unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long *total) {   // 256 threads
+    __shared__ unsigned long long wave_sum64[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_sum64[w] = x;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+    for (int i = 0; i < 4; ++i) { if (i < w) before += wave_sum64[i]; all += wave_sum64[i]; }
+    __syncthreads();
+    *total = all;
+    return before + x - v;
+}
+
+__global__ __launch_bounds__(256) void fe_prefix_block_sums_kernel(const uint32_t *before, int64_t n, unsigned long long *block_sum) {
+    const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long v = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (at + i < n) v += before[at + i];
+    unsigned long long total;
+    (void)block_exclusive_scan64(v, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void fe_prefix_scan_sums_kernel(unsigned long long *block_sum, int64_t n_blocks) {
+    unsigned long long carry = 0;
+    for (int64_t at = 0; at < n_blocks; at += 256) {
+        const int64_t i = at + threadIdx.x;
+        unsigned long long total;
+        const unsigned long long ex = block_exclusive_scan64(i < n_blocks ? block_sum[i] : 0, &total);
+        if (i < n_blocks) block_sum[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void fe_prefix_write_kernel(const uint32_t *before, int64_t n, const unsigned long long *block_sum, unsigned long long *before_sum) {
+    const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t f[SCAN_ITEMS];
+    unsigned long long v = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) { f[i] = at + i < n ? before[at + i] : 0; v += f[i]; }
+    unsigned long long total;
+    unsigned long long run = block_sum[blockIdx.x] + block_exclusive_scan64(v, &total);
+    for (int i = 0; i < SCAN_ITEMS && at + i < n; ++i) { run += f[i]; before_sum[at + i] = run; }
 }
 
 // ---- per candidate: was its window ever opened, how many tuples did it hold, does it survive -----------------------------------
@@ -725,6 +835,7 @@ struct clair_frontend {
     int64_t *d_bed = nullptr;
     // windows
     uint32_t *d_ins = nullptr;
+    unsigned long long *d_before_sum = nullptr, *d_prefix_block_sum = nullptr;   // running sum of d_before (pass 2 per operation)
     uint32_t *d_late = nullptr;          // --stop_consider_left_edge only
     int *d_tuple_diff = nullptr;
     uint8_t *d_keep = nullptr;
@@ -798,6 +909,8 @@ int scan_write(clair_frontend *f, const uint8_t *flags, int64_t n, uint32_t *blo
 void free_candidates(clair_frontend *f) {
     (void)hipFree(f->d_centre); f->d_centre = nullptr;
     (void)hipFree(f->d_ins); f->d_ins = nullptr;
+    (void)hipFree(f->d_before_sum); f->d_before_sum = nullptr;
+    (void)hipFree(f->d_prefix_block_sum); f->d_prefix_block_sum = nullptr;
     (void)hipFree(f->d_late); f->d_late = nullptr;
     (void)hipFree(f->d_tuple_diff); f->d_tuple_diff = nullptr;
     (void)hipFree(f->d_keep); f->d_keep = nullptr;
@@ -1146,10 +1259,23 @@ int clair_frontend_build_windows_ex(clair_frontend_t *f, int min_coverage, int d
         FE_TRY(f, hipMemsetAsync(f->d_tuple_diff, 0, ((size_t)room + 1) * sizeof(int), f->stream));
     }
     uint32_t *late = consider_left_edge ? nullptr : f->d_late;
-    Candidates c{f->d_centre, f->d_before, f->d_ins, late, consider_left_edge ? nullptr : f->d_tuple_diff};
+    if (consider_left_edge && nc) {      // the running sum of the candidate prefix: what lets pass 2 go operation by operation
+        const int64_t m = f->g.n + 1;
+        const unsigned nb = blocks_for(m, SCAN_BLOCK);
+        if (!f->d_before_sum) {
+            FE_TRY(f, hipMalloc((void **)&f->d_before_sum, (size_t)m * sizeof(unsigned long long)));
+            FE_TRY(f, hipMalloc((void **)&f->d_prefix_block_sum, ((size_t)nb + 1) * sizeof(unsigned long long)));
+        }
+        hipLaunchKernelGGL(fe_prefix_block_sums_kernel, dim3(nb), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, f->d_prefix_block_sum);
+        hipLaunchKernelGGL(fe_prefix_scan_sums_kernel, dim3(1), dim3(256), 0, f->stream, f->d_prefix_block_sum, (int64_t)nb);
+        hipLaunchKernelGGL(fe_prefix_write_kernel, dim3(nb), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, (const unsigned long long *)f->d_prefix_block_sum, f->d_before_sum);
+    }
+    Candidates c{f->d_centre, f->d_before, f->d_ins, f->d_before_sum, late, consider_left_edge ? nullptr : f->d_tuple_diff};
     for (Slab &s : f->slabs) {
         FE_TRY(f, hipMemsetAsync(s.tuples, 0, (size_t)s.n_reads * sizeof(uint64_t), f->stream));
-        if (s.n_elem && nc) hipLaunchKernelGGL(fe_windows_per_base_kernel, dim3(blocks_for(s.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
+        if (!s.n_elem || !nc) continue;
+        if (consider_left_edge) hipLaunchKernelGGL(fe_windows_per_op_kernel, dim3(blocks_for(s.n_ops, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
+        else hipLaunchKernelGGL(fe_windows_per_base_kernel, dim3(blocks_for(s.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
     }
     WindowRule rule{min_coverage, drop_non_iupac_centre, late};
     if (nc && late) hipLaunchKernelGGL(fe_window_totals_kernel, dim3(1), dim3(256), 0, f->stream, (const int *)f->d_tuple_diff, nc, f->d_window_tuples);
