@@ -59,3 +59,29 @@ def test_concordance_dissects_an_excursion(synth_weights, tmp_path):
     box = gt_concordance.box_info(full=False)
     assert "host" in box and isinstance(box["unique_ids"], list)
     assert isinstance(gt_concordance.gpu_state(), str)
+
+
+def test_fast_reads_are_well_formed_alignments():
+    """tools/fast_reads.py (inputs of the front-end benchmarks): CIGARs consume exactly their SEQ, stay inside the contig, start positions
+    ascend, and the host stages accept them and find candidates at about the advertised density."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fast_reads
+    from clair_amd import _hostapi
+    case = fast_reads.make(ref_len=60000, depth=20, read_len=(500, 3000), seed=2, noisy_every=20)
+    last = 0
+    for line in case["sam"].splitlines():
+        col = line.split(b"\t")
+        ops = re.findall(rb"(\d+)([MID])", col[5])
+        assert b"".join(n + o for n, o in ops) == col[5]
+        q = sum(int(n) for n, o in ops if o in b"MI")
+        r = sum(int(n) for n, o in ops if o in b"MD")
+        pos = int(col[3])
+        assert q == len(col[9]) == len(col[10]) and pos >= last and pos + r - 1 <= case["ref_len"] and ops[0][1] == b"M" and ops[-1][1] == b"M"
+        last = pos
+    f = _hostapi.CandidateFinder(case["ctg"], case["ref"], 0, min_coverage=4, threshold=0.125)
+    assert f.feed(case["sam"]) == b""
+    f.finish()
+    n = len(f.take_positions())
+    assert 60000 / 120 < n < 60000 / 15
