@@ -40,6 +40,13 @@ from . import param
 IUPAC = frozenset("ACGTURYSWKMBDHVN")
 
 
+def view_command(args, region):
+    """`samtools view -F 2316 <bam> <region>` as the reference spawns it (CreateTensor.py:163-170), plus -@ N with --samtools_threads N
+    (BGZF blocks inflated on N extra threads: the text that comes out is the same)."""
+    threads = getattr(args, "samtools_threads", 0) or 0
+    return shlex.split("%s view %s-F %d %s %s" % (args.samtools, "-@ %d " % threads if threads > 0 else "", ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region))
+
+
 def candidate_positions(args, quiet=False):
     """Stage 1.  -> int64 positions (1-based, ascending for sorted alignments)."""
     from . import _hostapi
@@ -59,7 +66,7 @@ def candidate_positions(args, quiet=False):
                                       ctg_start=args.ctgStart if have_range else None, ctg_end=args.ctgEnd if have_range else None,
                                       bed=None if tree is None else tree[args.ctgName],
                                       min_coverage=int(args.minCoverage), threshold=args.threshold, min_mq=0)   # callVarBam.py:75: int() before it reaches the extractor
-    view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+    view = ct.subprocess_popen(view_command(args, region),
                                text=False)
     chunks, tail = [], None
     while True:
@@ -129,7 +136,7 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
     builder = _hostapi.PileupBuilder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1, positions,
                                      consider_left_edge=not args.stop_consider_left_edge, dcov=args.dcov)
     region = "%s:%d-%d" % (args.ctgName, max(1, args.ctgStart - read_flank[0]), args.ctgEnd + read_flank[1]) if have_range else args.ctgName
-    view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+    view = ct.subprocess_popen(view_command(args, region),
                                text=False)
     from .tensor_binary import MAX_CTG, InfoTable, _IUPAC_TABLE
     total = 0
@@ -278,7 +285,7 @@ class DeviceFrontEnd(object):
         except _capi.EngineError as exc:
             sys.exit("[ERROR] %s" % exc)
         pack_kw = dict(dcov=args.dcov, evc_min_mq=0, pile_min_mq=0, pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
-        view = ct.subprocess_popen(shlex.split("%s view -F %d %s %s" % (args.samtools, ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region)),
+        view = ct.subprocess_popen(view_command(args, region),
                                    text=False)
         from time import time
         t_start, t_pack, t_dev = time(), 0.0, 0.0
@@ -631,6 +638,8 @@ def build_parser():
         help="where the candidate search and the pileup run: on the GPU (one pass over the alignments; auto = device, falling back to the host "
              "stages, with a message, where the device formulation does not reproduce the reference exactly) or on the host (two passes, the "
              "sequential code).  --front_end_workers > 1 implies host")
+    add('--samtools_threads', type=int, default=0,
+        help="extra decompression threads for `samtools view` (its -@): with the front end on the device the BAM decoder is what the run waits for")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
     add('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
         help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")

@@ -7,7 +7,7 @@ back.  No samtools exists in this image, so the tests (and tools/make_pileup_gol
 scripts) pass `--samtools "python tests/fake_samtools.py"`: `<bam>` is then a SAM text file.
 
     faidx <fasta> [region ...]   region = ctg | ctg:start-end (1-based, inclusive, clamped); 60 columns per line
-    view -F <int> <sam> [region] alignments with FLAG & int == 0 that overlap the region, header lines dropped
+    view [-@ N] -F <int> <sam> [region] alignments with FLAG & int == 0 that overlap the region, header lines dropped
 """
 import re
 import sys
@@ -55,9 +55,10 @@ def reference_span(cigar):
 
 def view(argv):
     flags = 0
-    if argv and argv[0] == "-F":
-        flags = int(argv[1])
-        argv = argv[2:]
+    while argv and argv[0] in ("-F", "-@"):
+        if argv[0] == "-F":
+            flags = int(argv[1])
+        argv = argv[2:]                      # -@ N: threads, nothing to do here
     path, regions = argv[0], [parse_region(r) for r in argv[1:]]
     with open(path) as f:
         for line in f:

@@ -326,7 +326,8 @@ def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, 
     open(sam, "w").write(case["sam"].rstrip("\n"))                       # no line end after the last alignment
     fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
     args = callVarBam.build_parser().parse_args(["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", fake, "--threshold", "0.15",
-                                                 "--minCoverage", "5"] + region)
+                                                 "--minCoverage", "5", "--samtools_threads", "2"] + region)
+    assert callVarBam.view_command(args, "x:1-2")[1:5] == [os.path.join(HERE, "fake_samtools.py"), "view", "-@", "2"]
     positions = callVarBam.candidate_positions(args, quiet=True)
     want = list(callVarBam.tensor_batches(args, positions, 64, progress=False))
     monkeypatch.setattr(_capi, "Frontend", _StandInFrontend)
