@@ -210,6 +210,117 @@ FE_REASONS = ((1, "alignments not sorted by position"), (2, "a zero-length inser
               (64, "a count beyond int16"), (128, "the reference's budget of 5 M outstanding tuples would run out"), (256, "candidate sites not strictly ascending"))
 
 
+class AlignmentStream(object):
+    """The text of `samtools view <bam> ctg:a-b`, produced by K `samtools view` processes over K consecutive pieces of [a, b] at once
+    (--view_readers K): BAM decoding is what the device front end waits for, and one samtools formats a few hundred MB of text per second.
+    The pieces' outputs, taken in order, are the single stream's lines exactly once each, in its order, when the alignments every piece
+    but the first prints that START before the piece are dropped: they overlap an earlier piece too and were printed there (sorted BAM:
+    those lines are a prefix of the piece's output).  readinto() / close() like the single pipe's."""
+
+    def __init__(self, args, ctg, first, last, readers):
+        import queue
+        import threading
+        edges = [first + (last - first + 1) * k // readers for k in range(readers)] + [last + 1]
+        self.starts = edges[:-1]
+        self.procs = [ct.subprocess_popen(view_command(args, "%s:%d-%d" % (ctg, edges[k], edges[k + 1] - 1)), text=False) for k in range(readers)]
+        self.queues = [queue.Queue(maxsize=16) for _ in range(readers)]          # 16 x 8 MB read ahead per piece
+        self.stop = threading.Event()
+        self.threads = [threading.Thread(target=self._drain, args=(k,), daemon=True) for k in range(readers)]
+        for t in self.threads:
+            t.start()
+        self.piece, self.pending, self.dropping, self.carry = 0, b"", False, b""
+
+    def _drain(self, k):
+        import queue
+        out = self.procs[k].stdout
+        while not self.stop.is_set():
+            chunk = out.read(1 << 23)
+            while not self.stop.is_set():
+                try:
+                    self.queues[k].put(chunk, timeout=0.2)      # b"" = end of this piece
+                    break
+                except queue.Full:
+                    continue
+            if not chunk:
+                return
+
+    def _next_chunk(self):
+        """-> bytes of the merged stream, b"" at its end"""
+        while self.piece < len(self.procs):
+            chunk = self.queues[self.piece].get()
+            if not chunk:
+                last, self.carry = self.carry, b""                   # a last line of the piece without its line end, still undecided
+                keep = b""
+                if last:
+                    col = last.split(None, 4)
+                    if not (self.piece > 0 and len(col) >= 4 and col[3].isdigit() and int(col[3]) < self.starts[self.piece]):
+                        keep = last + b"\n"
+                self.piece += 1
+                self.dropping = True
+                if keep:
+                    return keep
+                continue
+            if self.piece > 0 and self.dropping:
+                # the lines at the head of this piece that start before it: POS is the fourth column
+                data, at, start = self.carry + chunk, 0, self.starts[self.piece]
+                self.carry = b""
+                while True:
+                    nl = data.find(b"\n", at)
+                    if nl < 0:
+                        self.carry = data[at:]                        # no complete line yet
+                        data = b""
+                        break
+                    col = data[at:nl].split(None, 4)
+                    if len(col) >= 4 and col[0][:1] != b"@" and col[3].isdigit() and int(col[3]) < start:
+                        at = nl + 1
+                        continue
+                    self.dropping = False
+                    data = data[at:]
+                    break
+                if not data:
+                    continue
+                return data
+            return chunk
+        return b""
+
+    def readinto(self, mv):
+        if not self.pending:
+            self.pending = self._next_chunk()
+            if not self.pending:
+                return 0
+        n = min(len(mv), len(self.pending))
+        mv[:n] = self.pending[:n]
+        self.pending = self.pending[n:]
+        return n
+
+    def read(self, n):
+        if not self.pending:
+            self.pending = self._next_chunk()
+        out, self.pending = self.pending[:n], self.pending[n:]
+        return out
+
+    def finish(self):
+        """-> 0 when every samtools ended well"""
+        self.stop.set()
+        code = 0
+        for p in self.procs:
+            p.stdout.close()
+            p.wait()
+            code = code or p.returncode
+        return code
+
+
+class _OnePipe(object):
+    def __init__(self, args, region):
+        self.proc = ct.subprocess_popen(view_command(args, region), text=False)
+        self.readinto, self.read = self.proc.stdout.readinto, self.proc.stdout.read
+
+    def finish(self):
+        self.proc.stdout.close()
+        self.proc.wait()
+        return self.proc.returncode
+
+
 class DeviceFrontEnd(object):
     """Both pileup stages on the GPU for one contig / region.  run() -> number of windows, or None when the run has to take the host
     path (reason logged); batches() then yields what tensor_batches yields, with the counts as clair_amd._capi.DeviceWindows."""
@@ -285,8 +396,12 @@ class DeviceFrontEnd(object):
         except _capi.EngineError as exc:
             sys.exit("[ERROR] %s" % exc)
         pack_kw = dict(dcov=args.dcov, evc_min_mq=0, pile_min_mq=0, pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
-        view = ct.subprocess_popen(view_command(args, region),
-                                   text=False)
+        readers = max(1, int(getattr(args, "view_readers", 1) or 1))
+        span = (max(1, args.ctgStart - 2), args.ctgEnd + 2) if have_range else (1, contig_length(args.ref_fn, args.ctgName) or 0)
+        if readers > 1 and span[1] - span[0] + 1 >= 2 * readers:
+            view = AlignmentStream(args, args.ctgName, span[0], span[1], readers)
+        else:
+            view = _OnePipe(args, region)
         from time import time
         t_start, t_pack, t_dev = time(), 0.0, 0.0
         if self.pinned is not None and os.environ.get("CLAIR_AMD_FE_PACK", "device") != "host":
@@ -298,7 +413,7 @@ class DeviceFrontEnd(object):
             fill, eof = 0, False
             while not eof:
                 while fill < TEXT_CHUNK:
-                    n = view.stdout.readinto(mv[fill:TEXT_CHUNK])
+                    n = view.readinto(mv[fill:TEXT_CHUNK])
                     if not n:
                         eof = True
                         break
@@ -333,7 +448,7 @@ class DeviceFrontEnd(object):
             packer = _hostapi.SamPacker(args.ctgName, **pack_kw)
             tail = None
             while True:
-                chunk = view.stdout.read(1 << 23)
+                chunk = view.read(1 << 23)
                 if not chunk:
                     break
                 t0 = time()
@@ -352,9 +467,7 @@ class DeviceFrontEnd(object):
             t_dev += time() - t0
             pst = packer.stats()
         t0 = time()
-        view.stdout.close()
-        view.wait()
-        if view.returncode != 0:
+        if view.finish() != 0:
             sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
         if given is None:
             if pst["evc_reads"] == 0:
@@ -638,6 +751,9 @@ def build_parser():
         help="where the candidate search and the pileup run: on the GPU (one pass over the alignments; auto = device, falling back to the host "
              "stages, with a message, where the device formulation does not reproduce the reference exactly) or on the host (two passes, the "
              "sequential code).  --front_end_workers > 1 implies host")
+    add('--view_readers', type=int, default=1,
+        help="with the front end on the device: read the alignments with this many `samtools view` processes at once, each over a consecutive piece "
+             "of the region (same lines, same order as one)")
     add('--samtools_threads', type=int, default=0,
         help="extra decompression threads for `samtools view` (its -@): with the front end on the device the BAM decoder is what the run waits for")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")

@@ -203,7 +203,7 @@ def test_callVarBam_device_front_end_options_and_fall_back(tmp_path, monkeypatch
     base = ["--chkpnt_fn", ck, "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"],
             "--samtools", FAKE_SAMTOOLS]
     for extra in (["--bed_fn", bed], ["--vcf_fn", sites], ["--dcov", "2", "--ctgStart", "200", "--ctgEnd", "2700"], ["--qual", "30"],
-                  ["--stop_consider_left_edge"], ["--debug"]):                          # --debug: the Python decode reads the tensors (host copies of the windows)
+                  ["--stop_consider_left_edge"], ["--view_readers", "3", "--samtools_threads", "2"], ["--debug"]):                          # --debug: the Python decode reads the tensors (host copies of the windows)
         outs = {}
         for fe in ("device", "host"):
             out = os.path.join(tmp, "%s.vcf" % fe)

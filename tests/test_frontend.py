@@ -311,9 +311,10 @@ class _StandInFrontend(object):
         pass
 
 
+@pytest.mark.parametrize("readers", [1, 3])
 @pytest.mark.parametrize("region", [[], ["--ctgStart", "300", "--ctgEnd", "2500"]], ids=["contig", "region"])
 @pytest.mark.parametrize("chunk", [3000, 1 << 20])
-def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, region, chunk):
+def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, region, chunk, readers):
     """clair_amd.callVarBam.DeviceFrontEnd: the pipe read into a "page-locked" buffer in chunks, whole lines handed on, the unfinished
     line carried over, a stream that ends without a line end -- the batches it yields = those of the host stages (tensor_batches)."""
     import pileup_synth
@@ -326,7 +327,7 @@ def test_callVarBam_device_driver_with_a_stand_in_device(tmp_path, monkeypatch, 
     open(sam, "w").write(case["sam"].rstrip("\n"))                       # no line end after the last alignment
     fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
     args = callVarBam.build_parser().parse_args(["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", fake, "--threshold", "0.15",
-                                                 "--minCoverage", "5", "--samtools_threads", "2"] + region)
+                                                 "--minCoverage", "5", "--samtools_threads", "2", "--view_readers", str(readers)] + region)
     assert callVarBam.view_command(args, "x:1-2")[1:5] == [os.path.join(HERE, "fake_samtools.py"), "view", "-@", "2"]
     positions = callVarBam.candidate_positions(args, quiet=True)
     want = list(callVarBam.tensor_batches(args, positions, 64, progress=False))
@@ -388,3 +389,29 @@ def test_callVarBamParallel_worker_with_stand_ins(tmp_path, monkeypatch):
         assert a == b, out
         rows += len([x for x in a.splitlines() if not x.startswith("#")])
     assert rows > 20
+
+
+@pytest.mark.parametrize("readers", [2, 5])
+def test_several_samtools_at_once_print_the_single_streams_lines(tmp_path, readers):
+    """clair_amd.callVarBam.AlignmentStream: K `samtools view` over K consecutive pieces of a region = the one stream, line for line."""
+    import pileup_synth
+    from clair_amd import callVarBam
+    tmp = str(tmp_path)
+    case = pileup_synth.synth_case(seed=5, n_reads=500, ref_len=4000, read_len=(40, 900), dup_burst=7)
+    sam = os.path.join(tmp, "reads.sam")
+    open(sam, "w").write(case["sam"])
+    fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
+    args = callVarBam.build_parser().parse_args(["--bam_fn", sam, "--ctgName", case["ctg"], "--samtools", fake])
+    for first, last in ((1, 4000), (700, 2900), (3990, 4000)):
+        one = callVarBam._OnePipe(args, "%s:%d-%d" % (case["ctg"], first, last))
+        want = one.read(1 << 30)
+        assert one.finish() == 0
+        many = callVarBam.AlignmentStream(args, case["ctg"], first, last, readers)
+        got, buf = b"", bytearray(777)
+        while True:
+            n = many.readinto(memoryview(buf))
+            if not n:
+                break
+            got += bytes(buf[:n])
+        assert many.finish() == 0
+        assert got == want and (want.count(b"\n") > 100 or first > 3000)
