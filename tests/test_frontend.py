@@ -415,3 +415,40 @@ def test_several_samtools_at_once_print_the_single_streams_lines(tmp_path, reade
             got += bytes(buf[:n])
         assert many.finish() == 0
         assert got == want and (want.count(b"\n") > 100 or first > 3000)
+
+
+def test_callVarBamParallel_worker_stops_when_a_samtools_fails(tmp_path, monkeypatch):
+    """A `samtools view` that dies on one chunk ends the worker with an error instead of leaving that chunk's VCF short."""
+    import pileup_synth
+    from test_decode import _CallsModel
+    from clair_amd import _capi, callVarBam, callVarBamParallel as par, weights
+    tmp = str(tmp_path)
+    case = pileup_synth.synth_case(seed=78, n_reads=150)
+    fa, sam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"])
+    open(os.path.join(tmp, "model.npz"), "w").close()
+    flaky = os.path.join(tmp, "flaky.py")
+    open(flaky, "w").write("import subprocess, sys\n"
+                           "if sys.argv[1] == 'view' and any(a.startswith('%s:1598-') for a in sys.argv): sys.exit(3)\n"
+                           "sys.exit(subprocess.run([sys.executable, %r] + sys.argv[1:]).returncode)\n" % (case["ctg"], os.path.join(HERE, "fake_samtools.py")))
+    w = weights.synthetic_weights(seed=4242, head_gain=6.0, lstm_bias_scale=0.1)
+
+    class Model(_CallsModel):
+        def submit_calls(self, slot, batch, centre, counts=False, with_probabilities=False):
+            if isinstance(batch, _capi.DeviceWindows):
+                batch, counts = batch.host(), True
+            _CallsModel.submit_calls(self, slot, batch, centre, counts=counts, with_probabilities=with_probabilities)
+
+        def close(self):
+            pass
+    monkeypatch.setattr(callVarBam, "load_model", lambda args: Model(w))
+    monkeypatch.setattr(_capi, "Frontend", _StandInFrontend)
+    common = ["--chkpnt_fn", os.path.join(tmp, "model"), "--bam_fn", sam, "--ref_fn", fa, "--samtools", "%s %s" % (sys.executable, flaky), "--includingAllContigs",
+              "--refChunkSize", "800", "--threshold", "0.15", "--minCoverage", "5", "--batch_size", "64", "--python", "PY"]
+    lines = par.commands(par.build_parser().parse_args(common + ["--output_prefix", os.path.join(tmp, "all", "var")]))
+    os.makedirs(os.path.join(tmp, "all"))
+    assert any('--ctgStart "1600"' in l for l in lines)
+    with pytest.raises(SystemExit, match="samtools view"):
+        par.run_worker(lines, 0, 2)
