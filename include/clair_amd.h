@@ -138,7 +138,8 @@ int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int 
  * host-side copy to make them contiguous.  centre: [n][2] bytes per candidate -- the centre character of its reference window (refseq[16],
  * clair/call_var.py:1015) and min(length of refseq, 255); required when calls != NULL.  calls: caller's array of n records, or NULL.
  * gt21 / genotype / indel_len1 / indel_len2: all four or all NULL (NULL: the probabilities stay on the device).  Pair with
- * clair_wait(slot); buffers must stay valid until it returns. */
+ * clair_wait(slot); buffers must stay valid until it returns.  `input` may also be a DEVICE address of int16 counts (the windows
+ * clair_frontend_build_windows leaves in HBM, clair_frontend_counts_device): nothing is copied then. */
 int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is_counts, int64_t input_stride_bytes, int n,
                     const uint8_t *centre, clair_call_t *calls, float *gt21, float *genotype, float *indel_len1, float *indel_len2);
 
