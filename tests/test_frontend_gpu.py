@@ -355,3 +355,19 @@ def test_text_on_the_device_reports_what_the_host_packer_reports():
     assert f.stats()["windows"] == g.stats()["windows"] > 0
     for a, b in zip(windows_of(f), windows_of(g)):
         assert np.array_equal(a, b)
+
+
+def test_text_of_long_reads_is_parsed_a_wave_per_line():
+    """Lines beyond 2 KB on average take the wave-per-line kernels: same alignments, same windows."""
+    case = fc.synth(9, n_reads=1200, ref_len=30000, read_len=(1500, 6000), cand_step=(1, 30))
+    assert len(case["sam"]) / case["sam"].count(b"\n") > 2048
+    (r, o, e, q), st = host_packed(case)
+    f = device_frontend_text(case, chunks=3)
+    got = np.concatenate(f.slab_reads)
+    assert f.text_stats() == dict(lines=st["lines"], evc_reads=st["evc_reads"], pile_reads=st["pile_reads"], anomalies=0)
+    assert np.array_equal(got["pos0"], r["pos0"]) and np.array_equal(got["flags"], r["flags"]) and np.array_equal(got["n_ops"], r["n_ops"])
+    hc, hs, hcounts = fc.host_windows(case)
+    f.set_candidates(case["candidates"])
+    f.build_windows(drop_non_iupac_centre=False)
+    centres, seqs, counts = windows_of(f)
+    assert f.stats()["anomalies"] == 0 and np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts) and len(hc) > 500
