@@ -357,8 +357,8 @@ def test_text_on_the_device_reports_what_the_host_packer_reports():
         assert np.array_equal(a, b)
 
 
-def test_text_of_long_reads_is_parsed_a_wave_per_line():
-    """Lines beyond 2 KB on average take the wave-per-line kernels: same alignments, same windows."""
+def test_text_of_long_reads():
+    """Long lines (several KB of CIGAR and SEQ each) through the text kernels: same alignments, same windows."""
     case = fc.synth(9, n_reads=1200, ref_len=30000, read_len=(1500, 6000), cand_step=(1, 30))
     assert len(case["sam"]) / case["sam"].count(b"\n") > 2048
     (r, o, e, q), st = host_packed(case)
