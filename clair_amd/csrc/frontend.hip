@@ -609,8 +609,22 @@ struct TextWindow {
 
 // end of the token that starts at q: 16 bytes at a time while none of them is below 0x21 (every white-space character is; SEQ and QUAL
 // bytes are not), byte by byte from the first word that holds one
+// LANES == 64: the whole wave stands for one line (every lane runs the same scalar code on the same bytes -- one broadcast load each)
+// and this search is shared out, a kilobyte per step.  With a thread per line a wave gathers 64 different cache lines per 16-byte
+// step, 344 dependent steps for a 5.5 kb read; with a wave per line it is six.
+template <int LANES>
 __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
     while (q < end && (q & 15)) { if (text_space(t[q])) return q; ++q; }
+    if (LANES == 64) {
+        const int lane = threadIdx.x & 63;
+        while (q + 1024 <= end) {
+            const uint4 w = *(const uint4 *)(t + q + lane * 16);
+            const uint32_t low = ((w.x - 0x21212121u) & ~w.x) | ((w.y - 0x21212121u) & ~w.y) | ((w.z - 0x21212121u) & ~w.z) | ((w.w - 0x21212121u) & ~w.w);
+            const unsigned long long hit = __ballot((low & 0x80808080u) != 0);
+            if (hit) { q += 16 * (__ffsll((long long)hit) - 1); break; }
+            q += 1024;
+        }
+    }
     while (q + 16 <= end) {
         const uint4 w = *(const uint4 *)(t + q);
         const uint32_t low = ((w.x - 0x21212121u) & ~w.x) | ((w.y - 0x21212121u) & ~w.y) | ((w.z - 0x21212121u) & ~w.z) | ((w.w - 0x21212121u) & ~w.w);
@@ -624,7 +638,8 @@ __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
 // walks a CIGAR; EMIT writes the kept operations
 template <bool EMIT>
 __device__ inline void walk_cigar(TextWindow &tw, int64_t cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
-                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
+                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero,
+                                  bool writer = true) {
     int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
     uint32_t n_ops = 0;
     uint64_t elems = 0;
@@ -644,7 +659,7 @@ __device__ inline void walk_cigar(TextWindow &tw, int64_t cg, uint32_t cl, uint3
         if (code >= 0) {
             if (adv > 0) {
                 const int64_t len = adv > 0x3fffffff ? 0x3fffffff : adv;
-                if (EMIT) {
+                if (EMIT && writer) {
                     ops[n_ops] = clair_op_t{read, (uint32_t)len << 2 | (uint32_t)code, (int32_t)rp, (uint32_t)qp};
                     op_elem[n_ops] = elem0 + (uint32_t)elems;
                 }
@@ -677,12 +692,14 @@ __device__ inline bool text_int(TextWindow &tw, int64_t s, uint32_t len, int64_t
     return true;
 }
 
+template <int LANES>
 __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text, const int64_t *newline, int64_t n_lines, TextOptions opt, TextLine *lines,
                                                             uint8_t *is_candidate, TextState *state) {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
     if (k >= n_lines) return;
+    const bool writer = LANES == 1 || (threadIdx.x & 63) == 0;
     TextLine out{};
-    is_candidate[k] = 0;
+    if (writer) is_candidate[k] = 0;
     const int64_t begin = k == 0 ? 0 : newline[k - 1] + 1, end = newline[k];
     uint32_t col[10], len[10];
     int n = 0;
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
         if (p >= end) break;
         // the short leading columns byte by byte out of the window, SEQ (and CIGAR) by the 16-byte search
         int64_t q = p;
-        if (n == 5 || n == 9) q = token_end(text, p, end);
+        if (n == 5 || n == 9) q = token_end<LANES>(text, p, end);
         else while (q < end && !text_space(tw.at(q))) ++q;
         col[n] = (uint32_t)p;
         len[n] = (uint32_t)(q - p);
@@ -701,13 +718,12 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
         p = q;
     }
     bool bad = n == 0;
-    if (!bad && tw.at(col[0]) == '@') { lines[k] = out; return; }            // header line
+    if (!bad && tw.at(col[0]) == '@') { if (writer) lines[k] = out; return; }   // header line
     bad = bad || n < 10;
     int64_t flag = 0, pos1 = 0, mq = 0;
     bad = bad || !text_int(tw, col[1], len[1], &flag) || !text_int(tw, col[3], len[3], &pos1) || !text_int(tw, col[4], len[4], &mq);
     if (bad) {                                                                // the host packer names the line and the column
-        atomicMin(&state->malformed, (uint32_t)(k + 1));
-        lines[k] = out;
+        if (writer) { atomicMin(&state->malformed, (uint32_t)(k + 1)); lines[k] = out; }
         return;
     }
     bool same_ctg = (int)len[2] == opt.ctg_len;
@@ -731,8 +747,7 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     out.n_elem = elems > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)elems;
     out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0)
                 | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) ? TL_LONG_SPAN : 0);
-    lines[k] = out;
-    is_candidate[k] = candidate ? 1 : 0;
+    if (writer) { lines[k] = out; is_candidate[k] = candidate ? 1 : 0; }
 }
 
 // --dcov: the rank of a pileup read among those of its start position = its index among the candidates minus the lower bound of its
@@ -816,16 +831,19 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
     }
 }
 
+template <int LANES>
 __global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, const TextLine *lines, const int64_t *kept, int64_t n_kept, const uint32_t *op0,
                                                            const uint32_t *elem0, clair_read_t *reads, clair_op_t *ops, uint32_t *op_elem, uint64_t total_ops,
                                                            uint64_t total_elems) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) op_elem[total_ops] = (uint32_t)total_elems;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
+    const bool writer = LANES == 1 || (threadIdx.x & 63) == 0;
+    if (i == 0 && writer) op_elem[total_ops] = (uint32_t)total_elems;
     if (i >= n_kept) return;
     const TextLine ln = lines[kept[i]];
     TextWindow tw{text, -16, {}};
     walk_cigar<true>(tw, ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr);
+                     nullptr, writer);
+    if (!writer) return;
     clair_read_t r;
     r.pos0 = ln.pos0;
     r.seq0 = ln.seq_off;
@@ -1108,8 +1126,13 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     TextState carry = f->text_state;
     carry.malformed = 0xffffffffu;
     FE_TRY(f, hipMemcpyAsync(f->d_text_state, &carry, sizeof carry, hipMemcpyHostToDevice, f->stream));
-    hipLaunchKernelGGL(fe_text_lines_kernel, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
-                       f->text_opt, lines, is_cand, f->d_text_state);
+    const bool long_lines = len / n_lines > 2048;         // a wave per line for long reads, a thread per line for short ones
+    if (long_lines)
+        hipLaunchKernelGGL(fe_text_lines_kernel<64>, dim3(blocks_for(n_lines * 64, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
+                           f->text_opt, lines, is_cand, f->d_text_state);
+    else
+        hipLaunchKernelGGL(fe_text_lines_kernel<1>, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
+                           f->text_opt, lines, is_cand, f->d_text_state);
     FE_TRY(f, hipGetLastError());
     int64_t n_cand = 0, n_kept = 0;
     if (scan_count(f, is_cand, n_lines, line_sum, d_count + 1, &n_cand)) return 1;
@@ -1154,8 +1177,12 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     d.seq = d_text;                     // the bases stay where samtools printed them
     tmp.keep(d_text);
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
-    hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
-                       (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+    if (long_lines)
+        hipLaunchKernelGGL(fe_text_emit_kernel<64>, dim3(blocks_for(n_kept * 64, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines,
+                           (const int64_t *)kept, n_kept, (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+    else
+        hipLaunchKernelGGL(fe_text_emit_kernel<1>, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines,
+                           (const int64_t *)kept, n_kept, (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
     if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
