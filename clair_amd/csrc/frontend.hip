@@ -591,40 +591,10 @@ struct TextState {                       // carried from chunk to chunk (host co
 
 __device__ inline bool text_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
 
-// Bytes of the text through a 16-byte window held in registers: a line is walked by ONE thread, and a chain of dependent single-byte
-// loads (half a microsecond each) is what a line costs -- a thousand CIGAR characters were 0.6 ms, whatever the occupancy.  The text
-// buffer is 16-byte aligned and padded (hipMalloc), so the aligned block around any of its bytes can be loaded whole.
-struct TextWindow {
-    const uint8_t *text;
-    int64_t base;            // first byte held, a multiple of 16; -16: nothing yet
-    uint4 w;
-    __device__ inline uint8_t at(int64_t i) {
-        const int64_t b = i & ~(int64_t)15;
-        if (b != base) { w = *(const uint4 *)(text + b); base = b; }
-        const int j = (int)(i & 15);
-        const uint32_t x = j < 8 ? (j < 4 ? w.x : w.y) : (j < 12 ? w.z : w.w);
-        return (uint8_t)(x >> ((j & 3) * 8));
-    }
-};
-
 // end of the token that starts at q: 16 bytes at a time while none of them is below 0x21 (every white-space character is; SEQ and QUAL
 // bytes are not), byte by byte from the first word that holds one
-// LANES == 64: the whole wave stands for one line (every lane runs the same scalar code on the same bytes -- one broadcast load each)
-// and this search is shared out, a kilobyte per step.  With a thread per line a wave gathers 64 different cache lines per 16-byte
-// step, 344 dependent steps for a 5.5 kb read; with a wave per line it is six.
-template <int LANES>
 __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
     while (q < end && (q & 15)) { if (text_space(t[q])) return q; ++q; }
-    if (LANES == 64) {
-        const int lane = threadIdx.x & 63;
-        while (q + 1024 <= end) {
-            const uint4 w = *(const uint4 *)(t + q + lane * 16);
-            const uint32_t low = ((w.x - 0x21212121u) & ~w.x) | ((w.y - 0x21212121u) & ~w.y) | ((w.z - 0x21212121u) & ~w.z) | ((w.w - 0x21212121u) & ~w.w);
-            const unsigned long long hit = __ballot((low & 0x80808080u) != 0);
-            if (hit) { q += 16 * (__ffsll((long long)hit) - 1); break; }
-            q += 1024;
-        }
-    }
     while (q + 16 <= end) {
         const uint4 w = *(const uint4 *)(t + q);
         const uint32_t low = ((w.x - 0x21212121u) & ~w.x) | ((w.y - 0x21212121u) & ~w.y) | ((w.z - 0x21212121u) & ~w.z) | ((w.w - 0x21212121u) & ~w.w);
@@ -637,15 +607,14 @@ __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
 
 // walks a CIGAR; EMIT writes the kept operations
 template <bool EMIT>
-__device__ inline void walk_cigar(TextWindow &tw, int64_t cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
-                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero,
-                                  bool writer = true) {
+__device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
+                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
     int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
     uint32_t n_ops = 0;
     uint64_t elems = 0;
     bool zero = false;
     for (uint32_t i = 0; i < cl; ++i) {
-        const uint8_t ch = tw.at(cg + i);
+        const uint8_t ch = cg[i];
         if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); if (adv > ((int64_t)1 << 40)) adv = (int64_t)1 << 40; continue; }
         int code = -1;
         switch (ch) {
@@ -659,7 +628,7 @@ __device__ inline void walk_cigar(TextWindow &tw, int64_t cg, uint32_t cl, uint3
         if (code >= 0) {
             if (adv > 0) {
                 const int64_t len = adv > 0x3fffffff ? 0x3fffffff : adv;
-                if (EMIT && writer) {
+                if (EMIT) {
                     ops[n_ops] = clair_op_t{read, (uint32_t)len << 2 | (uint32_t)code, (int32_t)rp, (uint32_t)qp};
                     op_elem[n_ops] = elem0 + (uint32_t)elems;
                 }
@@ -677,63 +646,57 @@ __device__ inline void walk_cigar(TextWindow &tw, int64_t cg, uint32_t cl, uint3
     if (!EMIT) { *o_rp = rp; *o_qp = qp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; }
 }
 
-__device__ inline bool text_int(TextWindow &tw, int64_t s, uint32_t len, int64_t *out) {     // [+-]digits, at most 18 of them (host_sampack.cpp)
+__device__ inline bool text_int(const uint8_t *s, uint32_t len, int64_t *out) {     // [+-]digits, at most 18 of them (host_sampack.cpp)
     uint32_t i = 0;
     bool neg = false;
-    if (i < len && (tw.at(s) == '-' || tw.at(s) == '+')) { neg = tw.at(s) == '-'; ++i; }
+    if (i < len && (s[i] == '-' || s[i] == '+')) { neg = s[i] == '-'; ++i; }
     if (i == len || len - i > 18) return false;
     int64_t x = 0;
     for (; i < len; ++i) {
-        const uint8_t c = tw.at(s + i);
-        if (c < '0' || c > '9') return false;
-        x = x * 10 + (c - '0');
+        if (s[i] < '0' || s[i] > '9') return false;
+        x = x * 10 + (s[i] - '0');
     }
     *out = neg ? -x : x;
     return true;
 }
 
-template <int LANES>
 __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text, const int64_t *newline, int64_t n_lines, TextOptions opt, TextLine *lines,
                                                             uint8_t *is_candidate, TextState *state) {
-    const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_lines) return;
-    const bool writer = LANES == 1 || (threadIdx.x & 63) == 0;
     TextLine out{};
-    if (writer) is_candidate[k] = 0;
+    is_candidate[k] = 0;
     const int64_t begin = k == 0 ? 0 : newline[k - 1] + 1, end = newline[k];
     uint32_t col[10], len[10];
     int n = 0;
     int64_t p = begin;
-    TextWindow tw{text, -16, {}};
     while (p < end && n < 10) {
-        while (p < end && text_space(tw.at(p))) ++p;
+        while (p < end && text_space(text[p])) ++p;
         if (p >= end) break;
-        // the short leading columns byte by byte out of the window, SEQ (and CIGAR) by the 16-byte search
-        int64_t q = p;
-        if (n == 5 || n == 9) q = token_end<LANES>(text, p, end);
-        else while (q < end && !text_space(tw.at(q))) ++q;
+        const int64_t q = token_end(text, p, end);
         col[n] = (uint32_t)p;
         len[n] = (uint32_t)(q - p);
         ++n;
         p = q;
     }
     bool bad = n == 0;
-    if (!bad && tw.at(col[0]) == '@') { if (writer) lines[k] = out; return; }   // header line
+    if (!bad && text[col[0]] == '@') { lines[k] = out; return; }            // header line
     bad = bad || n < 10;
     int64_t flag = 0, pos1 = 0, mq = 0;
-    bad = bad || !text_int(tw, col[1], len[1], &flag) || !text_int(tw, col[3], len[3], &pos1) || !text_int(tw, col[4], len[4], &mq);
+    bad = bad || !text_int(text + col[1], len[1], &flag) || !text_int(text + col[3], len[3], &pos1) || !text_int(text + col[4], len[4], &mq);
     if (bad) {                                                                // the host packer names the line and the column
-        if (writer) { atomicMin(&state->malformed, (uint32_t)(k + 1)); lines[k] = out; }
+        atomicMin(&state->malformed, (uint32_t)(k + 1));
+        lines[k] = out;
         return;
     }
     bool same_ctg = (int)len[2] == opt.ctg_len;
-    for (int i = 0; same_ctg && i < opt.ctg_len; ++i) same_ctg = tw.at(col[2] + i) == opt.ctg[i];
+    for (int i = 0; same_ctg && i < opt.ctg_len; ++i) same_ctg = text[col[2] + i] == opt.ctg[i];
     int64_t rp, qp, soft, total, rlen;
     uint32_t n_ops;
     uint64_t elems;
     bool zero;
-    walk_cigar<false>(tw, col[5], len[5], 0, nullptr, nullptr, 0, &rp, &qp, &soft, &total, &rlen, &n_ops, &elems, &zero);
-    const bool evc_ok = same_ctg && mq >= opt.evc_min_mq && !(len[5] == 1 && tw.at(col[5]) == '*') && !(1.0 - (double)soft / (double)(total + 1) < 0.55);
+    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &qp, &soft, &total, &rlen, &n_ops, &elems, &zero);
+    const bool evc_ok = same_ctg && mq >= opt.evc_min_mq && !(len[5] == 1 && text[col[5]] == '*') && !(1.0 - (double)soft / (double)(total + 1) < 0.55);
     bool in_region = true;
     if (opt.pile_start >= 0 && opt.pile_end >= 0) {
         const int64_t end1 = pos1 + (rlen > 0 ? rlen : 1) - 1;                // bam_endpos
@@ -747,7 +710,8 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     out.n_elem = elems > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)elems;
     out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0)
                 | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) ? TL_LONG_SPAN : 0);
-    if (writer) { lines[k] = out; is_candidate[k] = candidate ? 1 : 0; }
+    lines[k] = out;
+    is_candidate[k] = candidate ? 1 : 0;
 }
 
 // --dcov: the rank of a pileup read among those of its start position = its index among the candidates minus the lower bound of its
@@ -831,19 +795,15 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
     }
 }
 
-template <int LANES>
 __global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, const TextLine *lines, const int64_t *kept, int64_t n_kept, const uint32_t *op0,
                                                            const uint32_t *elem0, clair_read_t *reads, clair_op_t *ops, uint32_t *op_elem, uint64_t total_ops,
                                                            uint64_t total_elems) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
-    const bool writer = LANES == 1 || (threadIdx.x & 63) == 0;
-    if (i == 0 && writer) op_elem[total_ops] = (uint32_t)total_elems;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) op_elem[total_ops] = (uint32_t)total_elems;
     if (i >= n_kept) return;
     const TextLine ln = lines[kept[i]];
-    TextWindow tw{text, -16, {}};
-    walk_cigar<true>(tw, ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, writer);
-    if (!writer) return;
+    walk_cigar<true>(text + ln.cigar_off, ln.cigar_len, (uint32_t)i, ops + op0[i], op_elem + op0[i], elem0[i], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr);
     clair_read_t r;
     r.pos0 = ln.pos0;
     r.seq0 = ln.seq_off;
@@ -1107,7 +1067,7 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     } tmp;
     uint8_t *d_text = nullptr;
     uint32_t *block_sum = nullptr, *d_count = nullptr;
-    FE_TRY(f, tmp.get((void **)&d_text, (size_t)len + 16));      // + 16: the aligned block around the last byte (TextWindow)
+    FE_TRY(f, tmp.get((void **)&d_text, (size_t)len));
     FE_TRY(f, tmp.get((void **)&block_sum, ((size_t)blocks_for(len + 1, SCAN_BLOCK) + 2) * sizeof(uint32_t)));
     FE_TRY(f, tmp.get((void **)&d_count, 4 * sizeof(uint32_t)));
     FE_TRY(f, hipMemcpyAsync(d_text, sam, (size_t)len, hipMemcpyHostToDevice, f->stream));
@@ -1126,13 +1086,8 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     TextState carry = f->text_state;
     carry.malformed = 0xffffffffu;
     FE_TRY(f, hipMemcpyAsync(f->d_text_state, &carry, sizeof carry, hipMemcpyHostToDevice, f->stream));
-    const bool long_lines = len / n_lines > 2048;         // a wave per line for long reads, a thread per line for short ones
-    if (long_lines)
-        hipLaunchKernelGGL(fe_text_lines_kernel<64>, dim3(blocks_for(n_lines * 64, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
-                           f->text_opt, lines, is_cand, f->d_text_state);
-    else
-        hipLaunchKernelGGL(fe_text_lines_kernel<1>, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
-                           f->text_opt, lines, is_cand, f->d_text_state);
+    hipLaunchKernelGGL(fe_text_lines_kernel, dim3(blocks_for(n_lines, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const int64_t *)newline, n_lines,
+                       f->text_opt, lines, is_cand, f->d_text_state);
     FE_TRY(f, hipGetLastError());
     int64_t n_cand = 0, n_kept = 0;
     if (scan_count(f, is_cand, n_lines, line_sum, d_count + 1, &n_cand)) return 1;
@@ -1177,12 +1132,8 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     d.seq = d_text;                     // the bases stay where samtools printed them
     tmp.keep(d_text);
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
-    if (long_lines)
-        hipLaunchKernelGGL(fe_text_emit_kernel<64>, dim3(blocks_for(n_kept * 64, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines,
-                           (const int64_t *)kept, n_kept, (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
-    else
-        hipLaunchKernelGGL(fe_text_emit_kernel<1>, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines,
-                           (const int64_t *)kept, n_kept, (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+    hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
+                       (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
     if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
