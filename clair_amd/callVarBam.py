@@ -355,6 +355,8 @@ class DeviceFrontEnd(object):
         except _capi.MalformedText:
             raise
         except _capi.EngineError as exc:
+            if "out of memory" in str(exc).lower():       # tables for the whole region + the resident text: too much for what is free on this GPU
+                return self._fallback("not enough device memory for the region: %s" % exc)
             sys.exit("[ERROR] %s" % exc)
 
     def _run(self):
@@ -391,10 +393,7 @@ class DeviceFrontEnd(object):
         else:
             lo, hi = ref0 - TABLE_MARGIN, ref0 + len(seq) + TABLE_MARGIN
             region = args.ctgName
-        try:
-            f = self.frontend = _capi.Frontend(self.device, seq, ref0, lo, hi)
-        except _capi.EngineError as exc:
-            sys.exit("[ERROR] %s" % exc)
+        f = self.frontend = _capi.Frontend(self.device, seq, ref0, lo, hi)
         pack_kw = dict(dcov=args.dcov, evc_min_mq=0, pile_min_mq=0, pile_region=(args.ctgStart, args.ctgEnd) if have_range else None)
         readers = max(1, int(getattr(args, "view_readers", 1) or 1))
         span = (max(1, args.ctgStart - 2), args.ctgEnd + 2) if have_range else (1, contig_length(args.ref_fn, args.ctgName) or 0)

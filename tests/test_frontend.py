@@ -452,3 +452,29 @@ def test_callVarBamParallel_worker_stops_when_a_samtools_fails(tmp_path, monkeyp
     assert any('--ctgStart "1600"' in l for l in lines)
     with pytest.raises(SystemExit, match="samtools view"):
         par.run_worker(lines, 0, 2)
+
+
+def test_device_driver_hands_back_when_the_region_does_not_fit(tmp_path, monkeypatch, caplog):
+    """Out of device memory for the tables: `auto` runs the host stages and says so, `device` stops."""
+    import logging
+    import pileup_synth
+    from clair_amd import _capi, callVarBam
+    tmp = str(tmp_path)
+    case = pileup_synth.synth_case(seed=1, n_reads=20)
+    fa, sam = os.path.join(tmp, "r.fa"), os.path.join(tmp, "r.sam")
+    open(fa, "w").write(case["fasta"])
+    open(fa + ".fai", "w").write("%s\t%d\t6\t60\t61\n" % (case["ctg"], case["ref_len"]))
+    open(sam, "w").write(case["sam"])
+
+    class NoRoom(object):
+        def __init__(self, *a):
+            raise _capi.EngineError("clair_frontend_create failed: hipMalloc(read-base counters) failed: out of memory")
+    monkeypatch.setattr(_capi, "Frontend", NoRoom)
+    fake = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
+    args = callVarBam.build_parser().parse_args(["--bam_fn", sam, "--ref_fn", fa, "--ctgName", case["ctg"], "--samtools", fake])
+    with caplog.at_level(logging.INFO):
+        assert callVarBam.DeviceFrontEnd(args, 0).run() is None
+    assert "not enough device memory" in caplog.text
+    args.front_end = "device"
+    with pytest.raises(SystemExit, match="not enough device memory"):
+        callVarBam.DeviceFrontEnd(args, 0).run()
