@@ -299,6 +299,17 @@ class AlignmentStream(object):
         out, self.pending = self.pending[:n], self.pending[n:]
         return out
 
+    def abort(self):
+        """The consumer gave up: do not leave K samtools writing into full pipes."""
+        self.stop.set()
+        for p in self.procs:
+            try:
+                p.kill()
+                p.stdout.close()
+                p.wait()
+            except OSError:
+                pass
+
     def finish(self):
         """-> 0 when every samtools ended well"""
         self.stop.set()
@@ -314,6 +325,14 @@ class _OnePipe(object):
     def __init__(self, args, region):
         self.proc = ct.subprocess_popen(view_command(args, region), text=False)
         self.readinto, self.read = self.proc.stdout.readinto, self.proc.stdout.read
+
+    def abort(self):
+        try:
+            self.proc.kill()
+            self.proc.stdout.close()
+            self.proc.wait()
+        except OSError:
+            pass
 
     def finish(self):
         self.proc.stdout.close()
@@ -403,68 +422,72 @@ class DeviceFrontEnd(object):
             view = _OnePipe(args, region)
         from time import time
         t_start, t_pack, t_dev = time(), 0.0, 0.0
-        if self.pinned is not None and os.environ.get("CLAIR_AMD_FE_PACK", "device") != "host":
-            # the text goes to the GPU as it comes out of the pipe (read into a page-locked buffer, whole lines at a time) and is
-            # parsed there: the host touches no byte of it but the last megabyte of each chunk, looking for the line end
-            f.text_options(args.ctgName, **pack_kw)
-            buf = self.pinned(TEXT_CHUNK + 16)
-            mv = memoryview(buf)
-            fill, eof = 0, False
-            while not eof:
-                while fill < TEXT_CHUNK:
-                    n = view.readinto(mv[fill:TEXT_CHUNK])
-                    if not n:
-                        eof = True
-                        break
-                    fill += n
-                cut = fill
-                if not eof:
-                    cut, span = -1, 1 << 20
-                    while cut < 0:
-                        lo_ = max(0, fill - span)
-                        k = bytes(mv[lo_:fill]).rfind(b"\n")
-                        cut = lo_ + k + 1 if k >= 0 else -1
-                        if lo_ == 0:
+        try:
+            if self.pinned is not None and os.environ.get("CLAIR_AMD_FE_PACK", "device") != "host":
+                # the text goes to the GPU as it comes out of the pipe (read into a page-locked buffer, whole lines at a time) and is
+                # parsed there: the host touches no byte of it but the last megabyte of each chunk, looking for the line end
+                f.text_options(args.ctgName, **pack_kw)
+                buf = self.pinned(TEXT_CHUNK + 16)
+                mv = memoryview(buf)
+                fill, eof = 0, False
+                while not eof:
+                    while fill < TEXT_CHUNK:
+                        n = view.readinto(mv[fill:TEXT_CHUNK])
+                        if not n:
+                            eof = True
                             break
-                        span *= 4
-                    if cut <= 0:
-                        sys.exit("[ERROR] an alignment line longer than %d bytes" % TEXT_CHUNK)
-                elif fill and buf[fill - 1] != 10:             # the stream ended without a line end
-                    buf[fill] = 10
-                    fill = cut = fill + 1
-                if cut:
+                        fill += n
+                    cut = fill
+                    if not eof:
+                        cut, span = -1, 1 << 20
+                        while cut < 0:
+                            lo_ = max(0, fill - span)
+                            k = bytes(mv[lo_:fill]).rfind(b"\n")
+                            cut = lo_ + k + 1 if k >= 0 else -1
+                            if lo_ == 0:
+                                break
+                            span *= 4
+                        if cut <= 0:
+                            sys.exit("[ERROR] an alignment line longer than %d bytes" % TEXT_CHUNK)
+                    elif fill and buf[fill - 1] != 10:             # the stream ended without a line end
+                        buf[fill] = 10
+                        fill = cut = fill + 1
+                    if cut:
+                        t0 = time()
+                        try:
+                            f.add_text(buf.ctypes.data, cut)
+                        except _capi.MalformedText:
+                            _hostapi.SamPacker(args.ctgName, **pack_kw).feed(bytes(mv[:cut]), final=True)     # raises with the line and the column
+                            raise
+                        t_dev += time() - t0
+                    buf[:fill - cut] = buf[cut:fill]
+                    fill -= cut
+                pst = f.text_stats()
+            else:
+                packer = _hostapi.SamPacker(args.ctgName, **pack_kw)
+                tail = None
+                while True:
+                    chunk = view.read(1 << 23)
+                    if not chunk:
+                        break
                     t0 = time()
-                    try:
-                        f.add_text(buf.ctypes.data, cut)
-                    except _capi.MalformedText:
-                        _hostapi.SamPacker(args.ctgName, **pack_kw).feed(bytes(mv[:cut]), final=True)     # raises with the line and the column
-                        raise
-                    t_dev += time() - t0
-                buf[:fill - cut] = buf[cut:fill]
-                fill -= cut
-            pst = f.text_stats()
-        else:
-            packer = _hostapi.SamPacker(args.ctgName, **pack_kw)
-            tail = None
-            while True:
-                chunk = view.read(1 << 23)
-                if not chunk:
-                    break
+                    tail = packer.feed(chunk if tail is None else tail + chunk)
+                    t_pack += time() - t0
+                    if packer.stats()["seq_bytes"] >= SLAB_BYTES:
+                        t0 = time()
+                        f.add_slab(packer)
+                        t_dev += time() - t0
                 t0 = time()
-                tail = packer.feed(chunk if tail is None else tail + chunk)
+                if tail:
+                    packer.feed(tail, final=True)
                 t_pack += time() - t0
-                if packer.stats()["seq_bytes"] >= SLAB_BYTES:
-                    t0 = time()
-                    f.add_slab(packer)
-                    t_dev += time() - t0
-            t0 = time()
-            if tail:
-                packer.feed(tail, final=True)
-            t_pack += time() - t0
-            t0 = time()
-            f.add_slab(packer)
-            t_dev += time() - t0
-            pst = packer.stats()
+                t0 = time()
+                f.add_slab(packer)
+                t_dev += time() - t0
+                pst = packer.stats()
+        except BaseException:
+            view.abort()
+            raise
         t0 = time()
         if view.finish() != 0:
             sys.exit("[ERROR] `samtools view` failed on %s" % args.bam_fn)
