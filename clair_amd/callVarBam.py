@@ -44,7 +44,9 @@ def view_command(args, region):
     """`samtools view -F 2316 <bam> <region>` as the reference spawns it (CreateTensor.py:163-170), plus -@ N with --samtools_threads N
     (BGZF blocks inflated on N extra threads: the text that comes out is the same)."""
     threads = getattr(args, "samtools_threads", 0) or 0
-    return shlex.split("%s view %s-F %d %s %s" % (args.samtools, "-@ %d " % threads if threads > 0 else "", ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region))
+    extra = getattr(args, "samtools_view_args", None) or ""
+    return shlex.split("%s view %s%s-F %d %s %s" % (args.samtools, "-@ %d " % threads if threads > 0 else "", extra + " " if extra else "",
+                                                  ct.SAMTOOLS_VIEW_FILTER_FLAG, args.bam_fn, region))
 
 
 def candidate_positions(args, quiet=False):
@@ -776,6 +778,9 @@ def build_parser():
     add('--view_readers', type=int, default=1,
         help="with the front end on the device: read the alignments with this many `samtools view` processes at once, each over a consecutive piece "
              "of the region (same lines, same order as one)")
+    add('--samtools_view_args', type=str, default=None,
+        help="extra options for `samtools view`, e.g. \"--keep-tag NM\": nothing beyond SEQ is read from a line, and the tags of an ONT BAM (move "
+             "tables) can be several times the size of the rest")
     add('--samtools_threads', type=int, default=0,
         help="extra decompression threads for `samtools view` (its -@): with the front end on the device the BAM decoder is what the run waits for")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")

@@ -65,7 +65,7 @@ def commands(args):
         _flag("stop_consider_left_edge", args.stop_consider_left_edge), _flag("debug", args.debug),
         _flag("pysam_for_all_indel_bases", args.pysam_for_all_indel_bases), _flag("haploid_precision", args.haploid_precision),
         _flag("haploid_sensitive", args.haploid_sensitive), _flag("output_for_ensemble", args.output_for_ensemble),
-        _opt("front_end", args.front_end), _opt("batch_size", args.batch_size), _opt("samtools_threads", args.samtools_threads), _opt("view_readers", args.view_readers),
+        _opt("front_end", args.front_end), _opt("batch_size", args.batch_size), _opt("samtools_threads", args.samtools_threads), _opt("view_readers", args.view_readers), _opt("samtools_view_args", args.samtools_view_args),
     ] if x is not None)
     out, k = [], 0
     commands.chunks = []           # (device, output file) per command, for --run
@@ -216,6 +216,7 @@ def build_parser():
     add('--batch_size', type=int, default=None, help="passed on (callVarBam: candidates per forward pass)")
     add('--samtools_threads', type=int, default=None, help="passed on (callVarBam: -@ of `samtools view`)")
     add('--view_readers', type=int, default=None, help="passed on (callVarBam: `samtools view` processes per region)")
+    add('--samtools_view_args', type=str, default=None, help="passed on (callVarBam: extra options for `samtools view`)")
     return parser
 
 
