@@ -41,10 +41,10 @@ CXX = os.environ.get("CXX", "g++")
 
 def build_host(force=False):
     """Host-side helpers (include/clair_host.h): plain C++, no HIP."""
-    hdr = os.path.join(HERE, "..", "include", "clair_host.h")
-    hdr2 = os.path.join(HERE, "..", "include", "clair_reads.h")
+    # every header a host source includes: clair_call.h is the 32-byte record host_decode.cpp shares bit for bit with the device decode
+    hdrs = [os.path.join(HERE, "..", "include", h) for h in ("clair_host.h", "clair_reads.h", "clair_call.h", "clair_amd.h")]
     if (force or not os.path.isfile(HOST_OUT)
-            or max([os.path.getmtime(f) for f in HOST_SRCS] + [os.path.getmtime(hdr), os.path.getmtime(hdr2)]) > os.path.getmtime(HOST_OUT)):
+            or max([os.path.getmtime(f) for f in HOST_SRCS + hdrs]) > os.path.getmtime(HOST_OUT)):
         # -ffp-contract=off: the decode restates float32 product chains bit for bit (no fused multiply-add)
         subprocess.check_call([CXX, "-O3", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", "-Wall"] + HOST_SRCS + ["-o", HOST_OUT])
     return HOST_OUT

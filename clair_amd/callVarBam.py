@@ -209,7 +209,8 @@ TEXT_CHUNK = 64 << 20      # bytes of `samtools view` text handed to the device 
 TABLE_MARGIN = 64          # positions the device tables extend beyond the region (a window reaches 17 beyond its centre)
 FE_REASONS = ((1, "alignments not sorted by position"), (2, "a zero-length insertion/deletion"), (4, "an alignment spanning > 100 kb more than its bases"),
               (8, "a CIGAR longer than its SEQ"), (16, "a read base outside the IUPAC alphabet"), (32, "a reference base outside the IUPAC alphabet"),
-              (64, "a count beyond int16"), (128, "the reference's budget of 5 M outstanding tuples would run out"), (256, "candidate sites not strictly ascending"))
+              (64, "a count beyond int16"), (128, "the reference's budget of 5 M outstanding tuples would run out"), (256, "candidate sites not strictly ascending"),
+              (512, "an alignment that begins with an insertion/deletion after another one at the same start position"))
 
 
 class AlignmentStream(object):
@@ -780,7 +781,7 @@ def build_parser():
              "of the region (same lines, same order as one)")
     add('--samtools_view_args', type=str, default=None,
         help="extra options for `samtools view`, e.g. \"--keep-tag NM\": nothing beyond SEQ is read from a line, and the tags of an ONT BAM (move "
-             "tables) can be several times the size of the rest")
+             "tables) can be several times the size of the rest.  Write a value that is itself one option with `=`: --samtools_view_args=-x")
     add('--samtools_threads', type=int, default=0,
         help="extra decompression threads for `samtools view` (its -@): with the front end on the device the BAM decoder is what the run waits for")
     add('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")

@@ -65,7 +65,9 @@ def commands(args):
         _flag("stop_consider_left_edge", args.stop_consider_left_edge), _flag("debug", args.debug),
         _flag("pysam_for_all_indel_bases", args.pysam_for_all_indel_bases), _flag("haploid_precision", args.haploid_precision),
         _flag("haploid_sensitive", args.haploid_sensitive), _flag("output_for_ensemble", args.output_for_ensemble),
-        _opt("front_end", args.front_end), _opt("batch_size", args.batch_size), _opt("samtools_threads", args.samtools_threads), _opt("view_readers", args.view_readers), _opt("samtools_view_args", args.samtools_view_args),
+        _opt("front_end", args.front_end), _opt("batch_size", args.batch_size), _opt("samtools_threads", args.samtools_threads), _opt("view_readers", args.view_readers),
+        # as ONE token: a value that is a single option ("-x", "--no-PG") would otherwise be read as the next flag
+        None if args.samtools_view_args is None else '--samtools_view_args="%s"' % args.samtools_view_args,
     ] if x is not None)
     out, k = [], 0
     commands.chunks = []           # (device, output file) per command, for --run
@@ -135,20 +137,39 @@ def run_worker(command_lines, device, readers):
                 if buf is not None:
                     buffers.put(buf)
 
+        failed = []
         with ThreadPoolExecutor(max_workers=readers) as pool:
             ahead = [pool.submit(prepare, i, a) for i, a in enumerate(jobs)]
             try:
                 for args, fut in zip(jobs, ahead):
-                    callVarBam.call_region(args, m, prepared=fut.result())       # closes the front end
+                    # One chunk's failure is that chunk's: the printed commands run a process per chunk and the others would have finished
+                    # (clair/callVarBamParallel.py:90-119 under GNU parallel).  sys.exit(message) of a stage is such a failure too.
+                    fe = None
+                    try:
+                        fe = fut.result()
+                        callVarBam.call_region(args, m, prepared=fe)             # closes the front end
+                    except KeyboardInterrupt:
+                        raise
+                    except BaseException as err:
+                        if fe is not None:
+                            fe.close()                                           # (idempotent) its region leaves the GPU's memory now
+                        failed.append(args.call_fn)
+                        logging.error("[ERROR] %s: %s" % (args.call_fn, err if str(err) else repr(err)))
                     with turn:
                         state["called"] += 1
                         turn.notify_all()
             finally:
                 with turn:
-                    state["stop"] = True        # on an error: let the readers that wait for their turn run out
+                    state["stop"] = True        # interrupted: let the readers that wait for their turn run out
                     turn.notify_all()
+                for fut in ahead:               # ... and give back what those that had finished hold on the GPU
+                    if fut.done() and not fut.cancelled() and fut.exception() is None and fut.result() is not None:
+                        fut.result().close()
     finally:
         m.close()
+    if failed:
+        logging.error("[ERROR] %d of %d chunk(s) failed on device %d: %s" % (len(failed), len(jobs), device, " ".join(failed)))
+        return 1
     return 0
 
 

@@ -763,6 +763,11 @@ def call_variants(args, m, decoder, writer, batch_size=None, generator=None):
             retire()
     except BaseException:
         stop.set()
+        for slot, _ in inflight:                   # leave the engine usable for the caller's next region (callVarBamParallel --run goes on)
+            try:
+                m.wait(slot)
+            except Exception:
+                pass
         raise
     finally:
         if pool is not None:

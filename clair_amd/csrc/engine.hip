@@ -6,12 +6,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hip.h"
@@ -27,6 +33,7 @@ using namespace clair;
 namespace {
 
 thread_local std::string g_create_error;
+thread_local std::string *g_error_sink = nullptr;   // the staging worker: failures go to the slot they belong to, clair_wait reports them
 
 const int64_t TENSOR_COUNT[CLAIR_T_COUNT] = {
     160 * 512, 512, 160 * 512, 512, 384 * 512, 512, 384 * 512, 512, 256 * 33 * 30, 256 * 30,
@@ -37,19 +44,38 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
-struct Slot {
+// A LANE is what one forward pass in flight needs: a HIP stream for its kernels and the inter-kernel workspaces.  Three lanes fill the
+// chip (64 + 64 + 128 CUs: two recurrent kernels beside a projection GEMM); more only stretch every kernel (profiles/r02_stream_sweep.txt).
+struct Lane {
     hipStream_t stream = nullptr;
-    float *d_x = nullptr;     // [max_pad][1056]
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
     unsigned short *a1 = nullptr;   // [2][33][max_pad][256] fp16: LSTM1 output as its 2-way split
     float *a2 = nullptr;      // LSTM2 output, channel-group-major: [32 groups of 8 features][33][n_pad][8]
     float *l4part = nullptr;  // [32 groups][max_pad rounded to 64][192] split-K partials in the accumulator layout (dense.hip.h)
     unsigned *fuse_flags = nullptr;   // lstm2_fused.hip.h: [2][max_pad/32][33][8] ticket words, one error word, one claim word per workgroup
-    unsigned fuse_ticket = 0;         // ticket of the last fused forward pass on this slot
+    unsigned fuse_ticket = 0;         // ticket of the last fused forward pass on this lane
+    int last_n_pad = 0;
+    std::mutex order;         // one forward pass is enqueued at a time (the submitting thread and the staging worker both enqueue)
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> free_events;
+    // forward passes enqueued with the fused layer-2 launch since the lane's error word was last read: what recover_fused re-runs
+    struct FusedRun { const float *x; float *out; int n; int slot; };   // slot: the submit it belongs to, -1 for clair_run_resident
+    std::vector<FusedRun> fused_runs;
+};
+
+// A SLOT is one submit in flight at the host boundary: its input and output buffers on both sides of the link and a stream of its own for
+// the transfers, so that the copy engines move batch i+1 in and batch i-1 out while the lanes compute batch i.  Slot s computes on lane
+// s % lanes; the kernels of the slots that share a lane run back to back on the lane's stream (with as many slots as
+// lanes every lane idles while its only slot is on the link -- 3.9 M candidates/s of 7.5).
+struct Slot {
+    int lane = 0;
+    hipStream_t cin = nullptr, cout = nullptr;   // the streams the batch comes in on and the results go out on (copy_mode: whose they are)
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;   // input on the device / forward pass (and decode) finished / results on the host
+    float *d_x = nullptr;     // [max_pad][1056]
     float *d_out = nullptr;   // [max_pad][90]
-    float *h_out = nullptr;   // pinned [max_batch][90]
-    float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first clair_slot_input
-    short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first clair_submit_counts
+    float *h_out = nullptr;   // pinned [max_batch][90] (+ the fused launch's error word)
+    float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first use
+    short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first use
     char *d_records = nullptr;   // candidates copied with the caller's stride (binary tensor records as they lie), clair_submit_ex
     size_t d_records_bytes = 0;
     short *h_counts = nullptr;   // pinned [max_batch][1056]: staging of a caller's pageable count buffer (as h_x is for float input)
@@ -60,12 +86,10 @@ struct Slot {
     // pending host outputs of a submit
     float *o_gt21 = nullptr, *o_gt = nullptr, *o_l1 = nullptr, *o_l2 = nullptr;
     int pending_n = 0;
-    int last_n_pad = 0;
-    std::vector<TimedLaunch> timed;
-    std::vector<hipEvent_t> free_events;
-    // forward passes enqueued with the fused layer-2 launch since the slot's error word was last read: what recover_fused re-runs
-    struct FusedRun { const float *x; float *out; int n; };
-    std::vector<FusedRun> fused_runs;
+    bool refetch = false;     // a fused-launch recovery re-ran this slot's pass after its outputs had been fetched: fetch them again
+    // hand-over to the staging worker: 0 = nothing queued, 1 = queued, 2 = enqueued on the device, 3 = failed (message in worker_error)
+    int staged = 0;
+    std::string worker_error;
 };
 
 }  // namespace
@@ -78,7 +102,7 @@ struct clair_engine {
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
     int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
                                // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
-    int lstm2_fused = -1;      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one or
+    std::atomic<int> lstm2_fused{-1};      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one or
                                // two slots for 512 .. 2048 candidates (one slot: 104 us instead of 47 + 78 at batch 1024, +8 % per pass; two slots:
                                // 6.86 against 6.4 M/s; profiles/r02_lstm2_fused.txt); with three batches in flight the two launches pack
                                // better (7.5 against 7.4 M/s).  CLAIR_AMD_LSTM2_FUSED=0/1 forces
@@ -95,6 +119,23 @@ struct clair_engine {
     std::string error;
     std::vector<std::pair<char *, size_t>> pinned;   // page-locked host buffers handed to the caller (clair_pinned_alloc)
     std::vector<Slot> slots;
+    std::vector<std::unique_ptr<Lane>> lanes;
+    std::vector<hipStream_t> copy_streams;   // owned here; the slots point into it
+    int copy_mode = 3;                  // CLAIR_AMD_COPY_STREAMS=slot|two|lane|in (0, 1, 2, 3): see clair_engine_create
+    bool d2h_kernel = false;            // CLAIR_AMD_D2H=kernel: results written to page-locked host memory by a kernel instead of the copy engine
+    // the staging worker (clair_submit* on pageable memory): the copy of the caller's batch into page-locked memory and the enqueue of its
+    // transfers and kernels run on this thread, so that the submitting thread is free after a few microseconds, as the reference's
+    // predict thread leaves load and output to two others (clair/call_var.py:1331-1352)
+    struct Request {
+        const void *input; bool counts; int64_t stride; int n;
+        const uint8_t *centre; clair_call_t *calls; float *gt21, *gt, *l1, *l2;
+    };
+    bool async_staging = true;          // CLAIR_AMD_ASYNC_STAGING=0: everything on the submitting thread
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv, wdone;
+    std::deque<std::pair<int, Request>> wqueue;
+    bool wstop = false;
     std::vector<float> host_tensors[CLAIR_T_COUNT];
     // device weights
     float *bx1 = nullptr, *bx2 = nullptr;   // gate-scaled biases [2][512] of the two layers
@@ -114,7 +155,7 @@ int fail(clair_engine *e, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (e) e->error = buf; else g_create_error = buf;
+    if (g_error_sink) *g_error_sink = buf; else if (e) e->error = buf; else g_create_error = buf;
     return 1;
 }
 
@@ -196,12 +237,20 @@ int upload16(clair_engine *e, unsigned short **dst, const std::vector<unsigned s
     return 0;
 }
 
+void free_lane(Lane &l) {
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    for (auto &t : l.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto ev : l.free_events) (void)hipEventDestroy(ev);
+    (void)hipFree(l.zx); (void)hipFree(l.a1); (void)hipFree(l.a2); (void)hipFree(l.l4part); (void)hipFree(l.fuse_flags);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+}
+
 void free_slot(Slot &s) {
-    if (s.stream) (void)hipStreamSynchronize(s.stream);
-    for (auto &t : s.timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    for (auto ev : s.free_events) (void)hipEventDestroy(ev);
-    (void)hipFree(s.d_x); (void)hipFree(s.zx); (void)hipFree(s.a1); (void)hipFree(s.a2);
-    (void)hipFree(s.l4part); (void)hipFree(s.d_out); (void)hipFree(s.fuse_flags);
+    if (s.ev_out) (void)hipEventSynchronize(s.ev_out);
+    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    (void)hipFree(s.d_x); (void)hipFree(s.d_out);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_x) (void)hipHostFree(s.h_x);
     if (s.d_counts) (void)hipFree(s.d_counts);
@@ -211,10 +260,9 @@ void free_slot(Slot &s) {
     if (s.h_centre) (void)hipHostFree(s.h_centre);
     if (s.d_calls) (void)hipFree(s.d_calls);
     if (s.h_calls) (void)hipHostFree(s.h_calls);
-    if (s.stream) (void)hipStreamDestroy(s.stream);
 }
 
-hipEvent_t get_event(Slot &s) {
+hipEvent_t get_event(Lane &s) {
     if (!s.free_events.empty()) {
         hipEvent_t ev = s.free_events.back();
         s.free_events.pop_back();
@@ -226,8 +274,8 @@ hipEvent_t get_event(Slot &s) {
 }
 
 struct KernelTimer {
-    clair_engine *e; Slot &s; int id; hipEvent_t start = nullptr, stop = nullptr;
-    KernelTimer(clair_engine *e_, Slot &s_, int id_) : e(e_), s(s_), id(id_) {
+    clair_engine *e; Lane &s; int id; hipEvent_t start = nullptr, stop = nullptr;
+    KernelTimer(clair_engine *e_, Lane &s_, int id_) : e(e_), s(s_), id(id_) {
         if ((e->timing_mask >> id) & 1u) { start = get_event(s); stop = get_event(s); (void)hipEventRecord(start, s.stream); }
     }
     ~KernelTimer() {
@@ -235,8 +283,12 @@ struct KernelTimer {
     }
 };
 
+int quiesce(clair_engine *e);
+
 int drain_timers(clair_engine *e) {
-    for (auto &s : e->slots) {
+    if (quiesce(e)) return 1;           // nothing is being enqueued (and timed) while the lists are read
+    for (auto &lp : e->lanes) {
+        Lane &s = *lp;
         HIP_TRY(e, hipStreamSynchronize(s.stream));
         for (auto &t : s.timed) {
             float ms = 0.f;
@@ -251,7 +303,7 @@ int drain_timers(clair_engine *e) {
     return 0;
 }
 
-bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->slots.size() <= 2); }
+bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->lanes.size() <= 2); }
 bool use_lstm2_fused(const clair_engine *e, int ntiles) {   // pairs of tiles share a 64-row activation tile: even tile counts only
     if ((ntiles & 1) || !fused_possible(e)) return false;
     return e->lstm2_fused == 1 || (ntiles >= 16 && ntiles <= 64);   // 512 .. 2048 candidates: beyond, every kernel fills the chip by itself and
@@ -263,7 +315,7 @@ bool use_lstm2_pair(const clair_engine *e, int ntiles) { return e->lstm2_pair < 
 
 // Enqueue the forward pass for n candidates whose input is at x_dev ([n_pad][1056], rows >= n
 // zero or any finite value) writing packed outputs to out_dev ([n][90]).
-int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev, int n) {
+int enqueue_forward(clair_engine *e, Lane &s, const float *x_dev, float *out_dev, int n, int slot_index) {
     const int n_pad = (n + 31) & ~31;
     const int ntiles = n_pad / L32_TILE;
     const int m_rows = T_POS * n_pad;
@@ -285,7 +337,7 @@ int enqueue_forward(clair_engine *e, Slot &s, const float *x_dev, float *out_dev
         if (fault) HIP_TRY(e, hipMemsetD32Async((hipDeviceptr_t)a.f.claims, (int)s.fuse_ticket, 1, s.stream));
         hipLaunchKernelGGL(lstm2_fused_kernel, dim3(32 * groups + consumers), dim3(256), 0, s.stream, a);
         if (fault) HIP_TRY(e, hipMemsetAsync(s.a2, 0x7f, (size_t)T_POS * n_pad * 256 * sizeof(float), s.stream));
-        s.fused_runs.push_back({x_dev, out_dev, n});
+        s.fused_runs.push_back({x_dev, out_dev, n, slot_index});
     } else {
         {   // LSTM2 input projection on the fp16 matrix cores, fp32-grade via the 2-way split; weight-stationary persistent workgroups
             KernelTimer kt(e, s, CLAIR_K_PROJ2);
@@ -341,10 +393,10 @@ void gather_rows(void *dst, const void *src, int n, size_t row, int64_t stride) 
 }
 
 // The decode of the slot's batch on the device (decode.hip.h): probabilities in d_out + window in d_x + centre bytes -> call records.
-int enqueue_decode(clair_engine *e, Slot &s, int n) {
-    KernelTimer kt(e, s, CLAIR_K_DECODE);
+int enqueue_decode(clair_engine *e, Lane &l, Slot &s, int n) {
+    KernelTimer kt(e, l, CLAIR_K_DECODE);
     DecodeArgs a{s.d_x, s.d_out, s.d_centre, s.d_calls, n};
-    hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(256), 0, s.stream, a);
+    hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(256), 0, l.stream, a);
     HIP_TRY(e, hipGetLastError());
     return 0;
 }
@@ -354,33 +406,228 @@ int enqueue_decode(clair_engine *e, Slot &s, int n) {
 // results of the slot's fused passes cannot be trusted.  The reference never drops a batch (clair/call_var.py:1331-1352), so
 // neither does this: the fused launch is switched off for the rest of the handle's life, the affected passes are enqueued again
 // on the two-launch path (same arithmetic, bit-identical outputs) and the caller sees success; stderr gets one line.
-// Called with the slot's stream idle.
-int recover_fused(clair_engine *e, Slot &s) {
-    HIP_TRY(e, hipMemsetAsync(s.fuse_flags + fuse_words(e->max_pad), 0, sizeof(unsigned), s.stream));
+// Called with the lane's order lock held; waits for the lane first.  Slots other than `current` whose pass was re-run fetch their
+// outputs again when they are waited for (Slot::refetch).
+int recover_fused(clair_engine *e, Lane &l, int current) {
+    HIP_TRY(e, hipStreamSynchronize(l.stream));
+    HIP_TRY(e, hipMemsetAsync(l.fuse_flags + fuse_words(e->max_pad), 0, sizeof(unsigned), l.stream));
     if (e->lstm2_fused != 0)
         fprintf(stderr, "clair_amd: the fused layer-2 launch found its blocks placed differently from what it assumes (a logical id claimed twice, or "
-                        "a bounded wait that ran out); re-running %d pass(es) on the two-launch path and keeping it for this handle\n", (int)s.fused_runs.size());
+                        "a bounded wait that ran out); re-running %d pass(es) on the two-launch path and keeping it for this handle\n", (int)l.fused_runs.size());
     e->lstm2_fused = 0;
-    std::vector<Slot::FusedRun> runs;
-    runs.swap(s.fused_runs);
+    std::vector<Lane::FusedRun> runs;
+    runs.swap(l.fused_runs);
     for (const auto &r : runs) {
-        if (enqueue_forward(e, s, r.x, r.out, r.n)) return 1;
+        if (enqueue_forward(e, l, r.x, r.out, r.n, r.slot)) return 1;
+        if (r.slot >= 0 && r.slot != current) e->slots[r.slot].refetch = true;
         ++e->fused_recoveries;
     }
-    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    HIP_TRY(e, hipStreamSynchronize(l.stream));
     return 0;
 }
 
 int check_fused_placement(clair_engine *e) {
-    for (auto &s : e->slots) {
-        if (!s.fuse_flags) continue;
-        if (!s.fused_runs.empty()) {
+    for (auto &lp : e->lanes) {
+        Lane &l = *lp;
+        if (!l.fuse_flags) continue;
+        std::lock_guard<std::mutex> g(l.order);
+        if (!l.fused_runs.empty()) {
             unsigned bad = 0;
-            HIP_TRY(e, hipMemcpy(&bad, s.fuse_flags + fuse_words(e->max_pad), sizeof bad, hipMemcpyDeviceToHost));
-            if (bad && recover_fused(e, s)) return 1;
+            HIP_TRY(e, hipMemcpy(&bad, l.fuse_flags + fuse_words(e->max_pad), sizeof bad, hipMemcpyDeviceToHost));
+            if (bad && recover_fused(e, l, -1)) return 1;
         }
-        s.fused_runs.clear();
+        l.fused_runs.clear();
     }
+    return 0;
+}
+
+// raw counts -> network input (clair/utils.py:96-98): one (position, row) quad of four channels per thread
+__global__ __launch_bounds__(256) void counts_to_input_kernel(const short4 *counts, f32x4 *x, int n_quads) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_quads) return;
+    const short4 c = counts[i];
+    const float c0 = (float)c.x;
+    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
+}
+
+// the same for candidates `stride` bytes apart (binary tensor records copied as they lie): quad i = candidate i / 264, quad i % 264 of it
+__global__ __launch_bounds__(256) void counts_to_input_strided_kernel(const char *base, size_t stride, f32x4 *x, int n_quads) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_quads) return;
+    const int cand = i / (CLAIR_INPUT_FLOATS / 4), q = i - cand * (CLAIR_INPUT_FLOATS / 4);
+    const short4 c = *(const short4 *)(base + (size_t)cand * stride + (size_t)q * 8);
+    const float c0 = (float)c.x;
+    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
+}
+
+
+// results of a forward pass (and decode) to the slot's page-locked buffers, written by the GPU itself: no copy engine, no queue switch
+__global__ __launch_bounds__(256) void results_to_host_kernel(const uint4 *out, uint4 *h_out, int out_vec, const uint4 *calls, uint4 *h_calls, int call_vec,
+                                                             const unsigned *word, unsigned *h_word) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < out_vec) h_out[i] = out[i];
+    else if (i - out_vec < call_vec) h_calls[i - out_vec] = calls[i - out_vec];
+    if (i == 0 && word) *h_word = *word;
+}
+
+// The way back: call records, probabilities and the fused launch's error word into the slot's page-locked buffers, on the slot's
+// outgoing stream (which may be the lane's own), then the event clair_wait sleeps on.
+int enqueue_results(clair_engine *e, Lane &l, Slot &s, int n, bool calls, bool probs) {
+    unsigned *word = l.fuse_flags ? l.fuse_flags + fuse_words(e->max_pad) : nullptr;
+    unsigned *h_word = (unsigned *)(s.h_out + (size_t)e->max_batch * OUT_FLOATS);
+    if (e->d2h_kernel) {
+        const int out_vec = probs ? (n * OUT_FLOATS * (int)sizeof(float) + 15) / 16 : 0, call_vec = calls ? n * (int)sizeof(clair_call_t) / 16 : 0;
+        hipLaunchKernelGGL(results_to_host_kernel, dim3((std::max(out_vec + call_vec, 1) + 255) / 256), dim3(256), 0, s.cout, (const uint4 *)s.d_out, (uint4 *)s.h_out, out_vec,
+                           (const uint4 *)s.d_calls, (uint4 *)s.h_calls, call_vec, word, h_word);
+    } else {
+        if (calls) HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.cout));
+        if (probs) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.cout));
+        if (word) HIP_TRY(e, hipMemcpyAsync(h_word, word, sizeof(unsigned), hipMemcpyDeviceToHost, s.cout));
+    }
+    HIP_TRY(e, hipEventRecord(s.ev_out, s.cout));
+    return 0;
+}
+
+// Everything one submit puts on the device, in order: the batch over the link on the slot's copy stream (through page-locked staging
+// when the caller's memory is pageable), the forward pass (and the decode) on the slot's lane once the batch has arrived, the results
+// back over the link once the lane is done.  Runs on the submitting thread or on the staging worker.
+int enqueue_request(clair_engine *e, int slot_index, const clair_engine::Request &q) {
+    Slot &s = e->slots[slot_index];
+    Lane &l = *e->lanes[s.lane];
+    const int n = q.n, n_pad = (n + 31) & ~31;
+    const bool want_probs = q.gt21 != nullptr;
+    const bool same_in = s.cin == l.stream, same_out = s.cout == l.stream;     // copy_mode "lane": copies in line with the kernels, no events
+    std::unique_lock<std::mutex> whole(l.order, std::defer_lock);
+    if (same_in) whole.lock();
+    // A caller's buffer from clair_pinned_alloc (or the slot's own input buffer) is read by the DMA engine where it lies: no pass over
+    // the batch on any host thread.  Anything else goes through the slot's page-locked staging buffer.
+    const size_t row_bytes = CLAIR_INPUT_FLOATS * (q.counts ? sizeof(short) : sizeof(float));
+    const size_t stride = q.stride ? (size_t)q.stride : row_bytes;
+    const size_t span = (size_t)(n - 1) * stride + row_bytes;
+    const bool direct = (q.input == (const void *)s.h_x && stride == row_bytes && !q.counts) || in_pinned(e, q.input, span);
+    const bool on_device = !direct && is_device_pointer(q.input);   // e.g. the windows of clair_frontend_build_windows: no copy at all
+    if (on_device && !q.counts) return fail(e, "a device pointer is taken for int16 counts only");
+    enum { NONE, DENSE, STRIDED } convert = NONE;                    // the int16 -> float32 kernel the lane runs first
+    const char *convert_from = nullptr;
+    if (q.counts) {
+        if (!s.d_counts && !on_device) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
+        if (on_device) {
+            convert = STRIDED; convert_from = (const char *)q.input;
+        } else if (direct && stride != row_bytes) {   // records as they lie: ONE contiguous copy of the span, the conversion kernel skips what lies between the counts
+            if (s.d_records_bytes < span) {
+                (void)hipFree(s.d_records); s.d_records = nullptr; s.d_records_bytes = 0;
+                const size_t want = std::max(span, (size_t)e->max_batch * stride);
+                HIP_TRY(e, hipMalloc((void **)&s.d_records, want));
+                s.d_records_bytes = want;
+            }
+            HIP_TRY(e, hipMemcpyAsync(s.d_records, q.input, span, hipMemcpyHostToDevice, s.cin));
+            convert = STRIDED; convert_from = s.d_records;
+        } else {
+            const void *src = q.input;
+            if (!direct) {
+                if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
+                gather_rows(s.h_counts, q.input, n, row_bytes, q.stride);
+                src = s.h_counts;
+            }
+            HIP_TRY(e, hipMemcpyAsync(s.d_counts, src, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.cin));
+            convert = DENSE; convert_from = (const char *)s.d_counts;
+        }
+    } else if (direct && stride != row_bytes) {
+        HIP_TRY(e, hipMemcpy2DAsync(s.d_x, row_bytes, q.input, stride, row_bytes, (size_t)n, hipMemcpyHostToDevice, s.cin));
+    } else {
+        const void *src = q.input;
+        if (!direct) {
+            if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+            gather_rows(s.h_x, q.input, n, row_bytes, q.stride);
+            src = s.h_x;
+        }
+        HIP_TRY(e, hipMemcpyAsync(s.d_x, src, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.cin));
+    }
+    if (n_pad > n)
+        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.cin));
+    if (q.calls) {
+        if (!s.d_centre) {
+            HIP_TRY(e, hipMalloc((void **)&s.d_centre, (size_t)e->max_pad * 2));
+            HIP_TRY(e, hipHostMalloc((void **)&s.h_centre, (size_t)e->max_batch * 2, hipHostMallocDefault));
+            HIP_TRY(e, hipMalloc((void **)&s.d_calls, (size_t)e->max_pad * sizeof(clair_call_t)));
+            HIP_TRY(e, hipHostMalloc((void **)&s.h_calls, (size_t)e->max_batch * sizeof(clair_call_t), hipHostMallocDefault));
+        }
+        memcpy(s.h_centre, q.centre, (size_t)n * 2);
+        HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.cin));
+    }
+    if (!same_in) HIP_TRY(e, hipEventRecord(s.ev_in, s.cin));
+    {
+        std::unique_lock<std::mutex> g(l.order, std::defer_lock);
+        if (!same_in) g.lock();
+        if (!same_in) HIP_TRY(e, hipStreamWaitEvent(l.stream, s.ev_in, 0));
+        const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
+        if (convert == DENSE)
+            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, l.stream, (const short4 *)convert_from, (f32x4 *)s.d_x, n_quads);
+        else if (convert == STRIDED)
+            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, l.stream, convert_from, stride, (f32x4 *)s.d_x, n_quads);
+        if (enqueue_forward(e, l, s.d_x, s.d_out, n, slot_index)) return 1;
+        if (q.calls && enqueue_decode(e, l, s, n)) return 1;
+        if (same_out) return enqueue_results(e, l, s, n, q.calls != nullptr, want_probs);      // in line with the kernels, under the lane's lock
+        HIP_TRY(e, hipEventRecord(s.ev_done, l.stream));
+    }
+    HIP_TRY(e, hipStreamWaitEvent(s.cout, s.ev_done, 0));
+    return enqueue_results(e, l, s, n, q.calls != nullptr, want_probs);
+}
+
+void staging_worker(clair_engine *e) {
+    (void)hipSetDevice(e->device);
+    for (;;) {
+        std::pair<int, clair_engine::Request> job;
+        {
+            std::unique_lock<std::mutex> g(e->wmu);
+            e->wcv.wait(g, [&] { return e->wstop || !e->wqueue.empty(); });
+            if (e->wqueue.empty()) return;            // stop asked for and nothing left to do
+            job = e->wqueue.front();
+            e->wqueue.pop_front();
+        }
+        g_error_sink = &e->slots[job.first].worker_error;   // `error` belongs to the caller's threads
+        const int rc = enqueue_request(e, job.first, job.second);
+        g_error_sink = nullptr;
+        {
+            std::lock_guard<std::mutex> g(e->wmu);
+            e->slots[job.first].staged = rc ? 3 : 2;
+        }
+        e->wdone.notify_all();
+    }
+}
+
+// Validates a request on the caller's thread, then hands it to the staging worker when the caller's memory has to be copied first
+// (the worker does the copy AND the enqueue) or enqueues it right here.
+int submit_request(clair_engine *e, int slot, const clair_engine::Request &q) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    Slot &s = e->slots[slot];
+    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
+    s.o_gt21 = q.gt21; s.o_gt = q.gt; s.o_l1 = q.l1; s.o_l2 = q.l2;
+    s.o_calls = q.calls;
+    s.refetch = false;
+    if (e->async_staging) {
+        {
+            std::lock_guard<std::mutex> g(e->wmu);
+            s.staged = 1;
+            e->wqueue.emplace_back(slot, q);
+        }
+        e->wcv.notify_one();
+    } else {
+        s.staged = 0;
+        if (enqueue_request(e, slot, q)) return 1;
+    }
+    s.pending_n = q.n;
+    return 0;
+}
+
+// the staging worker has nothing queued and every stream of the handle is idle
+int quiesce(clair_engine *e) {
+    {
+        std::unique_lock<std::mutex> g(e->wmu);
+        e->wdone.wait(g, [&] { for (auto &s : e->slots) if (s.staged == 1) return false; return true; });
+    }
+    for (auto st : e->copy_streams) HIP_TRY(e, hipStreamSynchronize(st));
+    for (auto &lp : e->lanes) HIP_TRY(e, hipStreamSynchronize(lp->stream));
     return 0;
 }
 
@@ -427,43 +674,90 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     // batches in flight on several slots the 64-workgroup recurrent kernels of the other slots hold whole CUs for ~80 us; a
     // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Four groups (128
     // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
-    e->proj2_groups = n_slots > 1 ? 4 : 8;
+    int n_lanes = std::min(n_slots, 3);
+    { const char *t = getenv("CLAIR_AMD_LANES"); if (t && atoi(t) > 0) n_lanes = std::min(atoi(t), n_slots); }
+    e->proj2_groups = n_lanes > 1 ? 4 : 8;
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
     { const char *t = getenv("CLAIR_AMD_LSTM2_FUSED"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_fused = t[0] - '0'; }
     { const char *t = getenv("CLAIR_AMD_FUSED_GROUPS"); if (t && atoi(t) > 0 && atoi(t) <= 8) e->fused_groups = atoi(t); }
     { const char *t = getenv("CLAIR_AMD_LSTM2_PAIR"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_pair = t[0] - '0'; }
     { const char *t = getenv("CLAIR_AMD_FUSED_FAULT"); if (t && atoll(t) > 0) e->fused_fault_at = atoll(t); }
+    { const char *t = getenv("CLAIR_AMD_ASYNC_STAGING"); if (t && t[0] == '0') e->async_staging = false; }
+    { const char *t = getenv("CLAIR_AMD_COPY_STREAMS"); if (t) e->copy_mode = !strcmp(t, "slot") ? 0 : !strcmp(t, "two") ? 1 : !strcmp(t, "lane") ? 2 : 3; }
+    { const char *t = getenv("CLAIR_AMD_D2H"); if (t) e->d2h_kernel = !strcmp(t, "kernel"); }
+    for (int i = 0; i < n_lanes; ++i) e->lanes.emplace_back(new Lane());
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
-    for (auto &s : e->slots) {
-        hipError_t r = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
-        if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.a1, ((size_t)2 * T_POS * mp * 256 + 128 * 256) * sizeof(unsigned short));   // + slack rows read (never used) by gemm_split's ragged last tile
-        if (r == hipSuccess) r = hipMalloc((void **)&s.a2, (size_t)T_POS * mp * 256 * sizeof(float));
-        if (r == hipSuccess) r = hipMalloc((void **)&s.l4part, (size_t)L4_SPLITS * ((mp + L34_CAND - 1) / L34_CAND * L34_CAND) * L4_UNITS * sizeof(float));
+    hipError_t r = hipSuccess;
+    for (auto &lp : e->lanes) {
+        Lane &l = *lp;
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipMalloc((void **)&l.zx, (size_t)T_POS * mp * 1024 * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&l.a1, ((size_t)2 * T_POS * mp * 256 + 128 * 256) * sizeof(unsigned short));   // + slack rows read (never used) by gemm_split's ragged last tile
+        if (r == hipSuccess) r = hipMalloc((void **)&l.a2, (size_t)T_POS * mp * 256 * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&l.l4part, (size_t)L4_SPLITS * ((mp + L34_CAND - 1) / L34_CAND * L34_CAND) * L4_UNITS * sizeof(float));
         if (r == hipSuccess && fused_possible(e)) {
             const size_t words = fuse_words(e->max_pad) + 1 + fuse_claims(e);   // tickets | error word | claims
-            r = hipMalloc((void **)&s.fuse_flags, words * sizeof(unsigned));
-            if (r == hipSuccess) r = hipMemset(s.fuse_flags, 0, words * sizeof(unsigned));
-        }
-        if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
-        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, ((size_t)max_batch * OUT_FLOATS + 1) * sizeof(float), hipHostMallocDefault);   // + the fused launch's error word
-        if (r != hipSuccess) {
-            fail(nullptr, "allocating slot workspaces for max_batch=%d failed: %s", max_batch, hipGetErrorString(r));
-            clair_engine_destroy(e);
-            return 1;
+            r = hipMalloc((void **)&l.fuse_flags, words * sizeof(unsigned));
+            if (r == hipSuccess) r = hipMemset(l.fuse_flags, 0, words * sizeof(unsigned));
         }
     }
+    for (size_t i = 0; i < e->slots.size(); ++i) {
+        Slot &s = e->slots[i];
+        s.lane = (int)(i % e->lanes.size());
+        if (e->copy_mode == 0) {            // a stream per slot for both directions
+            hipStream_t st = nullptr;
+            if (r == hipSuccess) r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (r == hipSuccess) e->copy_streams.push_back(st);
+            s.cin = s.cout = st;
+        } else if (e->copy_mode == 1) {     // one stream for everything that comes in, one for everything that goes out
+            while (r == hipSuccess && e->copy_streams.size() < 2) {
+                hipStream_t st = nullptr;
+                r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                if (r == hipSuccess) e->copy_streams.push_back(st);
+            }
+            if (r == hipSuccess) { s.cin = e->copy_streams[0]; s.cout = e->copy_streams[1]; }
+        } else if (e->copy_mode == 2) {     // on the lane's own stream, in line with its kernels
+            s.cin = s.cout = e->lanes[s.lane]->stream;
+        } else {                            // ONE stream for everything that comes in; the results leave on the lane's own stream
+            if (r == hipSuccess && e->copy_streams.empty()) {
+                hipStream_t st = nullptr;
+                r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                if (r == hipSuccess) e->copy_streams.push_back(st);
+            }
+            if (r == hipSuccess) { s.cin = e->copy_streams[0]; s.cout = e->lanes[s.lane]->stream; }
+        }
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming);
+        if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
+        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, ((size_t)max_batch * OUT_FLOATS + 1) * sizeof(float), hipHostMallocDefault);   // + the fused launch's error word
+    }
+    if (r != hipSuccess) {
+        fail(nullptr, "allocating workspaces for max_batch=%d, %d slot(s) failed: %s", max_batch, n_slots, hipGetErrorString(r));
+        clair_engine_destroy(e);
+        return 1;
+    }
+    if (e->async_staging) e->worker = std::thread(staging_worker, e);
     *out = e;
     return 0;
 }
 
 void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
+    if (e->worker.joinable()) {
+        { std::lock_guard<std::mutex> g(e->wmu); e->wstop = true; }
+        e->wcv.notify_all();
+        e->worker.join();
+    }
     (void)hipSetDevice(e->device);
+    for (auto &lp : e->lanes) if (lp->stream) (void)hipStreamSynchronize(lp->stream);
+    for (auto st : e->copy_streams) (void)hipStreamSynchronize(st);
     for (auto &s : e->slots) free_slot(s);
+    for (auto st : e->copy_streams) (void)hipStreamDestroy(st);
+    for (auto &lp : e->lanes) free_lane(*lp);
     for (auto &b : e->pinned) (void)hipHostFree(b.first);
     float *w[] = {e->bx1, e->bx2, e->b4, e->w5f, e->b5, e->whf, e->bhf};
     for (float *p : w) (void)hipFree(p);
@@ -486,7 +780,7 @@ int clair_finalize_weights(clair_engine_t *e) {
     for (int i = 0; i < CLAIR_T_COUNT; ++i)
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
-    for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
+    if (quiesce(e)) return 1;
     float **dev[] = {&e->bx1, &e->bx2, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
@@ -597,72 +891,14 @@ int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21
     if (check_slot(e, slot)) return 1;
     if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
     if (!x || !gt21 || !genotype || !l1 || !l2) return fail(e, "NULL input/output pointer");
-    HIP_TRY(e, hipSetDevice(e->device));
-    Slot &s = e->slots[slot];
-    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
-    const int n_pad = (n + 31) & ~31;
-    // A caller's pageable buffer goes through the slot's page-locked one: hipMemcpyAsync straight from pageable memory stages the
-    // copy itself and blocks the caller for milliseconds at these sizes (4.5 ms per 2 MB batch measured; tools/gpu/e2e_profile.sh)
-    if (x != s.h_x) {
-        if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
-        memcpy(s.h_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float));
-    }
-    HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
-    if (n_pad > n)
-        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
-    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
-    HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    if (s.fuse_flags)
-        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
-    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
-    s.o_calls = nullptr;
-    s.pending_n = n;
-    return 0;
-}
-
-// raw counts -> network input (clair/utils.py:96-98): one (position, row) quad of four channels per thread
-__global__ __launch_bounds__(256) void counts_to_input_kernel(const short4 *counts, f32x4 *x, int n_quads) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_quads) return;
-    const short4 c = counts[i];
-    const float c0 = (float)c.x;
-    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
-}
-
-// the same for candidates `stride` bytes apart (binary tensor records copied as they lie): quad i = candidate i / 264, quad i % 264 of it
-__global__ __launch_bounds__(256) void counts_to_input_strided_kernel(const char *base, size_t stride, f32x4 *x, int n_quads) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_quads) return;
-    const int cand = i / (CLAIR_INPUT_FLOATS / 4), q = i - cand * (CLAIR_INPUT_FLOATS / 4);
-    const short4 c = *(const short4 *)(base + (size_t)cand * stride + (size_t)q * 8);
-    const float c0 = (float)c.x;
-    x[i] = (f32x4){c0, (float)c.y - c0, (float)c.z - c0, (float)c.w - c0};
+    return submit_request(e, slot, clair_engine::Request{x, false, 0, n, nullptr, nullptr, gt21, genotype, l1, l2});
 }
 
 int clair_submit_counts(clair_engine_t *e, int slot, const int16_t *counts, int n, float *gt21, float *genotype, float *l1, float *l2) {
     if (check_slot(e, slot)) return 1;
     if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
     if (!counts || !gt21 || !genotype || !l1 || !l2) return fail(e, "NULL input/output pointer");
-    HIP_TRY(e, hipSetDevice(e->device));
-    Slot &s = e->slots[slot];
-    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
-    if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
-    const int n_pad = (n + 31) & ~31;
-    if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
-    memcpy(s.h_counts, counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short));   // page-locked staging, as in clair_submit
-    HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(short), hipMemcpyHostToDevice, s.stream));
-    const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
-    hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
-    if (n_pad > n)
-        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
-    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
-    HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    if (s.fuse_flags)
-        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
-    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
-    s.o_calls = nullptr;
-    s.pending_n = n;
-    return 0;
+    return submit_request(e, slot, clair_engine::Request{counts, true, 0, n, nullptr, nullptr, gt21, genotype, l1, l2});
 }
 
 int clair_slot_input(clair_engine_t *e, int slot, float **x_pinned) {
@@ -679,21 +915,44 @@ int clair_wait(clair_engine_t *e, int slot) {
     if (check_slot(e, slot)) return 1;
     HIP_TRY(e, hipSetDevice(e->device));
     Slot &s = e->slots[slot];
-    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    Lane &l = *e->lanes[s.lane];
     const int n = s.pending_n;
-    if (s.fuse_flags) {
+    if (s.staged) {     // handed to the staging worker: it has enqueued the batch by the time this returns
+        std::unique_lock<std::mutex> g(e->wmu);
+        e->wdone.wait(g, [&] { return s.staged != 1; });
+        const bool failed = s.staged == 3;
+        s.staged = 0;
+        if (failed) {
+            g.unlock();
+            (void)hipStreamSynchronize(s.cout);
+            s.pending_n = 0; s.o_calls = nullptr;
+            e->error = s.worker_error;
+            return 1;
+        }
+    }
+    if (n) HIP_TRY(e, hipEventSynchronize(s.ev_out));
+    bool again = s.refetch;
+    s.refetch = false;
+    if (l.fuse_flags) {
+        std::lock_guard<std::mutex> g(l.order);
         unsigned bad;
         memcpy(&bad, s.h_out + (size_t)e->max_batch * OUT_FLOATS, sizeof bad);
-        if (bad && !s.fused_runs.empty()) {   // re-run on the two-launch path (d_x still holds the input), fetch the outputs again
-            if (recover_fused(e, s)) { s.pending_n = 0; return 1; }
-            if (s.o_calls) {
-                if (enqueue_decode(e, s, n)) { s.pending_n = 0; return 1; }
-                HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
-            }
-            if (s.o_gt21) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-            HIP_TRY(e, hipStreamSynchronize(s.stream));
+        bool mine = false;
+        for (const auto &r : l.fused_runs) mine = mine || r.slot == slot;
+        if (n && bad && mine) {   // re-run on the two-launch path (d_x still holds the input), fetch the outputs again
+            if (recover_fused(e, l, slot)) { s.pending_n = 0; return 1; }
+            again = true;
         }
-        s.fused_runs.clear();
+        l.fused_runs.erase(std::remove_if(l.fused_runs.begin(), l.fused_runs.end(), [slot](const Lane::FusedRun &r) { return r.slot == slot; }), l.fused_runs.end());
+    }
+    if (n && again) {
+        std::lock_guard<std::mutex> g(l.order);
+        if (s.o_calls) {
+            if (enqueue_decode(e, l, s, n)) { s.pending_n = 0; return 1; }
+            HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, l.stream));
+        }
+        if (s.o_gt21) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, l.stream));
+        HIP_TRY(e, hipStreamSynchronize(l.stream));
     }
     if (s.o_gt21)
         for (int i = 0; i < n; ++i) {
@@ -722,75 +981,7 @@ int clair_submit_ex(clair_engine_t *e, int slot, const void *input, int input_is
     if (calls && !centre) return fail(e, "call records need the candidates' centre bytes");
     if (input_stride_bytes != 0 && input_stride_bytes < (int64_t)(CLAIR_INPUT_FLOATS * (input_is_counts ? sizeof(short) : sizeof(float))))
         return fail(e, "input stride of %lld bytes is shorter than one candidate", (long long)input_stride_bytes);
-    HIP_TRY(e, hipSetDevice(e->device));
-    Slot &s = e->slots[slot];
-    if (s.pending_n) return fail(e, "slot %d still has a pending submit; call clair_wait first", slot);
-    const int n_pad = (n + 31) & ~31;
-    // A caller's buffer from clair_pinned_alloc is read by the DMA engine where it lies: no pass over the batch on this thread at all.
-    // Anything else goes through the slot's page-locked staging buffer.
-    const size_t row_bytes = CLAIR_INPUT_FLOATS * (input_is_counts ? sizeof(short) : sizeof(float));
-    const size_t stride = input_stride_bytes ? (size_t)input_stride_bytes : row_bytes;
-    const bool direct = in_pinned(e, input, (size_t)(n - 1) * stride + row_bytes);
-    const bool on_device = !direct && is_device_pointer(input);   // e.g. the windows of clair_frontend_build_windows: no copy at all
-    if (on_device && !input_is_counts) return fail(e, "a device pointer is taken for int16 counts only");
-    if (input_is_counts) {
-        if (!s.d_counts) HIP_TRY(e, hipMalloc((void **)&s.d_counts, (size_t)e->max_pad * CLAIR_INPUT_FLOATS * sizeof(short)));
-        const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
-        if (on_device) {
-            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const char *)input, stride, (f32x4 *)s.d_x, n_quads);
-        } else if (direct && stride != row_bytes) {   // records as they lie: ONE contiguous copy of the span, the conversion kernel skips what lies between the counts
-            const size_t span = (size_t)(n - 1) * stride + row_bytes;
-            if (s.d_records_bytes < span) {
-                (void)hipFree(s.d_records); s.d_records = nullptr; s.d_records_bytes = 0;
-                const size_t want = std::max(span, (size_t)e->max_batch * stride);
-                HIP_TRY(e, hipMalloc((void **)&s.d_records, want));
-                s.d_records_bytes = want;
-            }
-            HIP_TRY(e, hipMemcpyAsync(s.d_records, input, span, hipMemcpyHostToDevice, s.stream));
-            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const char *)s.d_records, stride, (f32x4 *)s.d_x, n_quads);
-        } else {
-            if (direct) {
-                HIP_TRY(e, hipMemcpyAsync(s.d_counts, input, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
-            } else {
-                if (!s.h_counts) HIP_TRY(e, hipHostMalloc((void **)&s.h_counts, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(short), hipHostMallocDefault));
-                gather_rows(s.h_counts, input, n, row_bytes, input_stride_bytes);   // page-locked staging, as in clair_submit
-                HIP_TRY(e, hipMemcpyAsync(s.d_counts, s.h_counts, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
-            }
-            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.stream, (const short4 *)s.d_counts, (f32x4 *)s.d_x, n_quads);
-        }
-    } else if (direct) {
-        HIP_TRY(e, hipMemcpy2DAsync(s.d_x, row_bytes, input, stride, row_bytes, (size_t)n, hipMemcpyHostToDevice, s.stream));
-    } else {
-        if (input != s.h_x) {
-            if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
-            gather_rows(s.h_x, input, n, row_bytes, input_stride_bytes);
-        }
-        HIP_TRY(e, hipMemcpyAsync(s.d_x, s.h_x, (size_t)n * row_bytes, hipMemcpyHostToDevice, s.stream));
-    }
-    if (n_pad > n)
-        HIP_TRY(e, hipMemsetAsync(s.d_x + (size_t)n * CLAIR_INPUT_FLOATS, 0, (size_t)(n_pad - n) * CLAIR_INPUT_FLOATS * sizeof(float), s.stream));
-    if (calls) {
-        if (!s.d_centre) {
-            HIP_TRY(e, hipMalloc((void **)&s.d_centre, (size_t)e->max_pad * 2));
-            HIP_TRY(e, hipHostMalloc((void **)&s.h_centre, (size_t)e->max_batch * 2, hipHostMallocDefault));
-            HIP_TRY(e, hipMalloc((void **)&s.d_calls, (size_t)e->max_pad * sizeof(clair_call_t)));
-            HIP_TRY(e, hipHostMalloc((void **)&s.h_calls, (size_t)e->max_batch * sizeof(clair_call_t), hipHostMallocDefault));
-        }
-        memcpy(s.h_centre, centre, (size_t)n * 2);
-        HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.stream));
-    }
-    if (enqueue_forward(e, s, s.d_x, s.d_out, n)) return 1;
-    if (calls) {
-        if (enqueue_decode(e, s, n)) return 1;
-        HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
-    }
-    if (want_probs) HIP_TRY(e, hipMemcpyAsync(s.h_out, s.d_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyDeviceToHost, s.stream));
-    if (s.fuse_flags)
-        HIP_TRY(e, hipMemcpyAsync(s.h_out + (size_t)e->max_batch * OUT_FLOATS, s.fuse_flags + fuse_words(e->max_pad), sizeof(unsigned), hipMemcpyDeviceToHost, s.stream));
-    s.o_gt21 = gt21; s.o_gt = genotype; s.o_l1 = l1; s.o_l2 = l2;
-    s.o_calls = calls;
-    s.pending_n = n;
-    return 0;
+    return submit_request(e, slot, clair_engine::Request{input, input_is_counts != 0, input_stride_bytes, n, centre, calls, gt21, genotype, l1, l2});
 }
 
 // The decode alone, on probabilities the caller already has (call_var's --input_probabilities path, clair/call_var.py:1276-1309): synchronous.
@@ -817,12 +1008,14 @@ int clair_decode(clair_engine_t *e, int slot, const float *x, const float *gt21,
         memcpy(row + 57, l2 + (size_t)i * 33, 33 * sizeof(float));
     }
     memcpy(s.h_centre, centre, (size_t)n * 2);
-    HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(e, hipMemcpyAsync(s.d_out, s.h_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.stream));
-    if (enqueue_decode(e, s, n)) return 1;
-    HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    Lane &l = *e->lanes[s.lane];
+    std::lock_guard<std::mutex> g(l.order);
+    HIP_TRY(e, hipMemcpyAsync(s.d_x, x, (size_t)n * CLAIR_INPUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, l.stream));
+    HIP_TRY(e, hipMemcpyAsync(s.d_out, s.h_out, (size_t)n * OUT_FLOATS * sizeof(float), hipMemcpyHostToDevice, l.stream));
+    HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, l.stream));
+    if (enqueue_decode(e, l, s, n)) return 1;
+    HIP_TRY(e, hipMemcpyAsync(s.h_calls, s.d_calls, (size_t)n * sizeof(clair_call_t), hipMemcpyDeviceToHost, l.stream));
+    HIP_TRY(e, hipStreamSynchronize(l.stream));
     memcpy(calls, s.h_calls, (size_t)n * sizeof(clair_call_t));
     return 0;
 }
@@ -872,14 +1065,15 @@ int clair_run_resident(clair_engine_t *e, int slot, const void *x_dev, void *out
     if (check_slot(e, slot)) return 1;
     if (n < 1 || n > e->max_batch) return fail(e, "n=%d out of range [1,%d]", n, e->max_batch);
     HIP_TRY(e, hipSetDevice(e->device));
-    return enqueue_forward(e, e->slots[slot], (const float *)x_dev + (size_t)first * CLAIR_INPUT_FLOATS,
-                           (float *)out_dev + (size_t)first * OUT_FLOATS, n);
+    Lane &l = *e->lanes[e->slots[slot].lane];
+    std::lock_guard<std::mutex> g(l.order);
+    return enqueue_forward(e, l, (const float *)x_dev + (size_t)first * CLAIR_INPUT_FLOATS, (float *)out_dev + (size_t)first * OUT_FLOATS, n, -1);
 }
 
 int clair_sync(clair_engine_t *e) {
     if (!e) return fail(nullptr, "engine is NULL");
     HIP_TRY(e, hipSetDevice(e->device));
-    for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));
+    if (quiesce(e)) return 1;
     return check_fused_placement(e);
 }
 
@@ -946,7 +1140,7 @@ int clair_pinned_free(clair_engine_t *e, void *ptr) {
     for (size_t i = 0; i < e->pinned.size(); ++i)
         if (e->pinned[i].first == (char *)ptr) {
             HIP_TRY(e, hipSetDevice(e->device));
-            for (auto &s : e->slots) HIP_TRY(e, hipStreamSynchronize(s.stream));   // no copy may still be reading it
+            if (quiesce(e)) return 1;   // no copy may still be reading it
             HIP_TRY(e, hipHostFree(ptr));
             e->pinned.erase(e->pinned.begin() + (long)i);
             return 0;
@@ -967,8 +1161,8 @@ int clair_engine_counter(clair_engine_t *e, int which, int64_t *value) {
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count) {
     if (check_slot(e, slot)) return 1;
     HIP_TRY(e, hipSetDevice(e->device));
-    Slot &s = e->slots[slot];
-    HIP_TRY(e, hipStreamSynchronize(s.stream));
+    if (quiesce(e)) return 1;
+    Lane &s = *e->lanes[e->slots[slot].lane];
     const float *src = nullptr;
     int64_t avail = 0;
     const int64_t np = s.last_n_pad;

@@ -577,14 +577,15 @@ struct TextLine {                        // what pass A learns about a line
     int64_t pos0;
     uint32_t cigar_off, cigar_len, seq_off, seq_len;
     uint32_t n_ops, n_elem;
-    uint32_t flags;                      // CLAIR_READ_REVERSE | CLAIR_READ_EVC | TL_CANDIDATE | TL_ZERO_INDEL | TL_LONG_SPAN
+    uint32_t flags;                      // CLAIR_READ_REVERSE | CLAIR_READ_EVC | TL_CANDIDATE | TL_ZERO_INDEL | TL_LONG_SPAN | TL_LEAD_INDEL
     uint32_t pad;
 };
-enum { TL_CANDIDATE = 16, TL_ZERO_INDEL = 32, TL_LONG_SPAN = 64 };
+enum { TL_CANDIDATE = 16, TL_ZERO_INDEL = 32, TL_LONG_SPAN = 64, TL_LEAD_INDEL = 128 };   // TL_LEAD_INDEL: an I / D while the reference cursor is still at POS
 
 struct TextState {                       // carried from chunk to chunk (host copy in clair_frontend)
     int64_t prev_pos, depth_cap;         // CreateTensor.py:249-250, 277-287
     int64_t last_pos, have_last;         // sortedness of the kept alignments
+    int64_t evc_last_pos, have_evc_last; // POS of the last alignment the candidate search accepted (CLAIR_FE_LEAD_INDEL)
     int64_t lines, evc_reads, pile_reads;
     uint32_t anomalies, malformed;       // malformed: 1 + index of the first line the host packer would reject
 };
@@ -608,11 +609,12 @@ __device__ inline int64_t token_end(const uint8_t *t, int64_t q, int64_t end) {
 // walks a CIGAR; EMIT writes the kept operations
 template <bool EMIT>
 __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read, clair_op_t *ops, uint32_t *op_elem, uint32_t elem0,
-                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero) {
+                                  int64_t *o_rp, int64_t *o_qp, int64_t *o_soft, int64_t *o_total, int64_t *o_rlen, uint32_t *o_ops, uint64_t *o_elems, bool *o_zero,
+                                  bool *o_lead = nullptr) {
     int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
     uint32_t n_ops = 0;
     uint64_t elems = 0;
-    bool zero = false;
+    bool zero = false, lead = false;
     for (uint32_t i = 0; i < cl; ++i) {
         const uint8_t ch = cg[i];
         if (ch >= '0' && ch <= '9') { adv = adv * 10 + (ch - '0'); if (adv > ((int64_t)1 << 40)) adv = (int64_t)1 << 40; continue; }
@@ -634,6 +636,7 @@ __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read,
                 }
                 ++n_ops;
                 elems += (uint64_t)len;
+                if (code != CLAIR_OP_M && rp == 0) lead = true;       // tallied at POS - 1 by the candidate search (EVC :326-336)
             } else if (code != CLAIR_OP_M) {
                 zero = true;
             }
@@ -643,7 +646,7 @@ __device__ inline void walk_cigar(const uint8_t *cg, uint32_t cl, uint32_t read,
         total += adv;
         adv = 0;
     }
-    if (!EMIT) { *o_rp = rp; *o_qp = qp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; }
+    if (!EMIT) { *o_rp = rp; *o_qp = qp; *o_soft = soft; *o_total = total; *o_rlen = rlen; *o_ops = n_ops; *o_elems = elems; *o_zero = zero; if (o_lead) *o_lead = lead; }
 }
 
 __device__ inline bool text_int(const uint8_t *s, uint32_t len, int64_t *out) {     // [+-]digits, at most 18 of them (host_sampack.cpp)
@@ -694,8 +697,8 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     int64_t rp, qp, soft, total, rlen;
     uint32_t n_ops;
     uint64_t elems;
-    bool zero;
-    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &qp, &soft, &total, &rlen, &n_ops, &elems, &zero);
+    bool zero, lead;
+    walk_cigar<false>(text + col[5], len[5], 0, nullptr, nullptr, 0, &rp, &qp, &soft, &total, &rlen, &n_ops, &elems, &zero, &lead);
     const bool evc_ok = same_ctg && mq >= opt.evc_min_mq && !(len[5] == 1 && text[col[5]] == '*') && !(1.0 - (double)soft / (double)(total + 1) < 0.55);
     bool in_region = true;
     if (opt.pile_start >= 0 && opt.pile_end >= 0) {
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(256) void fe_text_lines_kernel(const uint8_t *text,
     out.seq_off = col[9]; out.seq_len = len[9];
     out.n_ops = n_ops;
     out.n_elem = elems > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)elems;
-    out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0)
+    out.flags = ((flag & 16) ? CLAIR_READ_REVERSE : 0) | (evc_ok ? CLAIR_READ_EVC : 0) | (candidate ? TL_CANDIDATE : 0) | (zero ? TL_ZERO_INDEL : 0) | (lead ? TL_LEAD_INDEL : 0)
                 | ((rp > (int64_t)len[9] + 100000 - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) ? TL_LONG_SPAN : 0);
     lines[k] = out;
     is_candidate[k] = candidate ? 1 : 0;
@@ -742,7 +745,8 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
     __shared__ uint64_t s_ops, s_elems;
     __shared__ uint32_t s_anom;
     __shared__ unsigned long long s_evc, s_pile;
-    if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_evc = 0; s_pile = 0; }
+    __shared__ unsigned long long s_last_evc;                                 // 1 + index (among the kept lines) of the last one the candidate search accepts
+    if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_evc = 0; s_pile = 0; s_last_evc = 0; }
     __syncthreads();
     uint64_t carry_ops = 0, carry_elems = 0;
     uint32_t anom = 0;
@@ -758,6 +762,20 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
             if (ln.pos0 < before) anom |= CLAIR_FE_UNSORTED;
             if ((ln.flags & TL_ZERO_INDEL) && (ln.flags & CLAIR_READ_EVC)) anom |= CLAIR_FE_ZERO_INDEL;
             if (ln.flags & TL_LONG_SPAN) anom |= CLAIR_FE_LONG_SPAN;
+            if (ln.flags & CLAIR_READ_EVC) {
+                atomicMax(&s_last_evc, (unsigned long long)(i + 1));
+                if (ln.flags & TL_LEAD_INDEL) {                                // rare: look back over the run of equal start positions for an accepted alignment
+                    bool earlier = false;
+                    int64_t j = i - 1;
+                    for (; j >= 0; --j) {
+                        const TextLine &b4 = lines[kept[j]];
+                        if (b4.pos0 != ln.pos0) break;
+                        if (b4.flags & CLAIR_READ_EVC) { earlier = true; break; }
+                    }
+                    if (!earlier && j < 0 && carry.have_evc_last && carry.evc_last_pos == ln.pos0) earlier = true;   // the run began in an earlier chunk
+                    if (earlier) anom |= CLAIR_FE_LEAD_INDEL;
+                }
+            }
             evc += (ln.flags & CLAIR_READ_EVC) ? 1 : 0;
             pile += (ln.flags & CLAIR_READ_PILE) ? 1 : 0;
         }
@@ -782,6 +800,7 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
         st.evc_reads = carry.evc_reads + (int64_t)s_evc;
         st.pile_reads = carry.pile_reads + (int64_t)s_pile;
         if (n_kept) { st.last_pos = lines[kept[n_kept - 1]].pos0; st.have_last = 1; }
+        if (s_last_evc) { st.evc_last_pos = lines[kept[s_last_evc - 1]].pos0; st.have_evc_last = 1; }
         if (n_cand) {                                                         // previous_position / depthCap after the last pileup candidate
             const int64_t pos = lines[cand[n_cand - 1]].pos0;
             int64_t a = 0, b = n_cand - 1;

@@ -39,6 +39,8 @@ struct clair_sampack {
     int64_t prev_pos = 0, depth_cap = 0;          // CreateTensor.py:249-250, 277-287
     bool have_last = false;
     int64_t last_pos = 0;
+    bool have_evc_last = false;                   // POS of the last alignment the candidate search accepted (CLAIR_FE_LEAD_INDEL)
+    int64_t evc_last_pos = 0;
     int64_t lines_seen = 0, evc_reads = 0, pile_reads = 0, reads_total = 0;
     uint32_t anomalies = 0;
 
@@ -91,7 +93,7 @@ struct clair_sampack {
         // the CIGAR, once: the operations, the aligned fraction of the candidate search (EVC :143-157), samtools' reference length
         const size_t op_first = ops.size();
         int64_t adv = 0, rp = 0, qp = 0, soft = 0, total = 0, rlen = 0;
-        bool zero_indel = false;
+        bool zero_indel = false, lead_indel = false;   // lead_indel: an I / D while the reference cursor is still at POS (tallied at POS - 1, EVC :326-336)
         uint64_t elems = op_elem.back();
         const uint32_t read_index = (uint32_t)reads.size();
         auto push = [&](uint32_t code) {
@@ -110,11 +112,11 @@ struct clair_sampack {
                 rp += adv; qp += adv; rlen += adv;
                 break;
             case 'I':
-                if (adv) push(CLAIR_OP_I); else zero_indel = true;
+                if (adv) { push(CLAIR_OP_I); lead_indel |= rp == 0; } else zero_indel = true;
                 qp += adv;
                 break;
             case 'D':
-                if (adv) push(CLAIR_OP_D); else zero_indel = true;
+                if (adv) { push(CLAIR_OP_D); lead_indel |= rp == 0; } else zero_indel = true;
                 rp += adv; rlen += adv;
                 break;
             case 'N': rlen += adv; break;
@@ -151,6 +153,11 @@ struct clair_sampack {
         have_last = true;
         last_pos = pos;
         if (zero_indel && evc_ok) anomalies |= CLAIR_FE_ZERO_INDEL;
+        if (evc_ok) {   // the search flushes every position < POS after each alignment it accepts (EVC :345): a tally at POS - 1 by a later one stands alone
+            if (lead_indel && have_evc_last && evc_last_pos == pos) anomalies |= CLAIR_FE_LEAD_INDEL;
+            have_evc_last = true;
+            evc_last_pos = pos;
+        }
         if (rp > (int64_t)sl + LOOKAHEAD - 64 || rp > 0x7fffff00 || qp > 0x7fffff00) anomalies |= CLAIR_FE_LONG_SPAN;   // the last two: offsets beyond 32 bits
         if (elems > 0xfffffff0ull || seq.size() + sl > 0xfffffff0ull)
             return clair_host_fail("alignment line %lld: the slab is full (take it before feeding more)", (long long)line_no);

@@ -55,7 +55,10 @@ enum {
     CLAIR_FE_BAD_REF = 32,        /* reference base missing or not an IUPAC code under a walked position */
     CLAIR_FE_OVERFLOW = 64,       /* a count beyond int16 */
     CLAIR_FE_BUDGET = 128,        /* the budget of 5 M outstanding tuples would have run out (CT :181, 289): results depend on offer order */
-    CLAIR_FE_CANDIDATES = 256     /* a given candidate list is not strictly ascending */
+    CLAIR_FE_CANDIDATES = 256,    /* a given candidate list is not strictly ascending */
+    CLAIR_FE_LEAD_INDEL = 512     /* an alignment the candidate search accepts begins with an I or D (tallied at POS - 1) and an earlier accepted alignment has
+                                   * the same POS: the reference flushed POS - 1 after that one (EVC :316-345: positions < POS after EVERY alignment) and
+                                   * evaluates the late tally on its own, which one sum per position cannot reproduce */
 };
 
 #ifdef __cplusplus

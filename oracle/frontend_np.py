@@ -49,7 +49,7 @@ EVC_IDX[ord("N")] = 6
 OP_M, OP_I, OP_D = 0, 1, 2
 F_STRAND, F_EVC, F_PILE, F_FLUSH = 1, 2, 4, 8
 
-A_UNSORTED, A_ZERO_INDEL, A_LONG_SPAN, A_SEQ_OVERRUN, A_BAD_BASE, A_BAD_REF, A_OVERFLOW, A_BUDGET, A_CANDIDATES = (1 << i for i in range(9))
+A_UNSORTED, A_ZERO_INDEL, A_LONG_SPAN, A_SEQ_OVERRUN, A_BAD_BASE, A_BAD_REF, A_OVERFLOW, A_BUDGET, A_CANDIDATES, A_LEAD_INDEL = (1 << i for i in range(10))
 
 
 def _is_space(c):
@@ -68,6 +68,7 @@ def pack_sam(sam, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=N
     anomalies = 0
     prev_pos, depth_cap = 0, 0
     last_pos = None
+    evc_last_pos = None
     n_lines = 0
     lines = sam.split(b"\n")
     if lines and lines[-1] == b"":
@@ -85,7 +86,7 @@ def pack_sam(sam, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=N
         cigar, seq = col[5], col[9].upper()
         pos = pos1 - 1
         # the operations both scripts walk: M/=/X, I, D; S moves the read cursor; anything else is skipped without moving either cursor
-        ops, adv, rp, qp, soft, total, zero_indel = [], 0, 0, 0, 0, 0, False
+        ops, adv, rp, qp, soft, total, zero_indel, lead_indel = [], 0, 0, 0, 0, 0, False, False
         for ch in cigar:
             if 48 <= ch <= 57:
                 adv = adv * 10 + (ch - 48)
@@ -102,12 +103,14 @@ def pack_sam(sam, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=N
             elif c == "I":
                 if adv:
                     ops.append((OP_I, adv, rp, qp))
+                    lead_indel |= rp == 0
                 else:
                     zero_indel = True
                 qp += adv
             elif c == "D":
                 if adv:
                     ops.append((OP_D, adv, rp, qp))
+                    lead_indel |= rp == 0
                 else:
                     zero_indel = True
                 rp += adv
@@ -143,6 +146,12 @@ def pack_sam(sam, ctg_name, dcov=250, evc_min_mq=0, pile_min_mq=0, pile_region=N
         last_pos = pos
         if zero_indel and evc_ok:
             anomalies |= A_ZERO_INDEL
+        if evc_ok:
+            # ExtractVariantCandidates.py:345 flushes every position < POS after EACH accepted alignment: an I / D tallied at POS - 1
+            # (:326-336, the cursor still at POS) by a later alignment of the same POS is evaluated on its own there
+            if lead_indel and evc_last_pos == pos:
+                anomalies |= A_LEAD_INDEL
+            evc_last_pos = pos
         if rp > len(seq) + LOOKAHEAD - 64 or rp > 0x7fffff00 or qp > 0x7fffff00:
             anomalies |= A_LONG_SPAN
         r = len(pos0)

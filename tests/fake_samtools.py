@@ -8,6 +8,7 @@ scripts) pass `--samtools "python tests/fake_samtools.py"`: `<bam>` is then a SA
 
     faidx <fasta> [region ...]   region = ctg | ctg:start-end (1-based, inclusive, clamped); 60 columns per line
     view [-@ N] -F <int> <sam> [region] alignments with FLAG & int == 0 that overlap the region, header lines dropped
+         [--no-PG] [-x TAG] [--keep-tag TAG[,TAG]]   as samtools: no effect on alignment lines / drop a tag / keep only these tags
 """
 import re
 import sys
@@ -54,11 +55,21 @@ def reference_span(cigar):
 
 
 def view(argv):
-    flags = 0
-    while argv and argv[0] in ("-F", "-@"):
+    flags, drop, keep = 0, set(), None
+    while argv and argv[0].startswith("-"):
+        if argv[0] == "--no-PG":
+            argv = argv[1:]
+            continue
         if argv[0] == "-F":
             flags = int(argv[1])
-        argv = argv[2:]                      # -@ N: threads, nothing to do here
+        elif argv[0] == "-x":
+            drop.add(argv[1])
+        elif argv[0] == "--keep-tag":
+            keep = set(argv[1].split(","))
+        elif argv[0] != "-@":                # -@ N: threads, nothing to do here
+            sys.stderr.write("[view] unknown option %s\n" % argv[0])
+            return 1
+        argv = argv[2:]
     path, regions = argv[0], [parse_region(r) for r in argv[1:]]
     with open(path) as f:
         for line in f:
@@ -71,6 +82,9 @@ def view(argv):
             end = pos + max(reference_span(col[5]), 1) - 1
             if regions and not any(col[2] == c and (s is None or (pos <= e and end >= s)) for c, s, e in regions):
                 continue
+            if (drop or keep is not None) and len(col) > 11:
+                tags = [t for t in line.rstrip("\n").split("\t")[11:] if t[:2] not in drop and (keep is None or t[:2] in keep)]
+                line = "\t".join(col[:11]).rstrip("\n") + "".join("\t" + t for t in tags) + "\n"
             sys.stdout.write(line)
     return 0
 

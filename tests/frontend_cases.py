@@ -124,13 +124,14 @@ def text_of(ctg, centres, seqs, counts):
                    for i, c in enumerate(centres.tolist()))
 
 
-def fuzz_case(seed):
-    """A random small case with random options of both stages -> (case, pileup kw, candidate-search kw, region or None)."""
+def fuzz_case(seed, **synth_kw):
+    """A random small case with random options of both stages -> (case, pileup kw, candidate-search kw, region or None).
+    synth_kw: further options of pileup_synth.synth_case (lead_indel: drawn from a generator of its own, the rest of the case is unchanged)."""
     rng = np.random.default_rng(1000 + seed)
     ref_len = int(rng.integers(600, 2500))
     case = synth(seed, n_reads=int(rng.integers(20, 260)), ref_len=ref_len, read_len=(30, int(rng.integers(60, 400))),
                  cand_step=(1, int(rng.integers(3, 50))), sub_rate=float(rng.choice([0.01, 0.04, 0.15])), ins_rate=float(rng.choice([0.0, 0.02, 0.1])),
-                 del_rate=float(rng.choice([0.0, 0.02, 0.1])), dup_burst=int(rng.choice([0, 0, 5, 12])), skip_ops=bool(rng.integers(0, 2)))
+                 del_rate=float(rng.choice([0.0, 0.02, 0.1])), dup_burst=int(rng.choice([0, 0, 5, 12])), skip_ops=bool(rng.integers(0, 2)), **synth_kw)
     pile_kw = dict(dcov=int(rng.choice([250, 250, 1, 3])), min_mq=int(rng.choice([0, 0, 10, 40])), min_coverage=int(rng.choice([0, 0, 2, 6])))
     evc_kw = dict(min_coverage=float(rng.choice([4, 1, 8, 2.5])), threshold=float(rng.choice([0.125, 0.05, 0.3])), min_mq=int(rng.choice([0, 0, 15])))
     region = None

@@ -16,8 +16,14 @@ def _mutate(rng, base):
 
 
 def synth_case(seed, ref_len=3000, n_reads=300, read_len=(40, 300), ctg="chrS", cand_step=(3, 40),
-               sub_rate=0.04, ins_rate=0.02, del_rate=0.02, dup_burst=0, iupac=True, second_ctg=True, skip_ops=True):
+               sub_rate=0.04, ins_rate=0.02, del_rate=0.02, dup_burst=0, iupac=True, second_ctg=True, skip_ops=True,
+               lead_indel=0.0, lead_indel_late=True):
+    """lead_indel: share of reads whose CIGAR begins (after a clip) with an insertion or deletion -- what the candidate search tallies at
+    POS - 1 (ExtractVariantCandidates.py:326-336) and the pileup hangs on no window; lead_indel_late=False gives one only to reads that
+    are the first at their start position (the search then sees it together with the rest of POS - 1).  Drawn from a generator of its
+    own, so that every other byte of a case is what it was without the option."""
     rng = np.random.default_rng(seed)
+    lead_rng = np.random.default_rng(seed + 7919) if lead_indel > 0 else None
     ref = "".join(BASES[i] for i in rng.integers(0, 4, ref_len))
     ref = list(ref)
     if iupac:
@@ -46,6 +52,17 @@ def synth_case(seed, ref_len=3000, n_reads=300, read_len=(40, 300), ctg="chrS", 
                 ops.append((n, "S"))
                 seq += [BASES[i] for i in rng.integers(0, 4, n)]
         use_eqx = rng.random() < 0.15
+        if lead_rng is not None and lead_rng.random() < lead_indel and (lead_indel_late or ri == 0 or int(starts[ri - 1]) != start):
+            n = int(lead_rng.integers(1, 4))
+            if lead_rng.random() < 0.5:
+                ops.append((n, "I"))
+                seq += [BASES[i] for i in lead_rng.integers(0, 4, n)]
+            elif rp + n < ref_len - 2:
+                ops.append((n, "D"))
+                rp += n
+            if lead_rng.random() < 0.2 and ops and ops[-1][1] == "I" and rp + 2 < ref_len - 2:      # both before the first matched base
+                ops.append((2, "D"))
+                rp += 2
         while rp < min(start + want, ref_len):
             r = rng.random()
             if r < ins_rate and ops and ops[-1][1] in "M=X":

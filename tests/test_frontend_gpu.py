@@ -44,7 +44,7 @@ def test_windows_reproduce_reference_tensor_records(path):
     f = device_frontend(case, slabs=3, dcov=case["dcov"], pile_min_mq=case["min_mq"], pile_region=case["pile_region"])
     assert f.set_candidates(case["candidates"]) == len(case["candidates"])
     n = f.build_windows(min_coverage=case["min_coverage"], drop_non_iupac_centre=False, consider_left_edge=case["left_edge"])
-    assert f.stats()["anomalies"] == 0 and f.host_anomalies == 0 and not f.budget_binds()
+    assert f.stats()["anomalies"] == 0 and f.host_anomalies == (fe.A_LEAD_INDEL if "lead_indel" in path else 0) and not f.budget_binds()
     centres, seqs, counts = windows_of(f)
     assert n == len(centres) > 20
     assert fc.text_of(case["ctg"], centres, seqs, counts) == case["expected"]
@@ -58,6 +58,12 @@ def test_candidates_reproduce_reference_rows(path):
     n = f.find_candidates(min_coverage=case["min_coverage"], threshold=case["threshold"], ctg_start=rng[0], ctg_end=rng[1], bed=case["bed"])
     assert f.stats()["anomalies"] == 0
     got = f.candidates()
+    if "lead_indel_late" in path:     # reported by the packer (and by the device's own text pass, below): the sequential stage's regime
+        assert f.host_anomalies == fe.A_LEAD_INDEL
+        g = device_frontend_text(case, chunks=3, evc_min_mq=case["min_mq"])
+        assert g.text_stats()["anomalies"] == fe.A_LEAD_INDEL
+        return
+    assert f.host_anomalies == 0
     assert n == len(got) and np.array_equal(got, case["expected_positions"])
 
 
@@ -315,6 +321,33 @@ def test_differential_fuzz_with_the_text_parsed_on_the_device(block):
     assert done > 300
 
 
+def test_differential_fuzz_with_leading_indels_on_the_device():
+    """As tests/test_frontend.py::test_differential_fuzz_with_leading_indels, through both packing paths of the device front end."""
+    silent = reported = 0
+    for seed in range(300, 318):
+        case, pile_kw, evc_kw, region = fc.fuzz_case(seed, lead_indel=0.25, lead_indel_late=bool(seed & 1))
+        rng = dict(ctg_start=region[0], ctg_end=region[1]) if region else {}
+        want_pos = fc.host_candidates(case, **rng, **{k: v for k, v in evc_kw.items() if k != "bed"})
+        hc, hs, hcounts = fc.host_windows(case, candidates=want_pos, pile_region=region, dcov=pile_kw["dcov"], min_mq=pile_kw["min_mq"],
+                                          min_coverage=pile_kw["min_coverage"])
+        kw = dict(dcov=pile_kw["dcov"], pile_min_mq=pile_kw["min_mq"], evc_min_mq=evc_kw["min_mq"], pile_region=region)
+        f, g = device_frontend_text(case, chunks=1 + seed % 4, **kw), device_frontend(case, slabs=1 + seed % 3, **kw)
+        bits = g.host_anomalies
+        assert f.text_stats()["anomalies"] == bits and bits & ~fe.A_LEAD_INDEL == 0, seed
+        for h in (f, g):
+            n = h.find_candidates(min_coverage=evc_kw["min_coverage"], threshold=evc_kw["threshold"], ctg_start=rng.get("ctg_start"), ctg_end=rng.get("ctg_end"))
+            if not bits:
+                assert n == len(want_pos) and np.array_equal(h.candidates(), want_pos), seed
+            h.set_candidates(want_pos)
+            h.build_windows(min_coverage=pile_kw["min_coverage"], drop_non_iupac_centre=False)
+            centres, seqs, counts = windows_of(h)
+            assert np.array_equal(hc, centres) and np.array_equal(hs, seqs) and np.array_equal(hcounts, counts), seed
+            h.close()
+        silent += not bits
+        reported += bool(bits)
+    assert silent >= 4 and reported >= 2, (silent, reported)
+
+
 def test_text_on_the_device_reports_what_the_host_packer_reports():
     ok = b"r1\t0\tchrS\t10\t60\t5M\t*\t0\t0\tACGTA\tIIIII\n"
     ref = "ACGT" * 100
@@ -345,6 +378,24 @@ def test_text_on_the_device_reports_what_the_host_packer_reports():
     assert f.text_stats() == dict(lines=3, evc_reads=1, pile_reads=1, anomalies=0) and f.stats()["reads"] == 1
     with pytest.raises(_capi.EngineError, match="line end"):
         fresh().add_text(ok[:-1])
+    # an I / D before the first matched base, after another accepted alignment of the same POS: in one chunk, across chunks,
+    # behind an alignment only the pileup takes, and the cases that are fine
+    from test_frontend import _lead_indel_sam
+    for first, later, kw, want in (("30M", "2I30M", {}, fe.A_LEAD_INDEL), ("2I30M", "3D30M", {}, fe.A_LEAD_INDEL), ("30M", "4S2I3D30M", {}, fe.A_LEAD_INDEL),
+                                   ("2I30M", "30M", {}, 0), ("30M", "2M2I28M", {}, 0)):
+        sam = _lead_indel_sam(first, later)
+        for cut in (len(sam), sam.rindex(b"q1")):
+            f = fresh(**kw)
+            f.add_text(sam[:cut])
+            if cut < len(sam):
+                f.add_text(sam[cut:])
+            p = _hostapi.SamPacker("chrS", **kw)
+            p.feed(sam, final=True)
+            assert f.text_stats()["anomalies"] == p.stats()["anomalies"] == want, (first, later, cut)
+    sam = _lead_indel_sam("30M", "2I30M").replace(b"q0\t0\tchrS\t102\t60", b"q0\t0\tchrS\t102\t5")   # the search skips q0 (--minMQ), the pileup keeps it
+    f = fresh(evc_min_mq=10)
+    f.add_text(sam)
+    assert f.text_stats()["anomalies"] == 0
     # lower-case bases stay lower-case in the slab and count as their upper-case selves (both scripts upper-case SEQ first)
     f, g = fresh(), fresh()
     f.add_text(b"r1\t0\tchrS\t100\t60\t5M\t*\t0\t0\tacgta\tIIIII\n" * 6)

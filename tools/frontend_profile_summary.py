@@ -57,10 +57,13 @@ def main():
         print("%-34s %8d %10.1f %10d %12.1f %12.1f %12.0f %14.1f %10.0f"
               % (short, len(sel), mean, max(g for _, g in dur[name]), fmb, wmb, (fmb + wmb) / mean * 1e3 if mean else 0, alg, alg / mean * 1e3 if mean else 0))
     if elements:
-        for key, label in (("fe_tally", "pass 1"), ("fe_windows_per_base", "pass 2")):
+        for key, label in (("fe_tally", "pass 1"), ("fe_windows_per_", "pass 2")):   # pass 2: per operation, or per base with --stop_consider_left_edge
             d = [x for k in dur for x, _ in dur[k] if key in k]
             runs = arg("--runs", 4)                     # the bench builds the front end four times (twice per packing path)
             per_run = sum(d) / runs
+            if not d or per_run <= 0:
+                print("# %s: no launches in this trace" % label)
+                continue
             print("# %s: %.0f M read bases in %.0f us over %d launches = %.1f G read bases/s" % (label, elements / 1e6, per_run, len(d) // runs, elements / per_run / 1e3))
         print("# %d positions, %d windows" % (positions, windows))
 

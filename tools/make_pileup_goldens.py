@@ -52,6 +52,8 @@ CT_CASES = {
     "ct_dcov": (dict(seed=14, dup_burst=14), ["--dcov", "3"], False, False),
     "ct_dense_long": (dict(seed=15, n_reads=120, read_len=(300, 1200), cand_step=(1, 4), ref_len=2500), [], False, False),
     "ct_unsorted_candidates": (dict(seed=16, n_reads=200), [], False, True),
+    # round 4: alignments that begin with an insertion / deletion, also several at one start position
+    "ct_lead_indel": (dict(seed=17, dup_burst=8, lead_indel=0.3), [], False, False),
 }
 
 
@@ -64,8 +66,13 @@ def run_reference(module, args, stdin_text, cwd, extra_path=None):
     return r.stdout
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]     # mint just these cases (the others are committed and pinned)
+
+
 def mint_create_tensor():
     for name, (kw, extra, via_file, shuffle) in CT_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         case = pileup_synth.synth_case(**kw)
         cands = case["candidates"]
         if shuffle:
@@ -103,11 +110,18 @@ EVC_CASES = {
                 "chrS\t100\t600\nchrS\t550\t900\nchrS\t1500\t1500\nchrS\t2000\t2900\nchrOther\t0\t50\n", False),
     "evc_strict": (dict(seed=24, n_reads=500, sub_rate=0.08), ["--threshold", "0.3", "--minCoverage", "12"], None, False),
     "evc_lowcov": (dict(seed=25, n_reads=60), ["--minCoverage", "1", "--threshold", "0.05"], None, False),
+    # round 4: a leading I / D is tallied at POS - 1.  "first": only on the first alignment of a start position (one sum per
+    # position is what the reference evaluates); "late": also behind another alignment of the same POS, where the reference has flushed
+    # POS - 1 already and evaluates the late tally alone -- the regime CLAIR_FE_LEAD_INDEL hands to the sequential code
+    "evc_lead_indel_first": (dict(seed=26, n_reads=500, dup_burst=10, lead_indel=0.3, lead_indel_late=False, ins_rate=0.01), ["--minCoverage", "2"], None, False),
+    "evc_lead_indel_late": (dict(seed=27, n_reads=500, dup_burst=10, lead_indel=0.3, ins_rate=0.01), ["--minCoverage", "2"], None, False),
 }
 
 
 def mint_extract_candidates():
     for name, (kw, extra, bed, via_file) in EVC_CASES.items():
+        if ONLY and name not in ONLY:
+            continue
         case = pileup_synth.synth_case(**kw)
         with tempfile.TemporaryDirectory() as tmp:
             fa, sam, bedf, can = (os.path.join(tmp, n) for n in ("ref.fa", "reads.sam", "regions.bed", "cands.gz"))
@@ -165,4 +179,5 @@ if __name__ == "__main__":
     if "--evc-only" not in sys.argv:
         mint_create_tensor()
     mint_extract_candidates()
-    mint_parallel()
+    if not ONLY:
+        mint_parallel()

@@ -11,7 +11,8 @@ Committed outputs (data only -- inputs and expected outputs):
   tests/golden/ingest_cases.npz + ingest_*.txt.gz    G1  text records -> (X, infos) batches, stderr progress
   tests/golden/decode_cases.npz / decode_rows.json.gz   G2  (x, seq, probs) -> VCF rows, 6 output configs
   tests/golden/header_*.vcf                           G3  VCF headers without / with a .fai
-  tests/golden/ensemble_roundtrip.txt                 G4  --output_for_ensemble lines
+  tests/golden/decode_rows.json.gz ["ensemble"]       G4  --output_for_ensemble lines (the sixth output config of G2; read back
+                                                          through --input_probabilities in tests/test_decode.py)
   tests/golden/e2e_*.{txt.gz,vcf}                     C2  whole driver: tensor file -> VCF (oracle probabilities)
 
 NumPy note: this container has NumPy 2.2; the reference pins NumPy 1.18 (README.md:127).  Under
