@@ -14,6 +14,17 @@ RCCL / xGMI through the C ABI's communicator (include/clair_amd.h: clair_comm_*)
 runs --steps batches.  `--scaling strong --candidates M`: a fixed set of M candidates (default 5 000 000, the
 whole-genome configs[3]) is dealt in contiguous blocks of whole batches; --steps is then derived.
 
+After the contract's timed region (`value`: inputs resident in HBM) the same K steps are timed twice more, each exactly like `value`
+(W warm-up steps, barrier + device sync on both sides, max over ranks):
+  value_boundary        -- through the reference's own boundary, Clair.predict(batchX) on HOST arrays (clair/model.py:946-966, driven by
+                           clair/call_var.py:1331-1352): pageable float32 NumPy batches in, four fresh NumPy arrays per batch out
+                           (clair_submit / clair_wait, `boundary.slots` batches in flight);
+  value_boundary_int16  -- the same with the raw int16 counts the pileup stage produces (clair_submit_counts);
+and one leg over the whole candidate set BASELINE.json's config names (`--full-candidates`, 200 704 = 196 x 1024 for configs[1]):
+  value_full_config / value_boundary_full_config -- so that a driver run with a handful of --steps still shows the sustained rate.
+`gpu_state` holds the shader clock and socket power sampled from sysfs (tools/gpu_state_sampler.py, a process of its own) during
+each of those legs.
+
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the dominant kernel = the one with the most chip time (stand-alone duration x share of the 256 CUs its grid
                   occupies) in THIS run's own per-kernel table: SURVEY.md 8(d) algorithmic FLOP per launch / its mean
@@ -109,6 +120,8 @@ def parse_args(argv=None):
     ap.add_argument("--unique-batches", type=int, default=8, help="distinct synthetic batches kept resident")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--candidates", type=int, default=5000000, help="--scaling strong: size of the fixed candidate set")
+    ap.add_argument("--full-candidates", type=int, default=200704, help="size of the untimed-by-contract leg over the whole candidate set of the config (0: skip)")
+    ap.add_argument("--boundary-slots", type=int, default=6, help="batches in flight at the host-array boundary (0: skip the boundary legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -173,6 +186,122 @@ def cpu_baseline(w, x, seconds):
             "sample_4_threads": "%d candidates, 4 OpenMP threads (the reference's default --threads), %.1f s" % (n_4, dt_4)}
 
 
+class GpuStateSampler(object):
+    """sclk / socket power of this rank's GPU while a leg runs: tools/gpu_state_sampler.py as a child process writing time-stamped
+    samples (CLOCK_MONOTONIC, shared by all processes of the box); mean over the samples inside [t0, t1], or the nearest one."""
+
+    def __init__(self, device):
+        import subprocess
+        import tempfile
+        self.path = tempfile.mktemp(prefix="clair_gpu_state_", suffix=".txt")
+        self.proc = None
+        card = "auto"
+        try:                                   # the sysfs directory of THIS HIP device
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+                cand = "/sys/bus/pci/devices/%s" % buf.value.decode().lower()
+                if os.path.isdir(cand):
+                    card = cand
+        except OSError:
+            pass
+        try:
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_state_sampler.py"), card, self.path, "1"], stdin=subprocess.PIPE)
+        except OSError:
+            pass
+
+    def close(self):
+        self.samples, self.source = [], None
+        if self.proc is None:
+            return
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=5)
+        except Exception:
+            self.proc.kill()
+        try:
+            for line in open(self.path):
+                if line.startswith("#"):
+                    self.source = line[1:].strip()
+                    continue
+                t, mhz, w = line.split()
+                self.samples.append((int(t), float(mhz), float(w)))
+            os.remove(self.path)
+        except (OSError, ValueError):
+            pass
+
+    def during(self, t0, t1):
+        inside = [s_ for s_ in self.samples if t0 <= s_[0] <= t1]
+        how = "%d samples inside the leg" % len(inside)
+        if not inside and self.samples:
+            mid = (t0 + t1) // 2
+            inside = [min(self.samples, key=lambda s_: abs(s_[0] - mid))]
+            how = "nearest sample, %.1f ms from the middle of the leg" % (abs(inside[0][0] - mid) / 1e6)
+        mhz = [s_[1] for s_ in inside if s_[1] > 0]
+        w = [s_[2] for s_ in inside if s_[2] > 0]
+        return {"sclk_mhz": round(sum(mhz) / len(mhz)) if mhz else None, "power_w": round(sum(w) / len(w), 1) if w else None, "samples": how}
+
+
+def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq, steps, timed, full_steps):
+    """value_boundary: the timed loop again through clair_submit / clair_wait on host arrays.  A second handle with `--boundary-slots`
+    slots over the same three compute lanes; every batch is a pageable NumPy array (a different one per step, `nuniq` of them) and every
+    result four fresh NumPy arrays, as clair/model.py:946-966 returns them.  The last batch's outputs are compared bit for bit with the
+    resident path's."""
+    world = group.world
+    slots = args.boundary_slots
+    eng = _capi.Engine(device=device, max_batch=batch, n_slots=slots)
+    eng.load_weights(w)
+    xs = [np.ascontiguousarray(x[i * batch:(i + 1) * batch]) for i in range(nuniq)]
+    cs = []
+    for a in xs:                       # the raw counts these tensors stand for (clair/utils.py:96-98 undone): exactly representable
+        c = a.copy()
+        c[..., 1:] += c[..., 0:1]
+        cs.append(c.astype(np.int16))
+    last = [None, None]                # (step index, outputs) of the batch that came back last
+    pending = {}                       # slot -> step index
+
+    def loop(k, counts):
+        for i in range(k):
+            s = i % slots
+            if s in pending:
+                last[:] = [pending.pop(s), eng.wait(s)]
+            if counts:
+                eng.submit_counts(s, cs[i % nuniq])
+            else:
+                eng.submit(s, xs[i % nuniq])
+            pending[s] = i
+
+    def drain():
+        for s in sorted(pending, key=pending.get):
+            last[:] = [pending.pop(s), eng.wait(s)]
+
+    out = {"slots": slots, "lanes": min(slots, 3), "steps": steps,
+           "interface": "pageable NumPy batches [n,33,8,4] in, four fresh NumPy arrays per batch out (clair_submit / clair_submit_counts + clair_wait); "
+                        "staging copy and enqueue on the engine's staging threads, H2D on one copy stream, results written to page-locked host "
+                        "memory by a kernel on the lane"}
+    # device warm-up outside the contract's W steps, as before `value`: the handle's first-use allocations, and the clock the chip dropped to
+    # while this handle was being set up
+    loop(max(0, WARM_STEPS - args.warmup), False)
+    drain()
+    for name, counts, k in (("float32", False, steps), ("int16", True, steps), ("float32_full", False, full_steps), ("int16_full", True, full_steps)):
+        if k <= 0:
+            continue
+        loop(args.warmup, counts)
+        drain()
+        secs = group.max_float(timed("value_boundary" + ("" if name == "float32" else "_" + name), lambda: loop(k, counts), drain))
+        out[name] = {"value": round(world * k * batch / secs, 1), "steps": k, "ms_per_step": round(secs / k * 1e3, 4),
+                     "h2d_bytes_per_candidate": 2112 if counts else 4224}
+    # the last batch of the last leg against the resident path on the same candidates
+    i = (last[0] or 0) % nuniq
+    eng_resident.run_resident(0, xd, od, i * batch, batch)
+    eng_resident.sync()
+    ref = _capi.split_outputs(eng_resident.dataset_download(od, i * batch, batch))
+    out["bit_identical_to_resident"] = bool(last[1] is not None and all(np.array_equal(a, b) for a, b in zip(last[1], ref)))
+    eng.close()
+    return out
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -225,20 +354,42 @@ def run_ranked(args, group, json_fd):
     eng.sync()
     run(args.warmup)
     eng.sync()
+    sampler = GpuStateSampler(local_rank) if rank == 0 else None
+    legs = {}                                   # name -> (CLOCK_MONOTONIC ns at both ends) for gpu_state
+
+    def timed(name, body, finish):
+        """The contract's bracket: barrier + device sync, the body, device sync + barrier; -> this rank's seconds."""
+        group.barrier()
+        eng.sync()
+        m0, t_0 = time.monotonic_ns(), time.perf_counter()
+        body()
+        finish()
+        secs = time.perf_counter() - t_0
+        legs[name] = (m0, time.monotonic_ns())
+        group.barrier()
+        return secs
+
     # Timed region: the plain hot path, no instrumentation.
     eng.timing_enable(False)
-    group.barrier()
-    eng.sync()
-    t0 = time.perf_counter()
-    run(steps, ragged_last=True)
-    eng.sync()
-    mine_s = time.perf_counter() - t0
-    group.barrier()
+    mine_s = timed("value", lambda: run(steps, ragged_last=True), eng.sync)
     elapsed = group.max_float(mine_s)          # the slowest rank defines the job time
     per_rank_s = group.gather_floats(mine_s)
     per_rank_steps = [int(round(v)) for v in group.gather_floats(steps)]
     per_rank_candidates = [int(round(v)) for v in group.gather_floats(mine_candidates)]
     rccl_ranks = int(round(sum(group.gather_floats(1.0 if group.transport == "rccl" else 0.0))))
+
+    # The whole candidate set of the config, untimed by the contract: what the rate is when the run is not a handful of steps.
+    full = None
+    if args.full_candidates > 0 and args.scaling == "weak":
+        full_steps = (args.full_candidates + batch - 1) // batch
+        full_s = group.max_float(timed("value_full_config", lambda: run(full_steps), eng.sync))
+        full = {"steps": full_steps, "candidates_per_rank": full_steps * batch, "seconds": round(full_s, 6), "value": round(world * full_steps * batch / full_s, 1),
+                "ms_per_step": round(full_s / full_steps * 1e3, 4)}
+
+    # The same steps through the reference's own boundary: host arrays in, host arrays out (clair_submit / clair_wait), timed like `value`.
+    boundary = None
+    if args.boundary_slots > 0:
+        boundary = boundary_legs(args, group, eng, local_rank, w, x, xd, od, batch, nuniq, steps, timed, full["steps"] if full else 0)
 
     # Per-kernel tables, outside the timed region.  (a) the same loop, same streams, every kernel bracketed by HIP events (ten marker
     # packets per pass); (b) the same on ONE stream, so that a kernel's HIP-event duration is its own ("alone").
@@ -350,9 +501,16 @@ def run_ranked(args, group, json_fd):
         if world > 1 and rccl_ranks != world:
             sys.stderr.write("bench.py: %d of %d ranks hold an RCCL communicator; reporting n_gpus=%d\n" % (rccl_ranks, world, rccl_ranks))
             rc = 1
+        sampler.close()
+        gpu_state = {name: sampler.during(*span) for name, span in legs.items()}
+        gpu_state["source"] = sampler.source
         out = {
             "metric": "candidate sites/sec (whole node)",
             "value": round(value, 1),
+            "value_boundary": round(boundary["float32"]["value"], 1) if boundary else None,
+            "value_boundary_int16": round(boundary["int16"]["value"], 1) if boundary else None,
+            "value_full_config": round(full["value"], 1) if full else None,
+            "value_boundary_full_config": round(boundary["float32_full"]["value"], 1) if boundary and "float32_full" in boundary else None,
             "unit": "candidates/s",
             "n_gpus": n_gpus,
             "steps": steps_max,
@@ -373,6 +531,9 @@ def run_ranked(args, group, json_fd):
                        "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None},
             "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None}
                          for r, (s_, c_, t_) in enumerate(zip(per_rank_steps, per_rank_candidates, per_rank_s))],
+            "boundary": boundary,
+            "full_config": full,
+            "gpu_state": gpu_state,
             "roofline": roof,
             "roofline_path": {"achieved": round(path_tf, 2), "unit": "TFLOP/s per GPU (algorithmic, 40 386 432 FLOP / candidate)",
                               "frac_of_f16_mfma": round(path_tf / PEAK_F16_MFMA_TFLOPS, 4),

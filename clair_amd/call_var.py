@@ -823,7 +823,7 @@ def Run(args):
         from clair_amd.model import Clair
         batch = args.batch_size or param.predictBatchSize
         try:
-            m = Clair(device=args.device, max_batch=batch, n_slots=2)
+            m = Clair(device=args.device, max_batch=batch, n_slots=param.pipeline_slots())
             m.init()
             m.restore_parameters(os.path.abspath(args.chkpnt_fn))
         except Exception as exc:   # C-ABI errors surface as messages + non-zero exit

@@ -122,7 +122,7 @@ struct clair_engine {
     std::vector<std::unique_ptr<Lane>> lanes;
     std::vector<hipStream_t> copy_streams;   // owned here; the slots point into it
     int copy_mode = 3;                  // CLAIR_AMD_COPY_STREAMS=slot|two|lane|in (0, 1, 2, 3): see clair_engine_create
-    bool d2h_kernel = false;            // CLAIR_AMD_D2H=kernel: results written to page-locked host memory by a kernel instead of the copy engine
+    bool d2h_kernel = true;             // CLAIR_AMD_D2H=sdma: results fetched by the copy engine instead of written to page-locked host memory by a kernel
     // the staging worker (clair_submit* on pageable memory): the copy of the caller's batch into page-locked memory and the enqueue of its
     // transfers and kernels run on this thread, so that the submitting thread is free after a few microseconds, as the reference's
     // predict thread leaves load and output to two others (clair/call_var.py:1331-1352)
@@ -130,8 +130,9 @@ struct clair_engine {
         const void *input; bool counts; int64_t stride; int n;
         const uint8_t *centre; clair_call_t *calls; float *gt21, *gt, *l1, *l2;
     };
-    bool async_staging = true;          // CLAIR_AMD_ASYNC_STAGING=0: everything on the submitting thread
-    std::thread worker;
+    int staging_threads = 2;            // CLAIR_AMD_STAGING_THREADS (0: everything on the submitting thread): a 4.3 MB batch takes one core ~100 us
+                                        // to copy, 75 % of the 135 us the GPU needs for it
+    std::vector<std::thread> workers;
     std::mutex wmu;
     std::condition_variable wcv, wdone;
     std::deque<std::pair<int, Request>> wqueue;
@@ -555,16 +556,18 @@ int enqueue_request(clair_engine *e, int slot_index, const clair_engine::Request
         memcpy(s.h_centre, q.centre, (size_t)n * 2);
         HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.cin));
     }
+    {   // int16 counts -> the float32 tensor: behind the copy on the incoming stream, i.e. off the lane, which is computing another batch
+        const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
+        if (convert == DENSE)
+            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.cin, (const short4 *)convert_from, (f32x4 *)s.d_x, n_quads);
+        else if (convert == STRIDED)
+            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.cin, convert_from, stride, (f32x4 *)s.d_x, n_quads);
+    }
     if (!same_in) HIP_TRY(e, hipEventRecord(s.ev_in, s.cin));
     {
         std::unique_lock<std::mutex> g(l.order, std::defer_lock);
         if (!same_in) g.lock();
         if (!same_in) HIP_TRY(e, hipStreamWaitEvent(l.stream, s.ev_in, 0));
-        const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
-        if (convert == DENSE)
-            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, l.stream, (const short4 *)convert_from, (f32x4 *)s.d_x, n_quads);
-        else if (convert == STRIDED)
-            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, l.stream, convert_from, stride, (f32x4 *)s.d_x, n_quads);
         if (enqueue_forward(e, l, s.d_x, s.d_out, n, slot_index)) return 1;
         if (q.calls && enqueue_decode(e, l, s, n)) return 1;
         if (same_out) return enqueue_results(e, l, s, n, q.calls != nullptr, want_probs);      // in line with the kernels, under the lane's lock
@@ -605,7 +608,7 @@ int submit_request(clair_engine *e, int slot, const clair_engine::Request &q) {
     s.o_gt21 = q.gt21; s.o_gt = q.gt; s.o_l1 = q.l1; s.o_l2 = q.l2;
     s.o_calls = q.calls;
     s.refetch = false;
-    if (e->async_staging) {
+    if (!e->workers.empty()) {
         {
             std::lock_guard<std::mutex> g(e->wmu);
             s.staged = 1;
@@ -682,7 +685,8 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     { const char *t = getenv("CLAIR_AMD_FUSED_GROUPS"); if (t && atoi(t) > 0 && atoi(t) <= 8) e->fused_groups = atoi(t); }
     { const char *t = getenv("CLAIR_AMD_LSTM2_PAIR"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_pair = t[0] - '0'; }
     { const char *t = getenv("CLAIR_AMD_FUSED_FAULT"); if (t && atoll(t) > 0) e->fused_fault_at = atoll(t); }
-    { const char *t = getenv("CLAIR_AMD_ASYNC_STAGING"); if (t && t[0] == '0') e->async_staging = false; }
+    { const char *t = getenv("CLAIR_AMD_STAGING_THREADS"); if (t && atoi(t) >= 0 && atoi(t) <= 16) e->staging_threads = atoi(t); }
+    { const char *t = getenv("CLAIR_AMD_ASYNC_STAGING"); if (t && t[0] == '0') e->staging_threads = 0; }
     { const char *t = getenv("CLAIR_AMD_COPY_STREAMS"); if (t) e->copy_mode = !strcmp(t, "slot") ? 0 : !strcmp(t, "two") ? 1 : !strcmp(t, "lane") ? 2 : 3; }
     { const char *t = getenv("CLAIR_AMD_D2H"); if (t) e->d2h_kernel = !strcmp(t, "kernel"); }
     for (int i = 0; i < n_lanes; ++i) e->lanes.emplace_back(new Lane());
@@ -740,17 +744,17 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         clair_engine_destroy(e);
         return 1;
     }
-    if (e->async_staging) e->worker = std::thread(staging_worker, e);
+    for (int i = 0; i < e->staging_threads; ++i) e->workers.emplace_back(staging_worker, e);
     *out = e;
     return 0;
 }
 
 void clair_engine_destroy(clair_engine_t *e) {
     if (!e) return;
-    if (e->worker.joinable()) {
+    if (!e->workers.empty()) {
         { std::lock_guard<std::mutex> g(e->wmu); e->wstop = true; }
         e->wcv.notify_all();
-        e->worker.join();
+        for (auto &t : e->workers) t.join();
     }
     (void)hipSetDevice(e->device);
     for (auto &lp : e->lanes) if (lp->stream) (void)hipStreamSynchronize(lp->stream);

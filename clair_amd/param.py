@@ -10,3 +10,14 @@ matrixNum = 4               # shared/param.py:11
 predictBatchSize = 1000     # shared/param.py:16
 no_of_positions = 2 * flankingBaseNum + 1
 input_tensor_size = no_of_positions * matrixRow * matrixNum  # 1056
+
+
+def pipeline_slots():
+    """Batches the callers keep in flight at the engine's host boundary (clair_submit* / clair_wait).  Three compute lanes fill the
+    chip; twice as many slots keep every lane fed while its other batch is on the host link.  CLAIR_AMD_SLOTS
+    overrides (1 and 2 select the fused layer-2 launch of one- and two-lane handles)."""
+    import os
+    try:
+        return max(1, min(64, int(os.environ.get("CLAIR_AMD_SLOTS", "6"))))
+    except ValueError:
+        return 6

@@ -9,6 +9,7 @@ first eight bytes, through `gzip -fdc` like the text.  Counts are the RAW pileup
     file   := MAGIC record*
     record := pos i64 | seq_len u8 | seq 33 bytes | ctg_len u8 | ctg 37 bytes | counts int16[33][8][4]
 """
+import os
 import sys
 
 import numpy as np
@@ -171,38 +172,109 @@ def _fill(stream, view):
     return have
 
 
-def read_batches_into(stream, batch_size, pool):
+def _records_of(buf, have, want):
+    """The batch that `have` bytes at the head of `buf` hold -> (infos, counts view, records kept) or None for an empty one."""
+    take = have // RECORD.itemsize * RECORD.itemsize
+    if take < have:
+        raise ValueError("truncated binary tensor record (%d trailing bytes)" % (have - take))
+    if take == 0:
+        return None
+    rec = buf[:take].view(RECORD)
+    seq_bytes = np.frombuffer(np.ascontiguousarray(rec["seq"]).tobytes(), dtype=np.uint8).reshape(len(rec), 33)
+    keep = (rec["seq_len"] > 16) & _IUPAC_TABLE[seq_bytes[:, 16]]
+    if not keep.all():
+        rec = rec[keep]                           # (a copy outside the buffer: that batch goes through the staging path)
+    if len(rec) == 0:
+        return (None, None, 0)
+    return InfoTable(rec["ctg"].copy(), rec["ctg_len"].copy(), rec["pos"].copy(), rec["seq"].copy(), rec["seq_len"].copy()), rec["counts"], len(rec)
+
+
+def _regular_file(stream):
+    import stat
+    try:
+        fd = stream.fileno()
+        return fd if stat.S_ISREG(os.fstat(fd).st_mode) and hasattr(os, "preadv") else None
+    except (AttributeError, OSError, ValueError):
+        return None
+
+
+def read_batches_into(stream, batch_size, pool, readers=3):
     """read_batches(with_input=False) that reads every batch of records straight into a buffer of `pool` (BufferPool) -- no copy of the
     batch is made on the host at all -- and yields (None, infos, counts view, buffer); the consumer gives the buffer back
-    (pool.put) once the GPU has taken the batch.  Same batching rules, same progress lines."""
+    (pool.put) once the GPU has taken the batch.  Same batching rules, same progress lines.
+
+    A regular file is read by `readers` threads at once, batch k at its own offset (records are fixed-size): one thread moves 9 MB out of
+    the page cache in ~0.7 ms, which alone caps a 4096-batch pipeline at 6 M candidates/s (round 4).  Batches are yielded in file order."""
     processed = 0
     want = batch_size * RECORD.itemsize
-    while True:
+    fd = _regular_file(stream) if readers > 1 else None
+    if fd is None:
+        while True:
+            try:
+                buf = pool.get()
+            except BufferPool.Closed:
+                return
+            have = _fill(stream, memoryview(buf)[:want])
+            got = _records_of(buf, have, want)
+            if got is None:
+                pool.put(buf)
+                return
+            infos, counts, n = got
+            processed += n
+            print("Processed %d tensors" % processed, file=sys.stderr)
+            if n == 0:
+                pool.put(buf)
+            else:
+                yield None, infos, counts, buf
+            if have < want:
+                return
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    start = stream.tell()
+    size = os.fstat(fd).st_size
+    n_batches = max(0, (size - start + want - 1) // want)
+
+    def load(k):
+        buf = pool.get()                          # (raises BufferPool.Closed when the consumer has given up)
+        view, have, off = memoryview(buf)[:want], 0, start + k * want
+        while have < want:
+            got = os.preadv(fd, [view[have:]], off + have)
+            if got <= 0:
+                break
+            have += got
         try:
-            buf = pool.get()
-        except BufferPool.Closed:
-            return
-        have = _fill(stream, memoryview(buf)[:want])
-        take = have // RECORD.itemsize * RECORD.itemsize
-        if take < have:
-            raise ValueError("truncated binary tensor record (%d trailing bytes)" % (have - take))
-        if take == 0:
+            return buf, have, _records_of(buf, have, want)
+        except Exception:
             pool.put(buf)
-            return
-        rec = buf[:take].view(RECORD)
-        seq_bytes = np.frombuffer(np.ascontiguousarray(rec["seq"]).tobytes(), dtype=np.uint8).reshape(len(rec), 33)
-        keep = (rec["seq_len"] > 16) & _IUPAC_TABLE[seq_bytes[:, 16]]
-        if not keep.all():
-            rec = rec[keep]                           # (a copy outside the buffer: that batch goes through the staging path)
-        n = len(rec)
-        processed += n
-        print("Processed %d tensors" % processed, file=sys.stderr)
-        if n == 0:
-            pool.put(buf)
-        else:
-            yield None, InfoTable(rec["ctg"].copy(), rec["ctg_len"].copy(), rec["pos"].copy(), rec["seq"].copy(), rec["seq_len"].copy()), rec["counts"], buf
-        if have < want:
-            return
+            raise
+
+    with ThreadPoolExecutor(max_workers=readers) as ex:
+        ahead, k = [], 0
+        try:
+            while k < n_batches or ahead:
+                while k < n_batches and len(ahead) < readers:
+                    ahead.append(ex.submit(load, k))
+                    k += 1
+                try:
+                    buf, have, got = ahead.pop(0).result()
+                except BufferPool.Closed:
+                    return
+                if got is None:
+                    pool.put(buf)
+                    return
+                infos, counts, n = got
+                processed += n
+                print("Processed %d tensors" % processed, file=sys.stderr)
+                if n == 0:
+                    pool.put(buf)
+                else:
+                    yield None, infos, counts, buf
+        finally:
+            for f in ahead:                       # a consumer that stopped early: the buffers in flight go back
+                try:
+                    pool.put(f.result()[0])
+                except Exception:
+                    pass
 
 
 def read_batches(stream, batch_size, first=b"", with_input=True):

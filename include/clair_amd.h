@@ -83,8 +83,12 @@ typedef struct clair_engine clair_engine_t;
 
 /* -- lifetime: Clair() + Clair.init()  (clair/model.py:58-192, 807-813) ------------------------
  * device: HIP device ordinal.  max_batch: largest n accepted by one predict/submit.
- * n_slots: number of independent pipeline slots (each has its own HIP stream and workspace);
- * 1 is enough for the synchronous predict. */
+ * n_slots: submits that may be pending at once (clair_submit* .. clair_wait); 1 is enough for the synchronous predict.  A slot owns the
+ * input and output buffers of its batch on both sides of the host link.  The forward passes themselves run on min(n_slots, 3) compute
+ * LANES (a HIP stream + the inter-kernel workspaces each: three passes in flight fill the chip), slot s on lane s % lanes; with twice as
+ * many slots as lanes a lane computes one batch of its slots while the copy engine brings the other one in, which is what takes the
+ * host-array boundary from half of the HBM-resident rate to within a few per cent of it.  clair_run_resident(slot)
+ * runs on the slot's lane. */
 int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t **out);
 /* Clair.close() / __del__  (clair/model.py:872-876, 1149-1152) */
 void clair_engine_destroy(clair_engine_t *e);
@@ -114,6 +118,9 @@ int clair_predict(clair_engine_t *e, const float *x, int n, float *gt21, float *
  *    x and the output arrays must stay valid until wait returns. */
 int clair_submit(clair_engine_t *e, int slot, const float *x, int n, float *gt21, float *genotype,
                  float *indel_len1, float *indel_len2);
+/* (A batch in pageable memory is copied to the slot's page-locked buffer, and its transfers and kernels are enqueued, by a staging
+ * thread of the engine: clair_submit returns at once and clair_wait reports a failure of that work.  This is why x must stay valid
+ * until clair_wait, as the reference's predict thread leaves loading and output to two others, clair/call_var.py:1331-1352.) */
 int clair_wait(clair_engine_t *e, int slot);
 /* The slot's own page-locked input buffer, [max_batch][33][8][4] float32.  A producer that writes its batch there and passes
  * this pointer as `x` to clair_submit gets a direct DMA transfer (pageable memory goes through the runtime's staging copies at

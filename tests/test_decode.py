@@ -368,3 +368,46 @@ def test_a_failing_stage_on_a_helper_thread_fails_call_variants():
 
     with pytest.raises(ValueError):
         cvar.call_variants(types.SimpleNamespace(tensor_fn=None), Model(), BadDecoder(), Sink(), 2, generator=two_batches())
+
+
+def test_binary_records_read_by_several_threads_are_the_single_readers_batches(tmp_path):
+    """tensor_binary.read_batches_into on a regular file: batch k is read at its own offset by one of `readers` threads (round 4: one
+    thread copying out of the page cache capped the 4096-batch pipeline); same batches, same order, ragged tail, dropped centres, and
+    a consumer that stops early gets its buffers back."""
+    import io
+    from clair_amd import synth, tensor_binary as tb
+    raw, infos = synth.synthetic_candidates(1030, "ont", seed=5)
+    seqs = [i[2] for i in infos]
+    seqs[7] = seqs[7][:16] + "-" + seqs[7][17:]           # not an IUPAC centre: dropped from its batch
+    blob = tb.MAGIC + tb.pack_records(infos[0][0], [int(i[1]) for i in infos], seqs, raw)
+    path = tmp_path / "t.bin"
+    path.write_bytes(blob)
+
+    def batches(readers, stop_after=None):
+        pool = tb.BufferPool([np.zeros(128 * tb.RECORD.itemsize, np.uint8) for _ in range(6)])
+        out = []
+        with open(path, "rb", buffering=1 << 16) as f:
+            assert f.read(len(tb.MAGIC)) == tb.MAGIC
+            gen = tb.read_batches_into(f, 128, pool, readers=readers)
+            for _, inf, counts, buf in gen:
+                out.append((inf.rows(), np.array(counts)))
+                pool.put(buf)
+                if stop_after and len(out) == stop_after:
+                    gen.close()
+                    break
+        return out, pool
+
+    one, _ = batches(1)
+    three, pool = batches(3)
+    assert [len(b[0]) for b in one] == [127] + [128] * 7 + [6]
+    assert len(one) == len(three) and all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(one, three))
+    assert pool._q.qsize() == 6
+    part, pool = batches(3, stop_after=2)
+    assert len(part) == 2 and pool._q.qsize() == 6            # the reads in flight gave their buffers back
+    # a pipe (no offsets to read at) takes the sequential path
+    pool = tb.BufferPool([np.zeros(128 * tb.RECORD.itemsize, np.uint8) for _ in range(3)])
+    piped = []
+    for _, inf, counts, buf in tb.read_batches_into(io.BytesIO(blob[len(tb.MAGIC):]), 128, pool, readers=3):
+        piped.append((inf.rows(), np.array(counts)))
+        pool.put(buf)
+    assert len(piped) == len(one) and all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(one, piped))

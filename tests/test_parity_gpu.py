@@ -487,6 +487,21 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
     assert d["gt_concordance"]["gt_identical"] is True and d["parity_max_abs_err"] < 1e-5
+    # round 4: the same steps through the reference's own boundary (host arrays in and out), timed like `value`; the whole candidate set of
+    # the config; clock and power of the GPU during each leg
+    b = d["boundary"]
+    assert b["bit_identical_to_resident"] is True and b["slots"] == 6 and b["lanes"] == 3 and b["float32"]["steps"] == 24
+    assert d["value_boundary"] == b["float32"]["value"] and d["value_boundary_int16"] == b["int16"]["value"]
+    assert abs(d["value_boundary"] - 24 * d["config"]["batch"] / (b["float32"]["ms_per_step"] * 24e-3)) < 0.01 * d["value_boundary"]
+    assert d["value_boundary"] > 0.5 * d["value"] and d["value_boundary_int16"] > 0.5 * d["value"]      # 24 steps: the pipeline's fill is a sixth of the leg
+    assert d["full_config"]["steps"] == 196 and d["full_config"]["candidates_per_rank"] == 200704
+    assert 0.8 * d["value"] < d["value_full_config"] < 1.25 * d["value"]
+    assert d["value_boundary_full_config"] == b["float32_full"]["value"] > 0.75 * d["value_full_config"]
+    state = d["gpu_state"]
+    for leg in ("value", "value_full_config", "value_boundary", "value_boundary_int16", "value_boundary_float32_full", "value_boundary_int16_full"):
+        assert set(state[leg]) == {"sclk_mhz", "power_w", "samples"}, leg
+    assert state["value_full_config"]["sclk_mhz"] is None or 500 < state["value_full_config"]["sclk_mhz"] < 3000
+    assert state["value_full_config"]["power_w"] is None or 100 < state["value_full_config"]["power_w"] < 2000
 
 
 def test_bench_strong_scaling_counts_one_ranks_share_of_the_whole_genome_set():

@@ -257,7 +257,15 @@ BENCH_WORKER = textwrap.dedent("""
     class FakeEngine(object):
         '''Stands in for the HIP engine on a GPU-less host: the oracle's outputs, made-up kernel times.'''
         def __init__(self, device=0, max_batch=1024, n_slots=1, lib_path=None):
-            self.max_batch, self.x, self.w, self.runs = max_batch, None, None, 0
+            self.max_batch, self.x, self.w, self.runs, self.held = max_batch, None, None, 0, {}
+        def submit(self, slot, x):
+            assert slot not in self.held
+            self.held[slot] = c_oracle.forward(self.w, np.asarray(x, np.float32))
+        def submit_counts(self, slot, counts):
+            x = np.asarray(counts).astype(np.float32)
+            x[..., 1:] -= x[..., 0:1]
+            self.submit(slot, x)
+        def wait(self, slot): return self.held.pop(slot)
         def load_weights(self, w): self.w = w
         def dataset_alloc(self, n): return 1, 2
         def dataset_upload(self, xd, first, x): self.x = np.array(x)
@@ -280,7 +288,7 @@ BENCH_WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("args,total", [(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline"], 2 * 6 * 64),
+@pytest.mark.parametrize("args,total", [(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline", "--full-candidates", "640"], 2 * 6 * 64),
                                         (["--gpus", "2", "--scaling", "strong", "--candidates", "1000", "--batch", "64", "--warmup", "1", "--no-cpu-baseline"], 1000)])
 def test_bench_two_rank_flow_with_a_stand_in_engine(tmp_path, args, total):
     """bench.py's multi-rank bookkeeping on two CPU ranks (the engine replaced by the oracle, the sockets as transport): one JSON line from
@@ -304,3 +312,13 @@ def test_bench_two_rank_flow_with_a_stand_in_engine(tmp_path, args, total):
     assert d["scaling"] == ("strong" if "strong" in args else "weak") and d["parity_max_abs_err"] == 0.0
     assert d["value"] > 0 and d["steps"] == max(r["steps"] for r in d["per_rank"])          # the slowest rank's step count; times are fake here
     assert "cpu_baseline" not in d and d["roofline"]["kernel"].split()[0] == "proj2"
+    # the legs behind the contract's timed region: the host-array boundary (timed like `value`), the whole candidate set, the GPU's state
+    b = d["boundary"]
+    assert d["value_boundary"] == b["float32"]["value"] > 0 and d["value_boundary_int16"] == b["int16"]["value"] > 0 and b["bit_identical_to_resident"] is True
+    assert b["slots"] == 6 and b["float32"]["steps"] == d["steps"] and b["float32"]["h2d_bytes_per_candidate"] == 4224 and b["int16"]["h2d_bytes_per_candidate"] == 2112
+    if "strong" in args:
+        assert d["value_full_config"] is None and d["full_config"] is None and "float32_full" not in b
+    else:
+        assert d["full_config"]["steps"] == 10 and d["value_full_config"] > 0 and d["value_boundary_full_config"] == b["float32_full"]["value"] > 0
+        assert "value_full_config" in d["gpu_state"] and "value_boundary_float32_full" in d["gpu_state"]
+    assert set(d["gpu_state"]["value"]) == {"sclk_mhz", "power_w", "samples"} and "value_boundary" in d["gpu_state"]
