@@ -68,8 +68,8 @@ DESIGN_BYTES = {
     "proj2": 33 * 256 * 4 + 33 * 1024 * 4,
     "lstm2": 33 * 1024 * 4 + 33 * 256 * 4,
     "l3": 0,
-    "l4": 33 * 256 * 4 + 32 * 192 * 4,
-    "tail": 32 * 192 * 4 + 90 * 4,
+    "l4": 33 * 256 * 4 + 8 * 192 * 4,
+    "tail": 8 * 192 * 4 + 90 * 4,
 }
 # HBM bytes per launch come from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py traffic --json writes profiles/pmc_traffic.json).  Not collected
@@ -276,6 +276,7 @@ def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq,
         for s in sorted(pending, key=pending.get):
             last[:] = [pending.pop(s), eng.wait(s)]
 
+    phases = []                        # forward passes launched, in order (tools/rocpd_summary.py --phases-from)
     out = {"slots": slots, "lanes": min(slots, 3), "steps": steps,
            "interface": "pageable NumPy batches [n,33,8,4] in, four fresh NumPy arrays per batch out (clair_submit / clair_submit_counts + clair_wait); "
                         "staging copy and enqueue on the engine's staging threads, H2D on one copy stream, results written to page-locked host "
@@ -284,6 +285,7 @@ def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq,
     # while this handle was being set up
     loop(max(0, WARM_STEPS - args.warmup), False)
     drain()
+    phases.append(["boundary handle: device warm-up", max(0, WARM_STEPS - args.warmup)])
     for name, counts, k in (("float32", False, steps), ("int16", True, steps), ("float32_full", False, full_steps), ("int16_full", True, full_steps)):
         if k <= 0:
             continue
@@ -292,12 +294,15 @@ def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq,
         secs = group.max_float(timed("value_boundary" + ("" if name == "float32" else "_" + name), lambda: loop(k, counts), drain))
         out[name] = {"value": round(world * k * batch / secs, 1), "steps": k, "ms_per_step": round(secs / k * 1e3, 4),
                      "h2d_bytes_per_candidate": 2112 if counts else 4224}
+        phases += [["boundary %s: warm-up" % name, args.warmup], ["boundary %s: timed (value_boundary%s)" % (name, "" if name == "float32" else "_" + name), k]]
     # the last batch of the last leg against the resident path on the same candidates
     i = (last[0] or 0) % nuniq
     eng_resident.run_resident(0, xd, od, i * batch, batch)
     eng_resident.sync()
     ref = _capi.split_outputs(eng_resident.dataset_download(od, i * batch, batch))
     out["bit_identical_to_resident"] = bool(last[1] is not None and all(np.array_equal(a, b) for a, b in zip(last[1], ref)))
+    phases.append(["boundary: the resident launch its last batch is compared with", 1])
+    out["launch_phases"] = phases
     eng.close()
     return out
 
@@ -354,6 +359,7 @@ def run_ranked(args, group, json_fd):
     eng.sync()
     run(args.warmup)
     eng.sync()
+    phases = [["device warm-up + --warmup", device_warm + args.warmup]]    # forward passes launched, in order (tools/rocpd_summary.py --phases-from)
     sampler = GpuStateSampler(local_rank) if rank == 0 else None
     legs = {}                                   # name -> (CLOCK_MONOTONIC ns at both ends) for gpu_state
 
@@ -372,6 +378,7 @@ def run_ranked(args, group, json_fd):
     # Timed region: the plain hot path, no instrumentation.
     eng.timing_enable(False)
     mine_s = timed("value", lambda: run(steps, ragged_last=True), eng.sync)
+    phases.append(["timed (value), %d lanes in flight" % streams, steps])
     elapsed = group.max_float(mine_s)          # the slowest rank defines the job time
     per_rank_s = group.gather_floats(mine_s)
     per_rank_steps = [int(round(v)) for v in group.gather_floats(steps)]
@@ -383,6 +390,7 @@ def run_ranked(args, group, json_fd):
     if args.full_candidates > 0 and args.scaling == "weak":
         full_steps = (args.full_candidates + batch - 1) // batch
         full_s = group.max_float(timed("value_full_config", lambda: run(full_steps), eng.sync))
+        phases.append(["whole candidate set (value_full_config)", full_steps])
         full = {"steps": full_steps, "candidates_per_rank": full_steps * batch, "seconds": round(full_s, 6), "value": round(world * full_steps * batch / full_s, 1),
                 "ms_per_step": round(full_s / full_steps * 1e3, 4)}
 
@@ -390,6 +398,7 @@ def run_ranked(args, group, json_fd):
     boundary = None
     if args.boundary_slots > 0:
         boundary = boundary_legs(args, group, eng, local_rank, w, x, xd, od, batch, nuniq, steps, timed, full["steps"] if full else 0)
+        phases += boundary.pop("launch_phases")
 
     # Per-kernel tables, outside the timed region.  (a) the same loop, same streams, every kernel bracketed by HIP events (ten marker
     # packets per pass); (b) the same on ONE stream, so that a kernel's HIP-event duration is its own ("alone").
@@ -399,12 +408,14 @@ def run_ranked(args, group, json_fd):
     run(steps)
     eng.sync()
     times = eng.kernel_times()
+    phases.append(["HIP events on every kernel, %d lanes in flight" % streams, steps])
     iso_steps = min(steps, 32)
     eng.timing_reset()
     for i in range(iso_steps):
         eng.run_resident(0, xd, od, (i % nuniq) * batch, batch)
     eng.sync()
     times_iso = eng.kernel_times()
+    phases.append(["alone on one stream (alone_ms)", iso_steps])
     wgs = eng.kernel_workgroups(batch)
     active = [k for k in _capi.KERNEL_NAMES if times_iso[k][1]]
     cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in active}
@@ -419,6 +430,7 @@ def run_ranked(args, group, json_fd):
     run(steps)
     eng.sync()
     elapsed_dom = time.perf_counter() - t1
+    phases.append(["HIP events on the dominant kernel only (roofline.kernel_ms)", steps])
     dom_ms, dom_cnt = eng.kernel_times()[dominant]
     eng.timing_enable(False)
 
@@ -430,6 +442,7 @@ def run_ranked(args, group, json_fd):
         ns = min(1024, batch * nuniq)
         eng.run_resident(0, xd, od, 0, min(ns, batch))
         eng.sync()
+        phases.append(["parity check against the oracle", 1])
         ns = min(ns, batch)
         got = _capi.split_outputs(eng.dataset_download(od, 0, ns))
         want = c_oracle.forward(w, x[:ns])
@@ -534,6 +547,7 @@ def run_ranked(args, group, json_fd):
             "boundary": boundary,
             "full_config": full,
             "gpu_state": gpu_state,
+            "launch_phases": phases,
             "roofline": roof,
             "roofline_path": {"achieved": round(path_tf, 2), "unit": "TFLOP/s per GPU (algorithmic, 40 386 432 FLOP / candidate)",
                               "frac_of_f16_mfma": round(path_tf / PEAK_F16_MFMA_TFLOPS, 4),

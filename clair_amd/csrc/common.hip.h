@@ -17,7 +17,7 @@ constexpr int L3_OUT = 7680;   // 30*256, flat index u*256+c (clair/model.py:474
 constexpr int L4_UNITS = 192;  // clair/model.py:82
 constexpr int L5_UNITS = 96;   // clair/model.py:84-91
 constexpr int OUT_FLOATS = 90; // 21 + 3 + 33 + 33
-constexpr int L4_SPLITS = 32;  // split-K factor of the 7680->192 GEMM: one partial per group of 8 LSTM2 features (dense.hip.h)
+constexpr int L4_SPLITS = 8;   // split-K factor of the 7680->192 GEMM: one partial per 32 LSTM2 features = four channel groups of 8 (dense.hip.h)
 
 // exp via v_exp_f32 (2^x); relative error ~1 ulp, enough for the 2e-6 probability tolerance.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -53,7 +53,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 selu_scaled2(f32x2 x, float k) {
     constexpr float alpha = 1.6732632423543772848170429916717f;
     constexpr float scale = 1.0507009873554804934193349852946f;
-    const f32x2 xm = {fminf(x[0], 0.0f), fminf(x[1], 0.0f)}, xp = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+    const f32x2 xm = {fminf(x[0], 0.0f), fminf(x[1], 0.0f)};
+    const f32x2 xp = x - xm;        // max(x, 0) exactly (one of the two is x, the other 0): one packed subtraction instead of two v_max
     f32x2 p = xm * (1.0f / 720.0f) + (1.0f / 120.0f);
     p = p * xm + (1.0f / 24.0f);
     p = p * xm + (1.0f / 6.0f);

@@ -51,7 +51,7 @@ struct Lane {
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
     unsigned short *a1 = nullptr;   // [2][33][max_pad][256] fp16: LSTM1 output as its 2-way split
     float *a2 = nullptr;      // LSTM2 output, channel-group-major: [32 groups of 8 features][33][n_pad][8]
-    float *l4part = nullptr;  // [32 groups][max_pad rounded to 64][192] split-K partials in the accumulator layout (dense.hip.h)
+    float *l4part = nullptr;  // [8 splits][max_pad rounded to 64][192] split-K partials in the accumulator layout (dense.hip.h)
     unsigned *fuse_flags = nullptr;   // lstm2_fused.hip.h: [2][max_pad/32][33][8] ticket words, one error word, one claim word per workgroup
     unsigned fuse_ticket = 0;         // ticket of the last fused forward pass on this lane
     int last_n_pad = 0;
@@ -143,7 +143,9 @@ struct clair_engine {
     unsigned short *wh1s = nullptr, *wh2s = nullptr, *wx1s = nullptr, *w4s = nullptr, *w3s = nullptr;   // fp16 split MFMA fragment images (lstm32.hip.h, dense.hip.h)
     unsigned short *wx2s = nullptr;   // [8][2][1024][32] fp16 planes of the gate-scaled Wx2
     float *b4 = nullptr;
-    float *w5f = nullptr, *b5 = nullptr, *whf = nullptr, *bhf = nullptr;
+    unsigned short *w5s = nullptr, *whs = nullptr;   // fp16 split A fragments of the L5 branches and the heads (dense.hip.h: tail_kernel)
+    float *b5 = nullptr, *bh = nullptr;
+    int w5_shift[4] = {0, 0, 0, 0}, wh_shift[4] = {0, 0, 0, 0};   // per-branch power-of-two image shifts of those tensors
     double ms_sum[CLAIR_K_COUNT] = {0};
     int64_t launches[CLAIR_K_COUNT] = {0};
 };
@@ -358,15 +360,19 @@ int enqueue_forward(clair_engine *e, Lane &s, const float *x_dev, float *out_dev
             }
         }
     }
-    {   // L3 (slice dense) + L4 (split-K over the 16 channel groups), fused
+    {   // L3 (slice dense) + L4 (split-K 8: a workgroup walks the four channel groups of its split), fused
         KernelTimer kt(e, s, CLAIR_K_L4);
         L3L4Args a{s.a2, e->w3s, e->w4s, s.l4part, n_pad, std::ldexp(1.0f, -e->w3_shift), e->tap_l3 ? s.zx : nullptr,
                    e->l34_stamps ? (unsigned long long *)s.zx : nullptr};   // zx is dead by now
-        hipLaunchKernelGGL(l3l4_kernel, dim3(((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS), dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL(l3l4_kernel, dim3(((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS), dim3(L34_THREADS), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
-        TailArgs a{s.l4part, e->b4, e->w5f, e->b5, e->whf, e->bhf, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE};
+        TailArgs a{s.l4part, e->b4, e->w5s, e->b5, e->whs, e->bh, out_dev, n_pad, n, std::ldexp(1.0f, -e->w4_shift) / L34_ACT_SCALE, {}, {}};
+        for (int k = 0; k < 4; ++k) {
+            a.l5_scale[k] = std::ldexp(1.0f, -e->w5_shift[k]) / TAIL_ACT_SCALE;
+            a.head_scale[k] = std::ldexp(1.0f, -e->wh_shift[k]) / TAIL_ACT_SCALE;
+        }
         hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
@@ -763,8 +769,9 @@ void clair_engine_destroy(clair_engine_t *e) {
     for (auto st : e->copy_streams) (void)hipStreamDestroy(st);
     for (auto &lp : e->lanes) free_lane(*lp);
     for (auto &b : e->pinned) (void)hipHostFree(b.first);
-    float *w[] = {e->bx1, e->bx2, e->b4, e->w5f, e->b5, e->whf, e->bhf};
+    float *w[] = {e->bx1, e->bx2, e->b4, e->b5, e->bh};
     for (float *p : w) (void)hipFree(p);
+    (void)hipFree(e->w5s); (void)hipFree(e->whs);
     (void)hipFree(e->wx2s); (void)hipFree(e->wh1s); (void)hipFree(e->wh2s); (void)hipFree(e->wx1s); (void)hipFree(e->w4s); (void)hipFree(e->w3s);
     delete e;
 }
@@ -785,7 +792,7 @@ int clair_finalize_weights(clair_engine_t *e) {
         if ((int64_t)e->host_tensors[i].size() != TENSOR_COUNT[i]) return fail(e, "tensor %d has not been set", i);
     HIP_TRY(e, hipSetDevice(e->device));
     if (quiesce(e)) return 1;
-    float **dev[] = {&e->bx1, &e->bx2, &e->b4, &e->w5f, &e->b5, &e->whf, &e->bhf};
+    float **dev[] = {&e->bx1, &e->bx2, &e->b4, &e->b5, &e->bh};
     for (float **p : dev) { (void)hipFree(*p); *p = nullptr; }
     auto &T = e->host_tensors;
     if (upload(e, &e->bx1, pack_bias32(T[1], T[3])) || upload(e, &e->bx2, pack_bias32(T[5], T[7]))) return 1;
@@ -849,8 +856,8 @@ int clair_finalize_weights(clair_engine_t *e) {
         for (float v : T[10]) w4max = std::max(w4max, std::fabs(v));
         e->w4_shift = image_shift(w4max);
         const float w4_pow2 = std::ldexp(1.0f, e->w4_shift);
-        std::vector<unsigned short> w4s((size_t)L4_SPLITS * L34_KS * 6 * 2 * 64 * 8);
-        for (int cg = 0; cg < L4_SPLITS; ++cg)
+        std::vector<unsigned short> w4s((size_t)L34_GROUPS * L34_KS * 6 * 2 * 64 * 8);
+        for (int cg = 0; cg < L34_GROUPS; ++cg)
             for (int ks = 0; ks < L34_KS; ++ks)
                 for (int nb = 0; nb < 6; ++nb)
                     for (int lane = 0; lane < 64; ++lane)
@@ -864,28 +871,44 @@ int clair_finalize_weights(clair_engine_t *e) {
                         }
         if (upload16(e, &e->w4s, w4s) || upload(e, &e->b4, T[11])) return 1;
     }
-    {   // tail B fragments (dense.hip.h: tail_kernel)
+    {   // tail A fragments (dense.hip.h: tail_kernel): W5_k^T and Wh_k^T as fp16 split, each tensor shifted by its own power of two
         const int sizes[4] = {21, 3, 33, 33};
-        std::vector<float> w5f((size_t)4 * 12 * 6 * 64 * 4), whf((size_t)4 * 6 * 3 * 64 * 4, 0.0f), bhf(4 * 48, 0.0f);
+        std::vector<unsigned short> w5s((size_t)4 * 12 * 3 * 2 * 64 * 8), whs((size_t)4 * 6 * 2 * 2 * 64 * 8, 0);
+        std::vector<float> bh(4 * 64, 0.0f);
         for (int k5 = 0; k5 < 4; ++k5) {
-            for (int k4 = 0; k4 < 12; ++k4)
-                for (int nb = 0; nb < 6; ++nb)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int k = (lane >> 4) * 48 + k4 * 4 + j, col = nb * 16 + (lane & 15);
-                            w5f[((((size_t)k5 * 12 + k4) * 6 + nb) * 64 + lane) * 4 + j] = T[12][((size_t)k5 * L4_UNITS + k) * L5_UNITS + col];
-                        }
-            for (int k4 = 0; k4 < 6; ++k4)
+            const float *W5 = T[12].data() + (size_t)k5 * L4_UNITS * L5_UNITS;
+            const std::vector<float> &Wh = T[14 + 2 * k5];
+            float m5 = 0.0f, mh = 0.0f;
+            for (int i = 0; i < L4_UNITS * L5_UNITS; ++i) m5 = std::max(m5, std::fabs(W5[i]));
+            for (float v : Wh) mh = std::max(mh, std::fabs(v));
+            e->w5_shift[k5] = image_shift(m5);
+            e->wh_shift[k5] = image_shift(mh);
+            const float p5 = std::ldexp(1.0f, e->w5_shift[k5]), ph = std::ldexp(1.0f, e->wh_shift[k5]);
+            for (int ks = 0; ks < 12; ++ks)
                 for (int nb = 0; nb < 3; ++nb)
                     for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int k = (lane >> 4) * 24 + k4 * 4 + j, col = nb * 16 + (lane & 15);
-                            if (col < sizes[k5])
-                                whf[((((size_t)k5 * 6 + k4) * 3 + nb) * 64 + lane) * 4 + j] = T[14 + 2 * k5][(size_t)k * sizes[k5] + col];
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * ks + 8 * (lane >> 5) + j, n = nb * 32 + (lane & 31);
+                            unsigned short hi, lo;
+                            split2_host(W5[(size_t)k * L5_UNITS + n] * p5, hi, lo);
+                            const size_t base = ((((((size_t)k5 * 12 + ks) * 3 + nb) * 2) * 64) + lane) * 8 + j;
+                            w5s[base] = hi;
+                            w5s[base + 64 * 8] = lo;
                         }
-            for (int j = 0; j < sizes[k5]; ++j) bhf[k5 * 48 + j] = T[15 + 2 * k5][j];
+            for (int ks = 0; ks < 6; ++ks)
+                for (int nb = 0; nb < 2; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * ks + 8 * (lane >> 5) + j, c = nb * 32 + (lane & 31);
+                            unsigned short hi = 0, lo = 0;
+                            if (c < sizes[k5]) split2_host(Wh[(size_t)k * sizes[k5] + c] * ph, hi, lo);
+                            const size_t base = ((((((size_t)k5 * 6 + ks) * 2 + nb) * 2) * 64) + lane) * 8 + j;
+                            whs[base] = hi;
+                            whs[base + 64 * 8] = lo;
+                        }
+            for (int j = 0; j < sizes[k5]; ++j) bh[k5 * 64 + j] = T[15 + 2 * k5][j];
         }
-        if (upload(e, &e->w5f, w5f) || upload(e, &e->b5, T[13]) || upload(e, &e->whf, whf) || upload(e, &e->bhf, bhf)) return 1;
+        if (upload16(e, &e->w5s, w5s) || upload16(e, &e->whs, whs) || upload(e, &e->b5, T[13]) || upload(e, &e->bh, bh)) return 1;
     }
     e->weights_ready = true;
     return 0;
@@ -1193,8 +1216,8 @@ int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_
         case 4: if (!e->tap_l3) return fail(e, "clair_debug_read: tap 4 needs CLAIR_AMD_TAP_L3=1 at engine creation");
                 src = s.zx; avail = np * L3_OUT; break;
         case 5: if (!e->l34_stamps) return fail(e, "clair_debug_read: tap 5 needs CLAIR_AMD_L34_STAMPS=1 at engine creation");
-                src = s.zx; avail = ((np + L34_CAND - 1) / L34_CAND) * L4_SPLITS * 4 * 16 * 2; break;   // uint64 pairs of floats
-        case 3: {   // split-K partials live in the accumulator layout (dense.hip.h): hand them back as [32][n_pad][192] in W4's own units
+                src = s.zx; avail = ((np + L34_CAND - 1) / L34_CAND) * L4_SPLITS * 8 * 16 * 2; break;   // uint64 pairs of floats
+        case 3: {   // split-K partials live in the accumulator layout (dense.hip.h): hand them back as [8 splits][n_pad][192] in W4's own units
             avail = (int64_t)L4_SPLITS * np * L4_UNITS;
             if (count > avail) return fail(e, "clair_debug_read: asked %lld floats, tap 3 holds %lld", (long long)count, (long long)avail);
             const int64_t nblk = (np + L34_CAND - 1) / L34_CAND;

@@ -200,7 +200,7 @@ int clair_engine_counter(clair_engine_t *e, int which, int64_t *value);
 
 /* -- layer taps for parity tests: copy an intermediate of the LAST forward pass run on `slot`
  *    to the host.  which: 1 = LSTM1 output [33,n_pad,256], 2 = LSTM2 output [33,n_pad,256],
- *    3 = split-K partials of the L4 product [32,n_pad,192], 4 = L3 output [n_pad,7680] (only when the engine was created
+ *    3 = split-K partials of the L4 product [8,n_pad,192], 4 = L3 output [n_pad,7680] (only when the engine was created
  *    with CLAIR_AMD_TAP_L3=1 in the environment)
  *    (L3/L4 activations only ever exist in LDS / split-K partials).  n_pad = n rounded up to 32. */
 int clair_debug_read(clair_engine_t *e, int slot, int which, float *host, int64_t count);

@@ -44,7 +44,7 @@ def test_layerwise_taps(engine, synth_weights):
     assert np.abs(a1 - inter["a1"]).max() <= ACT_TOL
     assert np.abs(a2 - inter["a2"]).max() <= ACT_TOL
     # L4: split-K partials (tap 3), reduced on the host in float64, bias + selu as clair/model.py:482-488
-    part = engine.debug_read(0, 3, (32, n_pad, 192)).astype(np.float64).sum(axis=0)[:n] + synth_weights["l4_bias"].astype(np.float64)
+    part = engine.debug_read(0, 3, (8, n_pad, 192)).astype(np.float64).sum(axis=0)[:n] + synth_weights["l4_bias"].astype(np.float64)
     l4 = 1.0507009873554804934193349852946 * np.where(part >= 0, part, 1.6732632423543772848170429916717 * np.expm1(part))
     assert np.abs(l4 - inter["l4"]).max() <= ACT_TOL
 

@@ -37,7 +37,7 @@ for rep in range(3):
     want, inter = c_oracle.forward(w, x, keep_intermediates=True)
     a1 = eng.debug_read(0, 1, (33, 1024, 256)).transpose(1, 0, 2)
     a2 = eng.debug_read(0, 2, (33, 1024, 256)).transpose(1, 0, 2)
-    part = eng.debug_read(0, 3, (32, 1024, 192)).astype(np.float64).sum(axis=0) + w["l4_bias"].astype(np.float64)
+    part = eng.debug_read(0, 3, (8, 1024, 192)).astype(np.float64).sum(axis=0) + w["l4_bias"].astype(np.float64)
     selu = lambda v: 1.0507009873554804934193349852946 * np.where(v >= 0, v, 1.6732632423543772848170429916717 * np.expm1(v))
     e4 = np.abs(selu(part) - inter["l4"])
     print("   l4 (selu of summed partials) err vs oracle: %.3g; mean %.3g; by cand%%32:" % (e4.max(), e4.mean()), " ".join("%.1e" % e4[c::32].max() for c in range(32)))
@@ -45,8 +45,8 @@ for rep in range(3):
     # per channel-group partial against a float64 evaluation of the same slice from the oracle's l3
     l3 = inter["l3"].astype(np.float64).reshape(1024, 30, 256)
     W4 = w["l4_kernel"].astype(np.float64).reshape(30, 256, 192)
-    raw = eng.debug_read(0, 3, (32, 1024, 192))
-    print("   partial err by channel group:", " ".join("%.1e" % np.abs(raw[g] - np.einsum("nuc,ucj->nj", l3[:, :, g * 8:(g + 1) * 8], W4[:, g * 8:(g + 1) * 8])).max() for g in range(32)))
+    raw = eng.debug_read(0, 3, (8, 1024, 192))
+    print("   partial err by split (32 channels):", " ".join("%.1e" % np.abs(raw[g] - np.einsum("nuc,ucj->nj", l3[:, :, g * 32:(g + 1) * 32], W4[:, g * 32:(g + 1) * 32])).max() for g in range(8)))
     l3g = eng.debug_read(0, 4, (1024, 7680))
     e3 = np.abs(l3g - inter["l3"])
     bad = np.argwhere(e3 > 2e-5)

@@ -15,7 +15,7 @@ for n in (64, 1024):
     n_pad = (n + 31) // 32 * 32
     a2 = eng.debug_read(0, 2, (33, n_pad, 256)).transpose(1, 0, 2)[:n]
     l3 = eng.debug_read(0, 4, (n_pad, 7680))[:n].reshape(n, 30, 256)
-    part = eng.debug_read(0, 3, (32, n_pad, 192))[:, :n]
+    part = eng.debug_read(0, 3, (8, n_pad, 192))[:, :n]
     o3 = inter["l3"].reshape(n, 30, 256)
     bad3 = ~np.isfinite(l3)
     print(n, "probs", [float(np.abs(g - t).max()) for g, t in zip(got, want)], "a2 %.2e" % np.abs(a2 - inter["a2"]).max(), flush=True)

@@ -84,10 +84,10 @@ def mfma():
     names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]
     c = {n: per_kernel(sys.argv[2], n, skip) for n in names}
     n_pad = (batch + 31) // 32 * 32
-    wgs = {"proj2": 32 * min(groups, (33 * n_pad // 64 + 7) // 8), "l4": (n_pad + 63) // 64 * 32, "tail": n_pad // 16, "lstm1": n_pad // 16,
+    wgs = {"proj2": 32 * min(groups, (33 * n_pad // 64 + 7) // 8), "l4": (n_pad + 63) // 64 * 8, "tail": n_pad // 32, "lstm1": n_pad // 16,
            "lstm2": (n_pad // 32 + 1) // 2 * 2 if n_pad >= 2048 else n_pad // 16}         # the two-tile kernel from 64 tiles on
     wgs["layer2_fused"] = 128 + 32 * ((n_pad // 64 + 7) // 8)      # 4 projection groups per XCD + the recurrent workgroups (lstm2_fused.hip.h)
-    per_cu = {"proj2": 1, "l4": 2, "tail": 1, "lstm1": 1, "lstm2": 1, "layer2_fused": 1}
+    per_cu = {"proj2": 1, "l4": 1, "tail": 1, "lstm1": 1, "lstm2": 1, "layer2_fused": 1}
     print("%-46s %14s %12s %8s %12s %12s %10s %10s" % ("kernel", "mfma_busy_cyc", "duration_cyc", "SIMDs", "mfma_util", "chip_util", "wait_any", "wait_inst"))
     for name in sorted(c["GRBM_GUI_ACTIVE"]):
         s = short(name)

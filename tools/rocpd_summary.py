@@ -10,7 +10,8 @@ output (profiles/rNN_kernel_resource_usage.txt) and prints ITS VGPR / AGPR / SGP
 kernel (warm-up launches) so the means line up with bench.py's timed region.  --phases W,K,I splits each kernel's dispatches the way bench.py issues
 them -- W warm-up launches, K timed steps (batches in flight on the slots), K steps with events around every kernel, I launches alone on
 one stream (`roofline.alone_kernel_ms`), K steps with HIP events around the dominant kernel only (`roofline.kernel_ms` is the dominant
-kernel's mean there), one launch of the parity check -- and prints the mean of each phase.
+kernel's mean there), one launch of the parity check -- and prints the mean of each phase.  --phases-from BENCH.json takes the split
+from the bench line itself (`launch_phases`: every leg of the run in launch order, bench.py) and prints one row per leg.
 """
 import sqlite3
 import sys
@@ -63,6 +64,8 @@ def main():
         for mangled, r in res.items():
             print("#   %-62s VGPRs %3d  AGPRs %3d  SGPRs %3d  scratch %d  LDS %6d  waves/SIMD %d"
                   % (mangled[:62], r.get("VGPRs", 0), r.get("AGPRs", 0), r.get("TotalSGPRs", 0), r.get("ScratchSize", 0), r.get("LDS", 0), r.get("Occupancy", 0)))
+    if "--phases-from" in sys.argv:
+        phases_from(per, sys.argv[sys.argv.index("--phases-from") + 1])
     if "--phases" in sys.argv:
         w, k, i = (int(v) for v in sys.argv[sys.argv.index("--phases") + 1].split(","))
         print("#\n# per phase of bench.py (mean us): %d warm-up launches | %d timed steps, batches in flight | %d steps, events on every kernel | "
@@ -75,6 +78,25 @@ def main():
             cut = [d[:w], d[w:w + k], d[w + k:w + 2 * k], d[w + 2 * k:w + 2 * k + i], d[w + 2 * k + i:w + 3 * k + i]]
             short = name if len(name) <= 58 else name[:55] + "..."
             print("%-58s %10.2f %10.2f %10.2f %10.2f %10.2f" % ((short,) + tuple(sum(c) / max(len(c), 1) for c in cut)))
+
+
+def phases_from(per, bench_json):
+    import json
+    line = [l for l in open(bench_json).read().splitlines() if l.lstrip().startswith("{")][-1]
+    phases = json.loads(line).get("launch_phases") or []
+    total = sum(n for _, n in phases)
+    cols = [(name, [(r[2] - r[1]) / 1e3 for r in rs]) for name, rs in per.items() if len(rs) == total]
+    print("#\n# per leg of bench.py, in launch order (mean us per launch; `launch_phases` of %s, %d forward passes)" % (bench_json.split("/")[-1], total))
+    if not cols:
+        print("# no kernel has exactly %d dispatches: %s" % (total, {k.split("(")[0][-24:]: len(v) for k, v in per.items()}))
+        return
+    short = [c[0].replace("clair::", "").replace("void ", "").split("(")[0][:22] for c in cols]
+    print("%-66s %6s " % ("leg", "passes") + " ".join("%22s" % s_ for s_ in short))
+    at = 0
+    for name, n in phases:
+        if n > 0:
+            print("%-66s %6d " % (name[:66], n) + " ".join("%22.2f" % (sum(c[1][at:at + n]) / n) for c in cols))
+        at += n
 
 
 if __name__ == "__main__":
