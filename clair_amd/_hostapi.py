@@ -11,6 +11,7 @@ SYMBOLS = ("clair_host_abi_version", "clair_host_last_error", "clair_host_thread
            "clair_host_decode_rows", "clair_host_decode_rows_ex", "clair_host_resolve_calls", "clair_host_format_calls", "clair_host_format_calls_records", "clair_host_centre_bytes",
            "clair_host_pileup_create", "clair_host_pileup_destroy", "clair_host_pileup_feed", "clair_host_pileup_finish",
            "clair_host_pileup_pending", "clair_host_pileup_take", "clair_host_pileup_take_text", "clair_host_pileup_stats",
+           "clair_host_pileup_set_order", "clair_host_pyset_order",
            "clair_host_evc_create", "clair_host_evc_destroy", "clair_host_evc_feed", "clair_host_evc_finish",
            "clair_host_evc_pending", "clair_host_evc_reads", "clair_host_evc_take", "clair_host_evc_take_text",
            "clair_host_sampack_create", "clair_host_sampack_destroy", "clair_host_sampack_feed", "clair_host_sampack_stats",
@@ -43,6 +44,8 @@ def load():
         lib.clair_host_pileup_create.argtypes = [ctypes.c_char_p, i64, i64, vp, i64, i32, i32, i32, i32, i64, i32, ctypes.POINTER(vp)]
         lib.clair_host_pileup_destroy.argtypes = [vp]
         lib.clair_host_pileup_destroy.restype = None
+        lib.clair_host_pileup_set_order.argtypes = [vp, i32]
+        lib.clair_host_pyset_order.argtypes = [vp, i64, vp, i64, ctypes.POINTER(i64)]
         lib.clair_host_pileup_feed.argtypes = [vp, vp, i64, i32, ctypes.POINTER(i64)]
         lib.clair_host_pileup_finish.argtypes = [vp]
         lib.clair_host_pileup_pending.argtypes = [vp]
@@ -289,11 +292,24 @@ def format_calls(calls, infos, show_reference, haploid_precision, haploid_sensit
     return (rows, status) if with_status else rows
 
 
+def pyset_order(ops):
+    """Iteration order of CPython's set after a history of operations (key >= 0: add, -(key + 1): remove), by the native restatement."""
+    lib = load()
+    ops = np.ascontiguousarray(ops, dtype=np.int64)
+    keys = np.empty(max(len(ops), 1), np.int64)
+    n = ctypes.c_int64(0)
+    if lib.clair_host_pyset_order(ops.ctypes.data, len(ops), keys.ctypes.data, len(keys), ctypes.byref(n)) != 0:
+        raise ValueError(lib.clair_host_last_error().decode())
+    return keys[:n.value].tolist()
+
+
 class PileupBuilder(object):
     """clair_host_pileup_*: the native twin of clair_amd.create_tensor.PileupBuilderPy (same constructor, same records)."""
 
     def __init__(self, ctg_name, reference_sequence, reference_start_0_based, candidates, consider_left_edge=True,
-                 dcov=250, min_coverage=0, min_mq=0, available_slots=5000000, force_general_path=False):
+                 dcov=250, min_coverage=0, min_mq=0, available_slots=5000000, force_general_path=False, set_order="ascending"):
+        if set_order not in ("ascending", "cpython"):
+            raise ValueError("set_order: 'ascending' or 'cpython'")
         self._lib = load()
         self.ctg = ctg_name
         ref = reference_sequence.encode("latin-1") if isinstance(reference_sequence, str) else bytes(reference_sequence)
@@ -306,6 +322,8 @@ class PileupBuilder(object):
             raise ValueError("pileup: " + self._lib.clair_host_last_error().decode())
         self._h = h
         self._text = None
+        if set_order == "cpython" and self._lib.clair_host_pileup_set_order(self._h, 1) != 0:
+            raise ValueError("pileup: " + self._lib.clair_host_last_error().decode())
 
     def close(self):
         if getattr(self, "_h", None):

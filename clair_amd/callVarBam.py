@@ -136,7 +136,7 @@ def tensor_batches(args, positions, batch_size, read_flank=(0, 0), progress=True
     if have_range:
         positions = positions[(positions >= args.ctgStart) & (positions <= args.ctgEnd)]
     builder = _hostapi.PileupBuilder(args.ctgName, seq, 0 if ref_start is None else ref_start - 1, positions,
-                                     consider_left_edge=not args.stop_consider_left_edge, dcov=args.dcov)
+                                     consider_left_edge=not args.stop_consider_left_edge, dcov=args.dcov, set_order=ct.set_order_of(getattr(args, "pypy", None)))
     region = "%s:%d-%d" % (args.ctgName, max(1, args.ctgStart - read_flank[0]), args.ctgEnd + read_flank[1]) if have_range else args.ctgName
     view = ct.subprocess_popen(view_command(args, region),
                                text=False)
@@ -751,7 +751,7 @@ def build_parser():
     add('--stop_consider_left_edge', action='store_true', help="open a window only for reads that cover its left edge")
     add('--dcov', type=int, default=250, help="at most this many reads per start position, default: %(default)s")
     add('--samtools', type=str, default="samtools", help="samtools executable")
-    add('--pypy', type=str, default="pypy3", help="ignored: no stage of this pipeline runs under pypy")
+    add('--pypy', type=str, default="pypy3", help="no stage of this pipeline runs under pypy; the name only selects whose set order the pileup follows where the reference's tuple budget binds (pypy*: insertion order, anything else: CPython's)")
     add('--threads', type=int, default=None, help="host threads, optional")
     add('--delay', type=int, default=10, help="ignored: there is no TensorFlow start-up thread storm to stagger")
     add('--debug', action='store_true', help="debug lines in the VCF body")

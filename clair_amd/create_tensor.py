@@ -25,6 +25,7 @@ CreateTensor.py:181, 303-309) is accounted for tuple by tuple, so the same bases
 documented liberty: when the budget runs out in the MIDDLE of one reference position, the reference serves the windows in
 CPython set-iteration order; here they are served in ascending centre order.
 """
+import os
 import shlex
 import subprocess
 import sys
@@ -50,7 +51,14 @@ class PileupBuilderPy(object):
     """Streaming restatement of OutputAlnTensor's main loop (CreateTensor.py:251-388) -- the checker for the native code."""
 
     def __init__(self, ctg_name, reference_sequence, reference_start_0_based, candidates, consider_left_edge=True,
-                 dcov=250, min_coverage=0, min_mq=0, available_slots=AVAILABLE_SLOTS):
+                 dcov=250, min_coverage=0, min_mq=0, available_slots=AVAILABLE_SLOTS, set_order="ascending"):
+        """set_order: the order in which a read base is offered to the windows open at its position, which only shows when the tuple budget
+        runs out in the middle of one base (CreateTensor.py:181, 296-310): "ascending" = the order the windows were opened in, what an
+        insertion-ordered set gives (PyPy, the interpreter clair/callVarBam.py starts the script with by default); "cpython" = the iteration order
+        of CPython's hash set -- here simply a real `set` driven by the reference's own sequence of add / remove calls."""
+        if set_order not in ("ascending", "cpython"):
+            raise ValueError("set_order: 'ascending' or 'cpython'")
+        self.set_order = set_order
         self.ctg = ctg_name
         self.ref = reference_sequence
         self.ref0 = reference_start_0_based
@@ -133,7 +141,16 @@ class PileupBuilderPy(object):
             if self.depth_cap >= self.dcov:
                 return
         active, end_to_centre = [], {}          # this read's open windows (ascending insertion), their closing positions
+        hashed = set() if self.set_order == "cpython" else None      # the reference's active_set itself: same adds, same removes, same order
         rp, qp, adv = pos, 0, 0
+
+        def offered():
+            return list(hashed) if hashed is not None else sorted(active)
+
+        def close_window(centre):
+            active.remove(centre)
+            if hashed is not None:
+                hashed.remove(centre)
 
         def open_windows():
             for end, centre in self.begin.get(rp, ()):
@@ -141,6 +158,8 @@ class PileupBuilderPy(object):
                     continue
                 end_to_centre[end] = centre
                 active.append(centre)
+                if hashed is not None:
+                    hashed.add(centre)
                 if centre not in self.windows:
                     self.windows[centre] = [np.zeros((N_POS, 8, 4), np.int32), 0, np.zeros(N_POS, np.int64)]
 
@@ -159,12 +178,12 @@ class PileupBuilderPy(object):
                         if qp >= len(seq):
                             raise PileupError("CIGAR %s walks past the end of SEQ (%d bases)" % (cigar, len(seq)))
                         rb, qb = self._ref_base(rp), seq[qp]
-                        for centre in sorted(active):
+                        for centre in offered():
                             if self.slots <= 0:
                                 break
                             self._count(centre, rp, 0, rb, qb, strand)
                     if rp in end_to_centre:
-                        active.remove(end_to_centre[rp])
+                        close_window(end_to_centre[rp])
                     rp += 1
                     qp += 1
             if ch == "I":
@@ -172,7 +191,7 @@ class PileupBuilderPy(object):
                     if active:
                         if qp >= len(seq):
                             raise PileupError("CIGAR %s walks past the end of SEQ (%d bases)" % (cigar, len(seq)))
-                        for centre in sorted(active):
+                        for centre in offered():
                             if self.slots <= 0:
                                 break
                             self._count(centre, rp, k, "-", seq[qp], strand)
@@ -181,13 +200,13 @@ class PileupBuilderPy(object):
                 for _ in range(adv):
                     if active:
                         rb = self._ref_base(rp)
-                        for centre in sorted(active):
+                        for centre in offered():
                             if self.slots <= 0:
                                 break
                             self._count(centre, rp, 0, rb, "-", strand)
                     open_windows()
                     if rp in end_to_centre:
-                        active.remove(end_to_centre[rp])
+                        close_window(end_to_centre[rp])
                     rp += 1
             adv = 0
 
@@ -264,6 +283,17 @@ def candidate_positions_from(handle, ctg_start, ctg_end):
     return out
 
 
+def set_order_of(interpreter=None):
+    """Which order the reference would have offered a base to its open windows in, given the interpreter its script runs under: PyPy's sets
+    keep insertion order ("ascending" here), CPython's iterate in hash order ("cpython").  CLAIR_AMD_SET_ORDER overrides; the default is the
+    reference pipeline's own default interpreter, pypy3 (clair/callVarBam.py: --pypy).  It only matters where the tuple budget binds."""
+    forced = os.environ.get("CLAIR_AMD_SET_ORDER")
+    if forced in ("ascending", "cpython"):
+        return forced
+    name = os.path.basename(interpreter or "pypy3")
+    return "ascending" if name.startswith("pypy") else "cpython"
+
+
 def make_builder(native, *args, **kwargs):
     if native:
         from . import _hostapi
@@ -318,7 +348,7 @@ def output_aln_tensor(args, native=True):
         can_proc.wait()
 
     builder = make_builder(native, args.ctgName, seq, ref0, cands, consider_left_edge=not args.stop_consider_left_edge,
-                           dcov=args.dcov, min_coverage=args.minCoverage, min_mq=args.minMQ)
+                           dcov=args.dcov, min_coverage=args.minCoverage, min_mq=args.minMQ, set_order=set_order_of())
     have_region = args.ctgStart is not None and args.ctgEnd is not None
     region = "%s:%d-%d" % (args.ctgName, args.ctgStart, args.ctgEnd) if have_region else args.ctgName
     is_native = not isinstance(builder, PileupBuilderPy)      # the native builder takes the bytes as they come

@@ -161,6 +161,170 @@ __global__ __launch_bounds__(256) void fe_tally_kernel(Region g, SlabView s) {
     }
 }
 
+// ---- pass 1 without a device-scope atomic per base (round 4) --------------------------------------------------
+// fe_tally_kernel above sends one 32-byte atomic request per aligned base to the memory side of the L2 (3.3 GB per 102 M bases, ten times
+// the text in plus tables out: the atomic unit is its bound).  Alignments come sorted by position, so the ~depth bases that land on one
+// position are found together if the work is cut by POSITION instead of by base: a workgroup owns a tile of TT_POS table positions,
+// keeps the tile's 64 bytes of counters per position in LDS, walks the part of every alignment that crosses the tile -- the alignments
+// with POS in (tile start - longest span of the slab, tile end), found by bisection; each one's first operation in the tile by bisection
+// in its operation list, all alignments of the tile at once, a thread each -- and adds its tile to the tables once: one atomic per
+// non-zero counter word and tile (the neighbour's I / D tally at "the position before" may land in this tile's words at the same time).
+// The tile of the first / last position also owns everything left / right of the tables: those bases tally nothing but are still
+// examined (sequence overrun, bases outside the alphabet), as the per-base kernel does.
+constexpr int TT_POS = 512;              // table positions per tile: 16 KB + 16 KB of counters
+constexpr int TT_THREADS = 1024;
+constexpr int TT_WAVES = TT_THREADS / 64;
+constexpr int TT_LIST = TT_THREADS;      // alignments examined per round, one thread each
+
+__global__ __launch_bounds__(256) void fe_slab_span_kernel(SlabView s, uint32_t n_reads, uint32_t *span) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_reads) return;
+    const clair_read_t r = s.reads[i];
+    if (!r.n_ops) return;
+    const clair_op_t last = s.ops[r.op0 + r.n_ops - 1];
+    const uint32_t len = last.code_len >> 2, code = last.code_len & 3u;
+    const int64_t reach = (int64_t)last.ref_off + (code == CLAIR_OP_I ? 1 : (int64_t)len);      // positions pos0 .. pos0 + reach - 1 are touched
+    atomicMax(span, (uint32_t)std::min<int64_t>(std::max<int64_t>(reach, 0), 0x7fffffff));
+}
+
+struct TileOp { int32_t rel; uint32_t code_len, q_off, first, k0; };    // an operation as the tile sees it: start relative to the tile, its first flat element, first k inside
+
+__global__ __launch_bounds__(TT_THREADS) void fe_tally_tile_kernel(Region g, SlabView s, uint32_t n_reads, const uint32_t *slab_span, int64_t tile0) {
+    __shared__ unsigned long long pq_l[TT_POS * 4];
+    __shared__ uint32_t misc_l[TT_POS * 8];
+    __shared__ uint2 list[TT_LIST];             // (alignment, its first operation that reaches into the tile)
+    __shared__ uint32_t n_list;
+    __shared__ TileOp opbuf[TT_WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the launch covers table tiles tile0 .. tile0 + gridDim.x - 1: where this slab's alignments lie (a guess is enough: the first and the last
+    // workgroup own everything left / right of their tile, and tally what falls inside the tables but outside their LDS window straight into them)
+    const int64_t t_lo = (tile0 + (int64_t)blockIdx.x) * TT_POS;
+    const bool first = blockIdx.x == 0, last = blockIdx.x == gridDim.x - 1;
+    const int64_t p_lo = first ? INT64_MIN / 4 : g.lo + t_lo, p_hi = last ? INT64_MAX / 4 : g.lo + t_lo + TT_POS;     // positions this tile owns
+    const int64_t p_base = g.lo + t_lo;
+    for (int i = tid; i < TT_POS * 4; i += TT_THREADS) pq_l[i] = 0ull;
+    for (int i = tid; i < TT_POS * 8; i += TT_THREADS) misc_l[i] = 0u;
+    // alignments that may reach into the tile: POS < p_hi, and POS + (longest reach of the slab) > p_lo
+    const int64_t span = (int64_t)*slab_span;
+    uint32_t ra = 0, rb = n_reads;
+    if (!first) { uint32_t a = 0, b = n_reads; while (a < b) { const uint32_t m = (a + b) >> 1; if (s.reads[m].pos0 + span > p_lo) b = m; else a = m + 1; } ra = a; }
+    if (!last) { uint32_t a = ra, b = n_reads; while (a < b) { const uint32_t m = (a + b) >> 1; if (s.reads[m].pos0 >= p_hi) b = m; else a = m + 1; } rb = a; }
+    for (uint32_t base = ra; base < rb; base += TT_LIST) {
+        if (tid == 0) n_list = 0u;
+        __syncthreads();
+        const uint32_t i = base + (uint32_t)tid;
+        if (i < rb) {
+            const clair_read_t r = s.reads[i];
+            if (r.n_ops && r.pos0 < p_hi) {
+                // operations are ordered and their ends (start + length; an insertion counts as one position) never decrease: first one ending beyond p_lo
+                uint32_t a = 0, b = r.n_ops;
+                while (a < b) {
+                    const uint32_t m = (a + b) >> 1;
+                    const clair_op_t op = s.ops[r.op0 + m];
+                    const int64_t end = r.pos0 + op.ref_off + ((op.code_len & 3u) == CLAIR_OP_I ? 1 : (int64_t)(op.code_len >> 2));
+                    if (end > p_lo) b = m; else a = m + 1;
+                }
+                if (a < r.n_ops) list[atomicAdd(&n_list, 1u)] = make_uint2(i, r.op0 + a);
+            }
+        }
+        __syncthreads();
+        const uint32_t n = n_list;
+        for (uint32_t li = (uint32_t)wave; li < n; li += TT_WAVES) {      // a wave per alignment
+            const uint2 ent = list[li];
+            const uint32_t ri = __builtin_amdgcn_readfirstlane(ent.x);
+            const clair_read_t r = s.reads[ri];
+            const bool evc = r.flags & CLAIR_READ_EVC, pile = r.flags & CLAIR_READ_PILE;
+            const int so = (r.flags & CLAIR_READ_REVERSE) ? 1 : 0;
+            const uint32_t jend = r.op0 + r.n_ops;
+            for (uint32_t j = __builtin_amdgcn_readfirstlane(ent.y); j < jend; j += 64) {          // 64 operations at a time, one per lane
+                const uint32_t jj = j + (uint32_t)lane;
+                const bool valid = jj < jend;
+                clair_op_t op{};
+                if (valid) op = s.ops[jj];
+                const uint32_t code = op.code_len & 3u, len = op.code_len >> 2;
+                const int64_t start = r.pos0 + op.ref_off;
+                const bool beyond = valid && start >= p_hi;
+                const bool in = valid && !beyond && start + (code == CLAIR_OP_I ? 1 : (int64_t)len) > p_lo;
+                uint32_t k0 = 0, k1 = 0;
+                if (in) {
+                    if (code == CLAIR_OP_I) { k1 = len; }
+                    else { k0 = (uint32_t)std::max<int64_t>(0, p_lo - start); k1 = (uint32_t)std::min<int64_t>((int64_t)len, p_hi - start); }
+                }
+                const uint32_t cnt = k1 - k0;
+                uint32_t incl = cnt;                       // inclusive prefix sum over the wave
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                const uint32_t total = __shfl(incl, 63);
+                opbuf[wave][lane] = TileOp{(int32_t)(start - p_base), op.code_len, op.q_off, incl - cnt, k0};
+                for (uint32_t e = (uint32_t)lane; e < total; e += 64) {
+                    int a = 0, b = 64;                     // last operation whose first flat element is <= e (empty ones share their successor's `first`: take the last)
+                    while (b - a > 1) { const int m = (a + b) >> 1; if (opbuf[wave][m].first <= e) a = m; else b = m; }
+                    const TileOp o = opbuf[wave][a];
+                    const uint32_t oc = o.code_len & 3u, k = o.k0 + (e - o.first);
+                    const int64_t lt = (int64_t)o.rel + (oc == CLAIR_OP_I ? 0 : (int64_t)k);   // position relative to the tile (outside [0, TT_POS) only in the first / last workgroup)
+                    const int64_t t = t_lo + lt;
+                    const int64_t rp = p_base + lt;
+                    const uint32_t qp = o.q_off + (oc == CLAIR_OP_D ? 0u : k);
+                    const bool inside = t >= 0 && t < g.n;
+                    auto bump = [&](int64_t at, int word) {          // misc counter `word` of tile position `at`: the tile's copy, or the table itself
+                        if (at >= 0 && at < TT_POS) atomicAdd(&misc_l[at * 8 + word], 1u); else atomicAdd(&g.misc[(t_lo + at) * 8 + word], 1u);
+                    };
+                    if (oc == CLAIR_OP_M) {
+                        if (qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); continue; }
+                        if (pile && inside && ref_row(g, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
+                        const uint8_t bs = s.seq[r.seq0 + qp];
+                        const uint8_t ei = BASES.evc[bs];
+                        if (ei == 255) { flag(g, CLAIR_FE_BAD_BASE); continue; }
+                        if (!inside) continue;
+                        const int row = BASES.pile[bs];
+                        unsigned long long add = pile ? 1ull << (so * PQ_BITS) : 0;
+                        if (evc && ei < 4) add += 1ull << (2 * PQ_BITS);
+                        if (add) {
+                            if (lt >= 0 && lt < TT_POS) atomicAdd(&pq_l[lt * 4 + row], add);
+                            else {
+                                const unsigned long long before = atomicAdd(&g.pq[t * 4 + row], add);
+                                if ((pile && pq_field(before, so) == PQ_MASK) || (evc && ei < 4 && pq_field(before, 2) == PQ_MASK)) flag(g, CLAIR_FE_OVERFLOW);
+                            }
+                        }
+                        if (evc && ei >= 4) bump(lt, 7);
+                        if (pile && rp == r.pos0) bump(lt, 4);
+                    } else if (oc == CLAIR_OP_I) {
+                        if (k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 5);   // once per operation, at the base before it
+                        if (!pile) continue;
+                        if (qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); continue; }
+                        if (rp <= r.pos0) continue;                                 // no window is open yet (CreateTensor.py:326-341)
+                        if (BASES.pile[s.seq[r.seq0 + qp]] == 255) flag(g, CLAIR_FE_BAD_BASE);
+                        if (inside) bump(lt, 3);
+                    } else {
+                        if (k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 6);
+                        if (!pile || !inside) continue;
+                        if (ref_row(g, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
+                        bump(lt, rp > r.pos0 ? so : 2);
+                    }
+                }
+                if (__ballot(beyond || !valid)) break;      // the rest of the alignment lies beyond the tile (or there is no rest)
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // the tile into the tables: one atomic per counter word that moved
+    for (int i = tid; i < TT_POS * 4; i += TT_THREADS) {
+        const unsigned long long add = pq_l[i];
+        const int64_t t = t_lo + (i >> 2);
+        if (add && t >= 0 && t < g.n) {
+            const unsigned long long before = atomicAdd(&g.pq[t * 4 + (i & 3)], add);
+            for (int fld = 0; fld < 3; ++fld)
+                if (pq_field(before, fld) + pq_field(add, fld) > PQ_MASK) flag(g, CLAIR_FE_OVERFLOW);       // a 21-bit counter ran over: 2 097 151 reads over one position
+        }
+    }
+    for (int i = tid; i < TT_POS * 8; i += TT_THREADS) {
+        const uint32_t add = misc_l[i];
+        const int64_t t = t_lo + (i >> 3);
+        if (add && t >= 0 && t < g.n) atomicAdd(&g.misc[t * 8 + (i & 7)], add);
+    }
+}
+
 // ---- the candidate filter (ExtractVariantCandidates.py:347-393) over the tallies: one flag per position -----------------------
 struct CandidateRule {
     double min_depth, min_af;
@@ -743,13 +907,13 @@ __global__ __launch_bounds__(256) void fe_text_keep_kernel(const TextLine *lines
 __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *lines, int64_t n_lines, const int64_t *kept, int64_t n_kept, const int64_t *cand, int64_t n_cand,
                                                               uint32_t *op0, uint32_t *elem0, uint64_t *totals, TextState carry, TextState *state) {
     __shared__ uint64_t s_ops, s_elems;
-    __shared__ uint32_t s_anom;
+    __shared__ uint32_t s_anom, s_reach;
     __shared__ unsigned long long s_evc, s_pile;
     __shared__ unsigned long long s_last_evc;                                 // 1 + index (among the kept lines) of the last one the candidate search accepts
-    if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_evc = 0; s_pile = 0; s_last_evc = 0; }
+    if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_reach = 0; s_evc = 0; s_pile = 0; s_last_evc = 0; }
     __syncthreads();
     uint64_t carry_ops = 0, carry_elems = 0;
-    uint32_t anom = 0;
+    uint32_t anom = 0, reach = 0;                 // reach: the longest alignment in elements (no reference span is longer)
     unsigned long long evc = 0, pile = 0;
     for (int64_t at = 0; at < n_kept; at += 256) {
         const int64_t i = at + threadIdx.x;
@@ -758,6 +922,7 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
             const TextLine ln = lines[kept[i]];
             a = ln.n_ops;
             b = ln.n_elem;
+            reach = max(reach, b);
             const int64_t before = i > 0 ? lines[kept[i - 1]].pos0 : (carry.have_last ? carry.last_pos : ln.pos0);
             if (ln.pos0 < before) anom |= CLAIR_FE_UNSORTED;
             if ((ln.flags & TL_ZERO_INDEL) && (ln.flags & CLAIR_READ_EVC)) anom |= CLAIR_FE_ZERO_INDEL;
@@ -787,12 +952,15 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
         carry_elems += tb;
     }
     atomicOr(&s_anom, anom);
+    atomicMax(&s_reach, reach);
     atomicAdd(&s_evc, evc);
     atomicAdd(&s_pile, pile);
     __syncthreads();
     if (threadIdx.x == 0) {
         totals[0] = carry_ops;
         totals[1] = carry_elems;
+        totals[2] = s_reach;
+        totals[3] = n_kept ? (uint64_t)lines[kept[0]].pos0 : 0;       // where the slab begins (the kept lines are sorted, or CLAIR_FE_UNSORTED is raised)
         TextState st = carry;
         st.anomalies = carry.anomalies | s_anom;
         st.malformed = state->malformed;
@@ -871,6 +1039,8 @@ struct clair_frontend {
     uint8_t *d_ctg = nullptr;
     TextState text_state{};
     TextState *d_text_state = nullptr;
+    uint32_t *d_span = nullptr;          // the longest reference reach of the slab being tallied (fe_slab_span_kernel)
+    bool tally_per_base = false;         // CLAIR_AMD_FE_TALLY=atomic when the handle was created: pass 1 by fe_tally_kernel (one device atomic per base)
     std::string error;
 
     SlabView view(const Slab &s) const {
@@ -973,6 +1143,7 @@ int clair_frontend_create(int device, const char *ref_seq, int64_t ref_len, int6
         return fe_fail(nullptr, "no HIP device is visible: the front end runs on an MI355X only (the host code is clair_host_evc_* / clair_host_pileup_*)");
     if (device < 0 || device >= n_dev) return fe_fail(nullptr, "device %d out of range [0,%d)", device, n_dev);
     clair_frontend *f = new clair_frontend;
+    { const char *t = getenv("CLAIR_AMD_FE_TALLY"); f->tally_per_base = t && !strcmp(t, "atomic"); }
     f->device = device;
     auto bail = [&](const char *what, hipError_t err) {
         fe_fail(nullptr, "%s failed: %s", what, hipGetErrorString(err));
@@ -1016,9 +1187,28 @@ void clair_frontend_destroy(clair_frontend_t *f) {
     free_candidates(f);
     (void)hipFree(f->d_ref); (void)hipFree(f->g.pq); (void)hipFree(f->g.misc); (void)hipFree(f->g.anomalies);
     (void)hipFree(f->d_flags); (void)hipFree(f->d_before); (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_bed);
-    (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state);
+    (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state); (void)hipFree(f->d_span);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
+}
+
+// Pass 1 over one slab.  The tiled kernel wherever its assumptions hold (fewer alignments in the slab than a 21-bit counter holds, so that a
+// tile's counters cannot carry into their neighbours); CLAIR_AMD_FE_TALLY=atomic keeps the per-base kernel (tests compare the two, bit for bit).
+// [p_first, p_reach): reference positions the slab may touch (a generous guess is fine, see fe_tally_tile_kernel).
+static int launch_tally(clair_frontend *f, const Slab &d, int64_t p_first, int64_t p_reach) {
+    if (!d.n_elem) return 0;
+    if (f->tally_per_base || d.n_reads >= (int64_t)PQ_MASK) {
+        hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
+        return 0;
+    }
+    if (!f->d_span) FE_TRY(f, hipMalloc((void **)&f->d_span, sizeof(uint32_t)));
+    FE_TRY(f, hipMemsetAsync(f->d_span, 0, sizeof(uint32_t), f->stream));
+    hipLaunchKernelGGL(fe_slab_span_kernel, dim3(blocks_for(d.n_reads, 256)), dim3(256), 0, f->stream, f->view(d), (uint32_t)d.n_reads, f->d_span);
+    const int64_t n_tiles = (f->g.n + TT_POS - 1) / TT_POS;
+    const int64_t tile0 = std::min(std::max<int64_t>((p_first - f->g.lo) / TT_POS - (p_first < f->g.lo ? 1 : 0), 0), n_tiles - 1);
+    const int64_t tile1 = std::min(std::max<int64_t>((p_reach - f->g.lo) / TT_POS, tile0), n_tiles - 1);
+    hipLaunchKernelGGL(fe_tally_tile_kernel, dim3((unsigned)(tile1 - tile0 + 1)), dim3(TT_THREADS), 0, f->stream, f->g, f->view(d), (uint32_t)d.n_reads, (const uint32_t *)f->d_span, tile0);
+    return 0;
 }
 
 int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int64_t n_reads, const clair_op_t *ops, int64_t n_ops,
@@ -1044,7 +1234,18 @@ int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int
     FE_TRY(f, hipMemcpyAsync(d.op_elem, op_elem, ((size_t)n_ops + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, f->stream));
     if (seq_bytes) FE_TRY(f, hipMemcpyAsync(d.seq, seq, (size_t)seq_bytes, hipMemcpyHostToDevice, f->stream));
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_reads * sizeof(uint64_t), f->stream));
-    if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
+    {   // where the slab lies, for the grid of the tiled tally: first and last start, the longest reach (host arrays: one look at every alignment's last operation)
+        int64_t p_first = reads[0].pos0, p_last = reads[0].pos0, reach = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            p_first = std::min(p_first, reads[i].pos0);
+            p_last = std::max(p_last, reads[i].pos0);
+            if (reads[i].n_ops && (int64_t)reads[i].op0 + reads[i].n_ops <= n_ops) {
+                const clair_op_t &o = ops[reads[i].op0 + reads[i].n_ops - 1];
+                reach = std::max(reach, (int64_t)o.ref_off + (int64_t)(o.code_len >> 2));
+            }
+        }
+        if (launch_tally(f, d, p_first, p_last + reach)) return 1;
+    }
     FE_TRY(f, hipGetLastError());
     // the caller's arrays may be reused as soon as this returns (the packer's slab is reset): wait for the copies
     FE_TRY(f, hipStreamSynchronize(f->stream));
@@ -1122,11 +1323,11 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     uint64_t *d_totals = nullptr;
     FE_TRY(f, tmp.get((void **)&op0, (size_t)n_kept * sizeof(uint32_t)));
     FE_TRY(f, tmp.get((void **)&elem0, (size_t)n_kept * sizeof(uint32_t)));
-    FE_TRY(f, tmp.get((void **)&d_totals, 2 * sizeof(uint64_t)));
+    FE_TRY(f, tmp.get((void **)&d_totals, 4 * sizeof(uint64_t)));
     hipLaunchKernelGGL(fe_text_offsets_kernel, dim3(1), dim3(256), 0, f->stream, (const TextLine *)lines, n_lines, (const int64_t *)kept, n_kept, (const int64_t *)cand, n_cand,
                        op0, elem0, d_totals, carry, f->d_text_state);
     FE_TRY(f, hipGetLastError());
-    uint64_t totals[2] = {0, 0};
+    uint64_t totals[4] = {0, 0, 0, 0};
     TextState after{};
     FE_TRY(f, hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, f->stream));
     FE_TRY(f, hipMemcpyAsync(&after, f->d_text_state, sizeof after, hipMemcpyDeviceToHost, f->stream));
@@ -1153,7 +1354,7 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
     hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
                        (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
-    if (d.n_elem) hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
+    if (launch_tally(f, d, (int64_t)totals[3], after.last_pos + (int64_t)totals[2])) return 1;
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
     return 0;

@@ -63,6 +63,73 @@ struct Active {
     Window *win;
 };
 
+// CPython's set of ints, as far as its ITERATION ORDER goes (Objects/setobject.c of CPython 3.7 - 3.12: open addressing, 9 linear probes, then
+// i = 5 i + 1 + perturb with perturb >>= 5; a removed key leaves a dummy that the next insertion along the same probe path takes over; the table
+// is rebuilt at four times the live keys once active + dummy entries reach 3/5 of it; hash(i) = i for 0 <= i < 2^61 - 1).  The reference keeps
+// the windows open over a read base in such a set and offers the base to them in the set's order (CreateTensor.py:296-310): the order shows
+// in its output only where the tuple budget runs out in the middle of one base.  Pinned against the interpreter itself (tests/test_pileup.py:
+// random add / remove histories) and against records minted from the real script with the budget binding (tests/golden/pileup_ct_budget_binds).
+struct PySetOrder {
+    static constexpr int64_t EMPTY = INT64_MIN, DUMMY = INT64_MIN + 1;
+    std::vector<int64_t> table;
+    size_t mask = 7, fill = 0, used = 0;
+    PySetOrder() : table(8, EMPTY) {}
+    void clear() { if (fill || mask != 7) { table.assign(8, EMPTY); mask = 7; fill = used = 0; } }
+    static void insert_clean(std::vector<int64_t> &t, size_t mask, int64_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & mask;
+        for (;;) {
+            const size_t probes = i + 9 <= mask ? 9 : 0;
+            for (size_t j = i; j <= i + probes; ++j)
+                if (t[j] == EMPTY) { t[j] = key; return; }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+    void resize(size_t minused) {
+        size_t n = 8;
+        while (n <= minused) n <<= 1;
+        std::vector<int64_t> old;
+        old.swap(table);
+        table.assign(n, EMPTY);
+        mask = n - 1;
+        fill = used;
+        for (int64_t k : old)
+            if (k != EMPTY && k != DUMMY) insert_clean(table, mask, k);
+    }
+    void add(int64_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & mask;
+        int64_t *freeslot = nullptr;
+        for (;;) {
+            const size_t probes = i + 9 <= mask ? 9 : 0;
+            for (size_t j = i; j <= i + probes; ++j) {
+                int64_t &e = table[j];
+                if (e == EMPTY) {
+                    if (freeslot) { *freeslot = key; ++used; return; }
+                    e = key; ++fill; ++used;
+                    if (fill * 5 >= mask * 3) resize(used > 50000 ? used * 2 : used * 4);
+                    return;
+                }
+                if (e == key) return;
+                if (e == DUMMY) freeslot = &e;
+            }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+    void remove(int64_t key) {
+        size_t perturb = (size_t)key, i = (size_t)key & mask;
+        for (;;) {
+            const size_t probes = i + 9 <= mask ? 9 : 0;
+            for (size_t j = i; j <= i + probes; ++j) {
+                if (table[j] == EMPTY) return;
+                if (table[j] == key) { table[j] = DUMMY; --used; return; }
+            }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+};
+
 }  // namespace
 
 struct clair_pileup {
@@ -87,6 +154,9 @@ struct clair_pileup {
     std::vector<Window *> out;             // finished windows; [out_head, size) not taken yet (then back to the pool)
     size_t out_head = 0;
     std::vector<Active> active;            // per read
+    int set_order = 0;                     // 0: a base is offered to the open windows in the order they were opened in; 1: in the order of CPython's set
+    PySetOrder hashed;                     // set_order 1: the reference's active_set of this read
+    std::vector<int64_t> offer;            // scratch
     std::vector<Window *> flushed;         // scratch
     int64_t reads_seen = 0;
 
@@ -152,12 +222,33 @@ struct clair_pileup {
         if (!active.empty() && active.back().centre > centre)
             pos = std::lower_bound(active.begin(), active.end(), centre, [](const Active &a, int64_t c) { return a.centre < c; });
         active.insert(pos, Active{centre, w});
+        if (set_order) hashed.add(centre);
+    }
+
+    // One tuple per open window, while the budget lasts (CreateTensor.py:306-310, 326-330, 343-347).  The order matters only to the base
+    // the budget runs out on.
+    template <class F> inline void offer_base(F &&one) {
+        if (set_order && slots < (int64_t)active.size()) {
+            offer.clear();
+            for (int64_t k : hashed.table)
+                if (k != PySetOrder::EMPTY && k != PySetOrder::DUMMY) offer.push_back(k);
+            for (int64_t centre : offer) {
+                if (slots <= 0) break;
+                for (const Active &a : active)
+                    if (a.centre == centre) { one(a.win); break; }
+            }
+            return;
+        }
+        for (const Active &a : active) {
+            if (slots <= 0) break;
+            one(a.win);
+        }
     }
 
     void close_window_ending_at(int64_t rp) {
         const int64_t centre = rp - (FLANK + 1);
         for (size_t i = 0; i < active.size(); ++i)
-            if (active[i].centre == centre) { active.erase(active.begin() + (long)i); return; }
+            if (active[i].centre == centre) { active.erase(active.begin() + (long)i); if (set_order) hashed.remove(centre); return; }
     }
 
     // one tuple of the reference's alignment lists applied to one window (generate_tensor :34-56); rn / qn: row of the
@@ -217,6 +308,7 @@ struct clair_pileup {
             if (depth_cap >= dcov) return 0;
         }
         active.clear();
+        if (set_order) hashed.clear();
         int64_t rp = pos, qp = 0, adv = 0;
         // sorted path: candidates [0, next_cand) are loaded; those within [rp-16, rp+17] may open at rp (left-edge mode), or
         // the one at rp+17 (otherwise).  `seen` = loaded candidates already offered to this read.
@@ -250,10 +342,7 @@ struct clair_pileup {
                         char rb;
                         if (!ref_base(rp, &rb)) return 1;
                         const int rn = base_row(rb), qn = base_row(seq[qp]);
-                        for (const Active &a : active) {
-                            if (slots <= 0) break;
-                            count(a.win, rp, 0, rn, qn, so);
-                        }
+                        offer_base([&](Window *w) { count(w, rp, 0, rn, qn, so); });
                     }
                     if (!active.empty() && active.front().centre <= rp - (FLANK + 1)) close_window_ending_at(rp);
                     ++rp;
@@ -265,10 +354,7 @@ struct clair_pileup {
                     if (!active.empty() && slots > 0) {
                         if (qp >= (int64_t)seq_len) return clair_host_fail("read at %lld: CIGAR walks past the end of SEQ (%zu bases)", (long long)pos1, seq_len);
                         const int qn = base_row(seq[qp]);
-                        for (const Active &a : active) {
-                            if (slots <= 0) break;
-                            count(a.win, rp, k, -2, qn, so);
-                        }
+                        offer_base([&](Window *w) { count(w, rp, k, -2, qn, so); });
                     }
                     ++qp;
                 }
@@ -279,10 +365,7 @@ struct clair_pileup {
                         char rb;
                         if (!ref_base(rp, &rb)) return 1;
                         const int rn = base_row(rb);
-                        for (const Active &a : active) {
-                            if (slots <= 0) break;
-                            count(a.win, rp, 0, rn, -2, so);
-                        }
+                        offer_base([&](Window *w) { count(w, rp, 0, rn, -2, so); });
                     }
                     open_at(rp);
                     if (!active.empty() && active.front().centre <= rp - (FLANK + 1)) close_window_ending_at(rp);
@@ -371,6 +454,30 @@ int clair_host_pileup_create(const char *ref_seq, int64_t ref_len, int64_t refer
 }
 
 void clair_host_pileup_destroy(clair_pileup_t *p) { delete p; }
+
+int clair_host_pileup_set_order(clair_pileup_t *p, int cpython_set) {
+    if (!p) return clair_host_fail("pileup builder is NULL");
+    if (p->reads_seen) return clair_host_fail("the offer order is chosen before the first alignment");
+    p->set_order = cpython_set ? 1 : 0;
+    return 0;
+}
+
+// test hook: replay a history of set operations (key >= 0: add; -(key + 1): remove) and hand back the keys in iteration order
+int clair_host_pyset_order(const int64_t *ops, int64_t n_ops, int64_t *keys, int64_t capacity, int64_t *n_keys) {
+    if (!ops || !keys || !n_keys || n_ops < 0) return clair_host_fail("bad arguments to clair_host_pyset_order");
+    PySetOrder s;
+    for (int64_t i = 0; i < n_ops; ++i) {
+        if (ops[i] >= 0) s.add(ops[i]); else s.remove(-(ops[i] + 1));
+    }
+    int64_t n = 0;
+    for (int64_t k : s.table)
+        if (k != PySetOrder::EMPTY && k != PySetOrder::DUMMY) {
+            if (n >= capacity) return clair_host_fail("room for %lld keys", (long long)capacity);
+            keys[n++] = k;
+        }
+    *n_keys = n;
+    return 0;
+}
 
 int clair_host_pileup_feed(clair_pileup_t *p, const char *sam, int64_t len, int final, int64_t *bytes_consumed) {
     if (!p || (!sam && len > 0) || !bytes_consumed) return clair_host_fail("bad argument");

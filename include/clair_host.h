@@ -100,14 +100,21 @@ int clair_host_format_calls_records(const clair_call_t *calls, const char *ctg, 
  *    or at clair_host_pileup_finish (:388-394), in first-touch order, and dropped when its centre depth is below min_coverage or
  *    it would start before the loaded reference (:58-59); available_slots is the reference's budget of outstanding
  *    (window, base) tuples (5 000 000, :181): bases are dropped once it is used up, exactly where the reference drops them
- *    (within one reference position the windows are served in ascending centre order; the reference's order there is CPython's
- *    set iteration order).  force_general_path != 0 selects the hash-map twin of the sorted-candidates fast path (tests).
+ *    (within one reference position the windows are served in the order clair_host_pileup_set_order selects).  force_general_path != 0 selects the hash-map twin of the sorted-candidates fast path (tests).
  *    Pinned byte for byte against records minted from the real script (tests/golden/pileup_ct_*.json.gz). */
 typedef struct clair_pileup clair_pileup_t;
 int clair_host_pileup_create(const char *ref_seq, int64_t ref_len, int64_t reference_start_0_based, const int64_t *candidates,
                              int64_t n_candidates, int consider_left_edge, int dcov, int min_coverage, int min_mq,
                              int64_t available_slots, int force_general_path, clair_pileup_t **out);
 void clair_host_pileup_destroy(clair_pileup_t *p);
+/* The order in which a read base is offered to the windows open over it (CreateTensor.py:296-310), before the first alignment is fed.  It shows
+ * in the records only where the budget of outstanding tuples runs out in the MIDDLE of one base.  0 (default): the order the windows were opened
+ * in -- what an insertion-ordered set gives, i.e. the script under PyPy, the interpreter clair/callVarBam.py runs it with by default (--pypy);
+ * 1: the iteration order of CPython's hash set, restated in host_pileup.cpp and pinned against records minted from the real script under
+ * CPython with the budget binding (tests/golden/pileup_ct_budget_binds.json.gz). */
+int clair_host_pileup_set_order(clair_pileup_t *p, int cpython_set);
+/* test hook for that restatement: replay set operations (key >= 0: add(key); -(key + 1): remove(key)) -> the keys in iteration order */
+int clair_host_pyset_order(const int64_t *ops, int64_t n_ops, int64_t *keys, int64_t capacity, int64_t *n_keys);
 /* Consume SAM text line by line ('\n'; a last line without '\n' only when `final`): header lines ('@') are skipped, columns
  * FLAG, POS, MAPQ, CIGAR, SEQ are used (:252-263).  *bytes_consumed = start of the first line not consumed.  Errors (too few
  * columns, non-integer column, CIGAR longer than SEQ, position outside the loaded reference) name the 0-based line index since

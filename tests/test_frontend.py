@@ -204,6 +204,20 @@ def test_columns_equal_the_sequential_candidate_search(seed):
     assert np.array_equal(want, got) and len(want) > 30
 
 
+def test_reference_case_whose_budget_binds_is_reported_with_the_real_budget():
+    """tests/golden/pileup_ct_budget_binds: minted from the real script, whose 5 000 000-tuple budget runs out.  The column formulation cannot
+    reproduce that (its result depends on the order bases are offered in, down to the interpreter's set order): the replay of the budget
+    says so, which is what sends callVarBam to the sequential stage (tests/test_pileup.py pins THAT against the same records)."""
+    case = fc.ct_golden_case(fc.BUDGET_GOLDEN)
+    col, _ = columns_of(case, dcov=case["dcov"], pile_min_mq=case["min_mq"], pile_region=case["pile_region"])
+    w = col.windows(case["candidates"], min_cov=case["min_coverage"])
+    assert col.anomalies == fe.A_BUDGET                       # said by windows() itself, with the reference's 5 000 000
+    totals = np.where(w["opened"], w["totals"], 0)
+    assert fe.budget_binds(col.slabs, w["tuples"], case["candidates"], totals, 5000000)
+    assert not fe.budget_binds(col.slabs, w["tuples"], case["candidates"], totals, 10 ** 9)
+    assert fc.text_of(case["ctg"], w["centres"], w["refseq"], w["counts"]) != case["expected"]     # unbounded counts are not the reference's here
+
+
 def test_budget_replay_is_safe_without_left_edge_windows():
     case = fc.synth(33, n_reads=200, ref_len=1500, cand_step=(1, 4))
     col, _ = columns_of(case)

@@ -101,6 +101,34 @@ def test_windows_equal_the_sequential_pileup_and_the_restatement(k, left_edge):
     assert int(got.sum()) == int(wt.sum()) > 0
 
 
+@pytest.mark.parametrize("margin", [64, 300, 511])
+@pytest.mark.parametrize("text", [False, True], ids=["packed", "text"])
+def test_tiled_tally_equals_the_per_base_tally(margin, text, monkeypatch):
+    """Pass 1 by position tiles in LDS (the default) against pass 1 with one device atomic per base (CLAIR_AMD_FE_TALLY=atomic): every candidate,
+    every window count and every anomaly the same, with the tile boundaries (multiples of 512 table positions) moved across the alignments by the
+    margin, reads of 200-3000 bases crossing dozens of tiles, dense insertions and deletions (the search tallies an I / D at the position BEFORE
+    it: across a tile boundary that word belongs to the neighbour), and the alignments in several slabs."""
+    for seed, kw in ((9, dict(n_reads=2500, ref_len=30000, read_len=(200, 3000), cand_step=(1, 30))),
+                     (8, dict(n_reads=900, ref_len=4000, ins_rate=0.12, del_rate=0.1, cand_step=(1, 6))),
+                     (5, dict(n_reads=600, ref_len=3000, dup_burst=6))):
+        case = fc.synth(seed, **kw)
+        got = {}
+        for mode in ("atomic", "tiles"):
+            if mode == "atomic":
+                monkeypatch.setenv("CLAIR_AMD_FE_TALLY", "atomic")
+            else:
+                monkeypatch.delenv("CLAIR_AMD_FE_TALLY", raising=False)
+            f = device_frontend_text(case, chunks=3, margin=margin) if text else device_frontend(case, slabs=3, margin=margin)
+            n = f.find_candidates(min_coverage=4, threshold=0.125)
+            pos = f.candidates()
+            f.build_windows(drop_non_iupac_centre=False)
+            got[mode] = (n, pos, windows_of(f), f.stats()["anomalies"], f.window_tuples())
+            f.close()
+        a, b = got["atomic"], got["tiles"]
+        assert a[0] == b[0] and a[0] > 50 and np.array_equal(a[1], b[1]) and a[3] == b[3]
+        assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2])) and np.array_equal(a[4], b[4])
+
+
 def test_candidates_then_windows_equal_the_two_sequential_stages():
     """The whole front end: one packed stream, candidate search on the tallies, windows at those candidates -- against the finder and the
     builder run one after the other on the text, with a region (the two stages then see different alignments) and a bed file."""
@@ -127,6 +155,17 @@ def test_budget_that_binds_is_reported():
     assert not f.budget_binds() and f.budget_binds(available_slots=3000)
     free = fc.host_windows(case)
     assert not all(np.array_equal(a, b) for a, b in zip(free, fc.host_windows(case, available_slots=3000)))
+
+
+def test_reference_case_whose_budget_binds_is_reported_by_the_device():
+    """The golden case minted from the real script with its budget binding: the device front end builds its (unbounded) windows and reports that
+    the reference's budget would have run out -- callVarBam then runs the sequential stage, which tests/test_pileup.py pins against the records."""
+    case = fc.ct_golden_case(fc.BUDGET_GOLDEN)
+    f = device_frontend(case, slabs=2, dcov=case["dcov"], pile_min_mq=case["min_mq"])
+    f.set_candidates(case["candidates"])
+    f.build_windows(min_coverage=case["min_coverage"], drop_non_iupac_centre=False)
+    assert f.stats()["anomalies"] == 0 and f.budget_binds() and not f.budget_binds(available_slots=10 ** 9)
+    f.close()
 
 
 def test_reports_of_what_leaves_the_regime():

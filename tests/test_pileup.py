@@ -21,7 +21,8 @@ import pileup_synth  # noqa: E402
 from clair_amd import _hostapi, create_tensor as ct  # noqa: E402
 
 FAKE_SAMTOOLS = "%s %s" % (sys.executable, os.path.join(HERE, "fake_samtools.py"))
-GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "pileup_ct_*.json.gz")))
+BUDGET_GOLDEN = os.path.join(HERE, "golden", "pileup_ct_budget_binds.json.gz")     # the reference's tuple budget binds: tests of their own below
+GOLDEN = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "pileup_ct_*.json.gz")) if p != BUDGET_GOLDEN)
 
 
 def load(path):
@@ -59,6 +60,60 @@ def builder_inputs(doc):
 
 def text_of(builder, ctg):
     return "".join(ct.format_record(ctg, c, s, t) + "\n" for c, s, t in builder.take())
+
+
+@pytest.mark.skipif(sys.implementation.name != "cpython", reason="the restatement is of CPython's set")
+def test_cpython_set_order_is_restated():
+    """host_pileup.cpp: PySetOrder against the interpreter's own set -- random histories of add / remove over clustered and scattered ints,
+    through dummies, probe-path reuse and table rebuilds; the iteration order must be the interpreter's after every history."""
+    import random
+    for trial in range(400):
+        rng = random.Random(trial)
+        live, s, ops = [], set(), []
+        base = rng.randrange(0, 10 ** 8)
+        for _ in range(rng.randrange(1, 500)):
+            if live and rng.random() < 0.45:
+                k = live.pop(rng.randrange(len(live)) if rng.random() < 0.3 else 0)      # mostly the oldest: windows close in the order they opened
+                s.remove(k)
+                ops.append(-(k + 1))
+            else:
+                k = base + rng.randrange(0, 80) if rng.random() < 0.7 else rng.randrange(0, 10 ** 9)
+                if k not in s:
+                    live.append(k)
+                s.add(k)
+                ops.append(k)
+        assert _hostapi.pyset_order(ops) == list(s), trial
+
+
+def test_budget_that_binds_reproduces_the_reference_records():
+    """The reference's budget of 5 000 000 outstanding tuples BINDS in this golden case (64 reads of 3-3.9 kb over a candidate at every
+    position).  Where it runs out in the middle of one read base, the windows the base still reaches are the first ones of the interpreter's
+    set (CreateTensor.py:296-310): with CPython's order restated (set_order="cpython") the native builder -- sorted-candidates path and
+    dict path -- and the Python twin (a real set) give the reference's records byte for byte; with insertion order (PyPy's sets, the
+    default) only the records of those few bases differ."""
+    doc = load(BUDGET_GOLDEN)
+    assert doc["python"].startswith("3.")
+    a, kw, sam = builder_inputs(doc)
+    free = _hostapi.PileupBuilder(*a, available_slots=10 ** 9, **kw)
+    unbounded = "".join(free.text_from_sam(io.BytesIO(sam.encode())))
+    assert unbounded != doc["expected"]                                    # the budget does bind
+    for general in (False, True):
+        b = _hostapi.PileupBuilder(*a, set_order="cpython", force_general_path=general, **kw)
+        assert "".join(b.text_from_sam(io.BytesIO(sam.encode()))) == doc["expected"]
+    b = _hostapi.PileupBuilder(*a, **kw)                                   # insertion order
+    got = "".join(b.text_from_sam(io.BytesIO(sam.encode()))).splitlines()
+    want = doc["expected"].splitlines()
+    differ = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
+    assert len(got) == len(want) and 0 < len(differ) <= 40
+    for i in differ:                                                       # same windows, same reference bases; a handful of counts moved
+        gx, wx = got[i].split(), want[i].split()
+        assert gx[:3] == wx[:3] and sum(x != y for x, y in zip(gx[3:], wx[3:])) <= 8
+    if sys.implementation.name == "cpython":
+        py = ct.PileupBuilderPy(*a, set_order="cpython", **kw)
+        for line in sam.splitlines():
+            py.add_sam_line(line)
+        py.finish()
+        assert text_of(py, doc["ctg"]) == doc["expected"]
 
 
 def test_golden_files_present():

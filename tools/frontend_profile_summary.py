@@ -33,6 +33,7 @@ def main():
     # what one launch must move at least once: the packed slab it walks, the table rows it touches, the windows it writes
     algorithmic = {
         "fe_tally_kernel": elements * (1 + 16 / 8.0 + 4) + elements * 3 * 4,                 # SEQ byte + its share of an operation (16 B per ~8 bases) + prefix entry; ~3 counters of 4 B
+        "fe_tally_tile_kernel": elements * (1 + 16 / 8.0) + positions * 64 * 2,               # SEQ byte + its share of an operation; the tile's 64 B of counters read and written once
         "fe_windows_per_base_kernel": elements * (1 + 16 / 8.0 + 4) + elements * 2 * 4,      # + two prefix look-ups
         "fe_candidate_flags_kernel": positions * (32 + 1),
         "fe_block_count_kernel": positions * 1,

@@ -54,6 +54,11 @@ CT_CASES = {
     "ct_unsorted_candidates": (dict(seed=16, n_reads=200), [], False, True),
     # round 4: alignments that begin with an insertion / deletion, also several at one start position
     "ct_lead_indel": (dict(seed=17, dup_burst=8, lead_indel=0.3), [], False, False),
+    # round 4 (VERDICT r03 "missing" 5): the reference's budget of 5 000 000 outstanding tuples BINDS -- a candidate at every position under
+    # 64 reads of 3-3.9 kb that all start within 1.2 kb, so that no window is written before the budget is gone.  Which windows the last base
+    # of a read reaches then follows the iteration order of the interpreter's set (CreateTensor.py:296-310): minted under CPython (sys.version
+    # is recorded), the order clair_host_pileup_set_order(.., 1) restates.  (~8 s, 0.6 GB: 5 M Python tuples.)
+    "ct_budget_binds": (dict(seed=31, ref_len=4200, n_reads=64, read_len=(3000, 3900), cand_step=(1, 2), second_ctg=False), [], False, False),
 }
 
 
@@ -95,7 +100,7 @@ def mint_create_tensor():
                     f.write(cands)
                 args += ["--can_fn", can]
             out = run_reference("dataPrepScripts.CreateTensor", args, None if via_file else cands, tmp)
-        doc = {"tool": "CreateTensor", "args": extra, "candidates_via_file": via_file, "ctg": case["ctg"],
+        doc = {"tool": "CreateTensor", "args": extra, "candidates_via_file": via_file, "ctg": case["ctg"], "python": sys.version.split()[0],
                "fasta": case["fasta"], "sam": case["sam"], "candidates": cands, "expected": out}
         with gzip.open(os.path.join(GOLD, "pileup_%s.json.gz" % name), "wt", compresslevel=9) as f:
             json.dump(doc, f)
