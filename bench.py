@@ -115,7 +115,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=196)      # 196 x 1024 ~= 200k chr20 candidate sites
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--streams", type=int, default=3, help="pipeline slots (HIP streams) with batches in flight")
+    ap.add_argument("--streams", type=int, default=4, help="forward passes in flight on the resident path (one compute lane each; the runtime has four hardware queues)")
     ap.add_argument("--platform", default="ont", choices=sorted(PLATFORM))
     ap.add_argument("--unique-batches", type=int, default=8, help="distinct synthetic batches kept resident")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
@@ -245,7 +245,7 @@ class GpuStateSampler(object):
 
 def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq, steps, timed, full_steps):
     """value_boundary: the timed loop again through clair_submit / clair_wait on host arrays.  A second handle with `--boundary-slots`
-    slots over the same three compute lanes; every batch is a pageable NumPy array (a different one per step, `nuniq` of them) and every
+    slots over three compute lanes (a handle with more than four slots: the fourth hardware queue is the incoming copy stream's); every batch is a pageable NumPy array (a different one per step, `nuniq` of them) and every
     result four fresh NumPy arrays, as clair/model.py:946-966 returns them.  The last batch's outputs are compared bit for bit with the
     resident path's."""
     world = group.world
@@ -277,7 +277,7 @@ def boundary_legs(args, group, eng_resident, device, w, x, xd, od, batch, nuniq,
             last[:] = [pending.pop(s), eng.wait(s)]
 
     phases = []                        # forward passes launched, in order (tools/rocpd_summary.py --phases-from)
-    out = {"slots": slots, "lanes": min(slots, 3), "steps": steps,
+    out = {"slots": slots, "lanes": slots if slots <= 4 else 3, "steps": steps,
            "interface": "pageable NumPy batches [n,33,8,4] in, four fresh NumPy arrays per batch out (clair_submit / clair_submit_counts + clair_wait); "
                         "staging copy and enqueue on the engine's staging threads, H2D on one copy stream, results written to page-locked host "
                         "memory by a kernel on the lane"}

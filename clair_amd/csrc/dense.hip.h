@@ -43,7 +43,8 @@ constexpr int L34_A2_BYTES = T_POS * L34_CAND * L34_CH * 4;   // the a2 staging 
 constexpr int L34_L3_BYTES = 2 * L34_CAND * L34_ROW * 2;      // the l3 tile, two planes: 63 488 B
 constexpr int L34_THREADS = 512;
 static_assert(2 * 6 * 64 * 16 * 4 <= L34_L3_BYTES, "the K-half exchange fits the l3 tile's buffer");
-static_assert(L34_WALK * L4_SPLITS * L34_CH == 2 * HID && L34_WALK == 4, "channel groups cover the 256 LSTM2 features; an XCD owns one split");
+constexpr int L34_SUB = 4 / L34_WALK;            // workgroups that share an XCD's four channel groups for one candidate block (1: the workgroup walks all four)
+static_assert(L34_WALK * L4_SPLITS * L34_CH == 2 * HID && L34_SUB * L34_WALK == 4, "channel groups cover the 256 LSTM2 features; an XCD owns four of them");
 static_assert(L34_A2_BYTES + L34_L3_BYTES + 16 <= 160 * 1024, "one workgroup per CU");
 // l3 is multiplied by 2^4 before its 2-way fp16 split and the L4 reduction by 2^-4 (folded into TailArgs::l4_scale): a selu output
 // of 0.01 would otherwise have a subnormal low plane (3e-8 absolute = 3e-6 relative); 2^4 keeps 22 bits down to |y| ~ 0.008 and
@@ -82,10 +83,11 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
     const int l32 = lane & 31, hq = lane >> 5;
     // XCD-aware order (workgroups go round-robin over the 8 XCDs by linear id): XCD x owns split x = channel groups 4x .. 4x+3 for every
     // candidate block, so each L2 holds only its own 1/8 of the W4 fragments (740 KB) instead of every L2 streaming all 5.9 MB.
-    const int xcd = blockIdx.x & 7, blk = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, sub = (blockIdx.x >> 3) % L34_SUB, blk = (blockIdx.x >> 3) / L34_SUB;
     const int nblk = (p.n_pad + L34_CAND - 1) / L34_CAND;
     const int n0 = blk * L34_CAND;
-    const int cg0 = xcd * L34_WALK;
+    const int split = xcd * L34_SUB + sub;
+    const int cg0 = split * L34_WALK;
     if (tid == 0) psync = 0u;
 
     if (w < 4) {
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
         }
         l34_barrier();                              // E2
         if (!kh) {
-            float *dst = p.part + (((size_t)xcd * nblk + blk) * 2 + nh) * (6 * 4 * 256) + lane * 4;
+            float *dst = p.part + (((size_t)split * nblk + blk) * 2 + nh) * (6 * 4 * 256) + lane * 4;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
 // clair/model.py:482-488 (L4), :507-569 (L5_k), :582-620 (heads: selu on the logits, then softmax).
 // Output rows are packed gt21(21) | genotype(3) | len1(33) | len2(33).
 //
-// One workgroup per 32-candidate tile; wave k owns branch k end to end (L5_k -> head k -> softmax).  Round 4: both products run as the
+// One workgroup of eight waves per 32-candidate tile; waves k and k + 4 share branch k's L5 product by K halves, wave k then owns the branch to
+// the end (head k -> softmax).  Round 4: both products run as the
 // 2-way fp16 split on v_mfma_f32_32x32x16_f16, TRANSPOSED (weights = A operand, candidates = columns) like L3 -- round 3 ran them on
 // v_mfma_f32_16x16x4_f32, a sixteenth of the rate: 360 MFMAs of 32 cycles per wave and 16 candidates, 11.5 k cycles of a 20 us kernel that
 // held 64 CUs.  Now 144 MFMAs per wave and 32 candidates, and with 32 candidates per workgroup the W5 fragments a wave streams from L2
@@ -369,49 +372,55 @@ struct TailArgs {
     float head_scale[4];        // 2^-wh_shift[k] / TAIL_ACT_SCALE
 };
 
-__global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
+constexpr int TAIL_THREADS = 512;
+
+__global__ __launch_bounds__(TAIL_THREADS) void tail_kernel(TailArgs p) {
     __shared__ __attribute__((aligned(16))) _Float16 l4h[2][TAIL_TILE][TL4_ROW];        // [plane][cand][unit]
-    __shared__ __attribute__((aligned(16))) _Float16 l5h[4][2][TAIL_TILE][TL5_ROW];     // [branch][plane][cand][unit]
+    __shared__ __attribute__((aligned(16))) _Float16 l5h[4][2][TAIL_TILE][TL5_ROW];     // [branch][plane][cand][unit]; before that the K-half exchange of the branch
+    static_assert(3 * 4 * 64 * 16 <= 2 * TAIL_TILE * TL5_ROW * 2, "a branch's upper-half accumulators fit its l5 tile");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, kh = wv >> 2;         // eight waves: branch w, K half kh of its L5 product (k-steps 6kh .. 6kh + 5)
     const int l32 = lane & 31, hq = lane >> 5;
     const int n0 = blockIdx.x * TAIL_TILE;
 
-    // the first W5 fragments of this wave's branch are on their way before anything else: they stream from L2 PF - 1 k-steps ahead (a
-    // k-step is 6 KiB per wave; at one or two workgroups per CU only the bytes in flight hide the L2 latency); fully unrolled, static ring
-    const f16x8 *wp = (const f16x8 *)p.w5s + (size_t)w * (12 * 3 * 2 * 64) + lane;   // + ((ks*3 + nb)*2 + plane)*64
-    constexpr int PF = 5;
-    f16x8 wq[PF][3][2];
-#pragma unroll
-    for (int i = 0; i < PF - 1; ++i)
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wq[i][nb][pl] = wp[((i * 3 + nb) * 2 + pl) * 64];
-
+    // This kernel is a chain of dependent memory round trips on 32 CUs (nothing to hide them behind at one workgroup per CU), so it is built to
+    // make as few of them as it can: the split-K partials and the first four of the wave's six k-steps of W5 fragments leave together, the last
+    // two as soon as the partials' registers are free -- the whole weight stream of the L5 product is two round trips, the reduction one.
+    const f16x8 *wp = (const f16x8 *)p.w5s + ((size_t)w * 12 + 6 * kh) * (3 * 2 * 64) + lane;   // + ((i*3 + nb)*2 + plane)*64, i = k-step within the half
+    f16x8 wq[6][3][2];
     // L4: fixed-order reduction of the split-K partials, bias, selu, 2-way split.  A thread takes accumulator quads of the producing
     // kernel's layout -- 16-byte loads, a wave instruction one contiguous KiB.  This tile is candidate block mb of the 64-candidate block
-    // n0 / 64: quad (nh, nb, a) of lane ln holds candidates 8a + 4*(ln/32) + r of column 96nh + 32nb + ln%32: 24 quads x 64 lanes over 256
-    // threads = 6 per thread, three at a time with all 24 partial loads in flight (two memory round trips for the whole reduction).
+    // n0 / 64: quad (nh, nb, a) of lane ln holds candidates 8a + 4*(ln/32) + r of column 96nh + 32nb + ln%32: 24 quads x 64 lanes over 512
+    // threads = 3 per thread, all their partial loads in flight at once.
     {
         const int blk = n0 / L34_CAND, mb = (n0 >> 5) & 1, nblk = (p.n_pad + L34_CAND - 1) / L34_CAND;
+        constexpr int QB = L4_SPLITS <= 8 ? 3 : 1;          // quads per round
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 part[3][L4_SPLITS];
-            float b4[3];
+        for (int round = 0; round < 3 / QB; ++round) {
+            f32x4 part[QB][L4_SPLITS];
+            float b4[QB];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int f = tid + 256 * (3 * half + q);
+            for (int q = 0; q < QB; ++q) {
+                const int f = tid + TAIL_THREADS * (QB * round + q);
                 const int g = f >> 6, ln = f & 63, nh = g / 12, rem = g - nh * 12, nb = rem >> 2, a = rem & 3;
                 const size_t at = ((((size_t)blk * 2 + nh) * 6 + mb * 3 + nb) * 4 + a) * 256 + ln * 4;
 #pragma unroll
                 for (int sp = 0; sp < L4_SPLITS; ++sp) part[q][sp] = *(const f32x4 *)(p.l4part + (size_t)sp * nblk * (2 * 6 * 4 * 256) + at);
                 b4[q] = p.b4[nh * 96 + nb * 32 + (ln & 31)];
             }
+            if (round == 0) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int f = tid + 256 * (3 * half + q);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) wq[i][nb][pl] = wp[((i * 3 + nb) * 2 + pl) * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const int f = tid + TAIL_THREADS * (QB * round + q);
                 const int g = f >> 6, ln = f & 63, nh = g / 12, rem = g - nh * 12, nb = rem >> 2, a = rem & 3;
                 f32x4 s = part[q][0];
 #pragma unroll
@@ -428,32 +437,51 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
             }
         }
     }
+#pragma unroll
+    for (int i = 4; i < 6; ++i)
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wq[i][nb][pl] = wp[((i * 3 + nb) * 2 + pl) * 64];
     __syncthreads();
 
-    // L5 branch w, transposed: D[n][cand] = sum_k W5_w[k][n] l4[cand][k]: three 32-row blocks, 12 k-steps, three product terms (small ones first)
+    // L5 branch w, K half kh, transposed: D[n][cand] = sum_k W5_w[k][n] l4[cand][k]: three 32-row blocks, six k-steps, three product terms
+    // (small ones first).  Summation order of a branch (fixed): each half one MFMA chain over its k-steps, lower + upper half.
     f32x16 acc[3];
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) {
-        if (ks + PF - 1 < 12) {
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) wq[(ks + PF - 1) % PF][nb][pl] = wp[(((ks + PF - 1) * 3 + nb) * 2 + pl) * 64];
-        }
+    for (int i = 0; i < 6; ++i) {
         f16x8 b[2];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) b[pl] = *(const f16x8 *)&l4h[pl][l32][16 * ks + 8 * hq];
+        for (int pl = 0; pl < 2; ++pl) b[pl] = *(const f16x8 *)&l4h[pl][l32][16 * (6 * kh + i) + 8 * hq];
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[ks % PF][nb][1], b[0], acc[nb]);
+        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[i][nb][1], b[0], acc[nb]);
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[ks % PF][nb][0], b[1], acc[nb]);
+        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[i][nb][0], b[1], acc[nb]);
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[ks % PF][nb][0], b[0], acc[nb]);
+        for (int nb = 0; nb < 3; ++nb) acc[nb] = mfma32h(wq[i][nb][0], b[0], acc[nb]);
     }
+    // the upper half hands its accumulators to the lower half's wave through the branch's (still unused) l5 tile and is done
+    f32x4 *xch = (f32x4 *)&l5h[w][0][0][0] + lane;      // [nb*4 + a][lane]
+    if (kh) {
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xch[(nb * 4 + a) * 64] = (f32x4){acc[nb][4 * a], acc[nb][4 * a + 1], acc[nb][4 * a + 2], acc[nb][4 * a + 3]};
+    }
+    __syncthreads();
+    if (kh) return;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 up = xch[(nb * 4 + a) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nb][4 * a + r] += up[r];
+        }
     // the head's fragments on their way while the l5 tile is made: [ks][nb][plane]
     const int nh = w == 0 ? 21 : (w == 1 ? 3 : 33);
     const int off = w == 0 ? 0 : (w == 1 ? 21 : (w == 2 ? 24 : 57));
@@ -488,7 +516,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs p) {
                 *(uint2 *)&l5h[w][1][l32][u0] = lo;
             }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();       // the branch's l5 tile is written and read by this wave alone (LDS serves a wave in order)
 
     // head w, transposed: D[class][cand] = sum_k Wh_w[k][class] l5[cand][k], 6 k-steps; selu on the logits (model.py:586), softmax over the classes
     f32x16 hacc[2];

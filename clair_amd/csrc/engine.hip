@@ -44,8 +44,8 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
-// A LANE is what one forward pass in flight needs: a HIP stream for its kernels and the inter-kernel workspaces.  Three lanes fill the
-// chip (64 + 64 + 128 CUs: two recurrent kernels beside a projection GEMM); more only stretch every kernel (profiles/r02_stream_sweep.txt).
+// A LANE is what one forward pass in flight needs: a HIP stream for its kernels and the inter-kernel workspaces.  Three or four lanes fill
+// the chip (clair_engine_create: as many as the process has hardware queues to spare).
 struct Lane {
     hipStream_t stream = nullptr;
     float *zx = nullptr;      // fragment-major x-projection, reused by both layers
@@ -373,7 +373,7 @@ int enqueue_forward(clair_engine *e, Lane &s, const float *x_dev, float *out_dev
             a.l5_scale[k] = std::ldexp(1.0f, -e->w5_shift[k]) / TAIL_ACT_SCALE;
             a.head_scale[k] = std::ldexp(1.0f, -e->wh_shift[k]) / TAIL_ACT_SCALE;
         }
-        hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(256), 0, s.stream, a);
+        hipLaunchKernelGGL(tail_kernel, dim3(n_pad / TAIL_TILE), dim3(TAIL_THREADS), 0, s.stream, a);
     }
     HIP_TRY(e, hipGetLastError());
     return 0;
@@ -683,9 +683,13 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     // batches in flight on several slots the 64-workgroup recurrent kernels of the other slots hold whole CUs for ~80 us; a
     // 256-workgroup persistent GEMM then runs its last 64 workgroups as a second round on a quarter of the chip.  Four groups (128
     // workgroups) pack beside two recurrent kernels: +4 % whole-pipeline throughput at 3 slots (profiles/r01_microbench.txt).
-    int n_lanes = std::min(n_slots, 3);
+    // Lanes.  The runtime gives a process four hardware queues: FOUR forward passes in flight when nothing else needs one (a handle of up to four
+    // slots: clair_run_resident, clair_predict -- 8.05 against 7.89 M candidates/s with three, profiles/r04_lanes_sweep.txt; a fifth stream shares a
+    // queue with one of the four and sets the whole pipeline back, 6.5 M/s); THREE plus the incoming copy stream for a handle with more slots than
+    // that, i.e. one that is fed from the host with batches in flight on the link (four lanes there: 6.2 against 7.3 M/s).
+    int n_lanes = n_slots <= 4 ? n_slots : 3;
     { const char *t = getenv("CLAIR_AMD_LANES"); if (t && atoi(t) > 0) n_lanes = std::min(atoi(t), n_slots); }
-    e->proj2_groups = n_lanes > 1 ? 4 : 8;
+    e->proj2_groups = n_lanes >= 4 ? 3 : (n_lanes > 1 ? 4 : 8);       // four lanes: 96 workgroups (8.00 against 7.91 M/s with 128, profiles/r04_lanes_sweep.txt)
     { const char *t = getenv("CLAIR_AMD_PROJ2_GROUPS"); if (t && atoi(t) > 0) e->proj2_groups = atoi(t); }
     { const char *t = getenv("CLAIR_AMD_LSTM2_FUSED"); if (t && (t[0] == '0' || t[0] == '1')) e->lstm2_fused = t[0] - '0'; }
     { const char *t = getenv("CLAIR_AMD_FUSED_GROUPS"); if (t && atoi(t) > 0 && atoi(t) <= 8) e->fused_groups = atoi(t); }

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(TT_THREADS) void fe_tally_tile_kernel(Region g, Sla
     __shared__ uint2 list[TT_LIST];             // (alignment, its first operation that reaches into the tile)
     __shared__ uint32_t n_list;
     __shared__ TileOp opbuf[TT_WAVES][64];
+    __shared__ uint8_t evc_l[256], pile_l[256];  // the base tables and the tile's reference rows next to the counters: what a base needs besides its own byte
+    __shared__ uint8_t ref_l[TT_POS];            // is one LDS read away (from constant / global memory each is a dependent trip of its own)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the launch covers table tiles tile0 .. tile0 + gridDim.x - 1: where this slab's alignments lie (a guess is enough: the first and the last
     // workgroup own everything left / right of their tile, and tally what falls inside the tables but outside their LDS window straight into them)
@@ -204,6 +206,8 @@ __global__ __launch_bounds__(TT_THREADS) void fe_tally_tile_kernel(Region g, Sla
     const int64_t p_base = g.lo + t_lo;
     for (int i = tid; i < TT_POS * 4; i += TT_THREADS) pq_l[i] = 0ull;
     for (int i = tid; i < TT_POS * 8; i += TT_THREADS) misc_l[i] = 0u;
+    if (tid < 256) { evc_l[tid] = BASES.evc[tid]; pile_l[tid] = BASES.pile[tid]; }
+    else if (tid < 256 + TT_POS) ref_l[tid - 256] = ref_row(g, p_base + (tid - 256));
     // alignments that may reach into the tile: POS < p_hi, and POS + (longest reach of the slab) > p_lo
     const int64_t span = (int64_t)*slab_span;
     uint32_t ra = 0, rb = n_reads;
@@ -256,27 +260,34 @@ __global__ __launch_bounds__(TT_THREADS) void fe_tally_tile_kernel(Region g, Sla
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
                 const uint32_t total = __shfl(incl, 63);
                 opbuf[wave][lane] = TileOp{(int32_t)(start - p_base), op.code_len, op.q_off, incl - cnt, k0};
-                for (uint32_t e = (uint32_t)lane; e < total; e += 64) {
+                // an element in two steps, so that two of them are in flight per lane: find its operation (LDS) and fetch its read base; tally
+                struct Prep { int64_t lt; uint32_t oc, k, qp; uint8_t bs; };
+                auto prep = [&](uint32_t e) {
                     int a = 0, b = 64;                     // last operation whose first flat element is <= e (empty ones share their successor's `first`: take the last)
                     while (b - a > 1) { const int m = (a + b) >> 1; if (opbuf[wave][m].first <= e) a = m; else b = m; }
                     const TileOp o = opbuf[wave][a];
-                    const uint32_t oc = o.code_len & 3u, k = o.k0 + (e - o.first);
-                    const int64_t lt = (int64_t)o.rel + (oc == CLAIR_OP_I ? 0 : (int64_t)k);   // position relative to the tile (outside [0, TT_POS) only in the first / last workgroup)
-                    const int64_t t = t_lo + lt;
-                    const int64_t rp = p_base + lt;
-                    const uint32_t qp = o.q_off + (oc == CLAIR_OP_D ? 0u : k);
+                    Prep q;
+                    q.oc = o.code_len & 3u;
+                    q.k = o.k0 + (e - o.first);
+                    q.lt = (int64_t)o.rel + (q.oc == CLAIR_OP_I ? 0 : (int64_t)q.k);   // position relative to the tile (outside [0, TT_POS) only in the first / last workgroup)
+                    q.qp = o.q_off + (q.oc == CLAIR_OP_D ? 0u : q.k);
+                    q.bs = (q.oc != CLAIR_OP_D && q.qp < r.seq_len) ? s.seq[r.seq0 + q.qp] : (uint8_t)0;
+                    return q;
+                };
+                auto apply = [&](const Prep &q) {
+                    const int64_t lt = q.lt, t = t_lo + lt, rp = p_base + lt;
                     const bool inside = t >= 0 && t < g.n;
+                    auto row_of = [&](int64_t at, int64_t pos) -> uint8_t { return at >= 0 && at < TT_POS ? ref_l[at] : ref_row(g, pos); };
                     auto bump = [&](int64_t at, int word) {          // misc counter `word` of tile position `at`: the tile's copy, or the table itself
                         if (at >= 0 && at < TT_POS) atomicAdd(&misc_l[at * 8 + word], 1u); else atomicAdd(&g.misc[(t_lo + at) * 8 + word], 1u);
                     };
-                    if (oc == CLAIR_OP_M) {
-                        if (qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); continue; }
-                        if (pile && inside && ref_row(g, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
-                        const uint8_t bs = s.seq[r.seq0 + qp];
-                        const uint8_t ei = BASES.evc[bs];
-                        if (ei == 255) { flag(g, CLAIR_FE_BAD_BASE); continue; }
-                        if (!inside) continue;
-                        const int row = BASES.pile[bs];
+                    if (q.oc == CLAIR_OP_M) {
+                        if (q.qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); return; }
+                        if (pile && inside && row_of(lt, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
+                        const uint8_t ei = evc_l[q.bs];
+                        if (ei == 255) { flag(g, CLAIR_FE_BAD_BASE); return; }
+                        if (!inside) return;
+                        const int row = pile_l[q.bs];
                         unsigned long long add = pile ? 1ull << (so * PQ_BITS) : 0;
                         if (evc && ei < 4) add += 1ull << (2 * PQ_BITS);
                         if (add) {
@@ -288,19 +299,27 @@ __global__ __launch_bounds__(TT_THREADS) void fe_tally_tile_kernel(Region g, Sla
                         }
                         if (evc && ei >= 4) bump(lt, 7);
                         if (pile && rp == r.pos0) bump(lt, 4);
-                    } else if (oc == CLAIR_OP_I) {
-                        if (k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 5);   // once per operation, at the base before it
-                        if (!pile) continue;
-                        if (qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); continue; }
-                        if (rp <= r.pos0) continue;                                 // no window is open yet (CreateTensor.py:326-341)
-                        if (BASES.pile[s.seq[r.seq0 + qp]] == 255) flag(g, CLAIR_FE_BAD_BASE);
+                    } else if (q.oc == CLAIR_OP_I) {
+                        if (q.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 5);   // once per operation, at the base before it
+                        if (!pile) return;
+                        if (q.qp >= r.seq_len) { flag(g, CLAIR_FE_SEQ_OVERRUN); return; }
+                        if (rp <= r.pos0) return;                                   // no window is open yet (CreateTensor.py:326-341)
+                        if (pile_l[q.bs] == 255) flag(g, CLAIR_FE_BAD_BASE);
                         if (inside) bump(lt, 3);
                     } else {
-                        if (k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 6);
-                        if (!pile || !inside) continue;
-                        if (ref_row(g, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
+                        if (q.k == 0 && evc && t - 1 >= 0 && t - 1 < g.n) bump(lt - 1, 6);
+                        if (!pile || !inside) return;
+                        if (row_of(lt, rp) == 255) flag(g, CLAIR_FE_BAD_REF);
                         bump(lt, rp > r.pos0 ? so : 2);
                     }
+                };
+                for (uint32_t e = (uint32_t)lane; e < total; e += 128) {
+                    const Prep q0 = prep(e);
+                    const bool two = e + 64 < total;
+                    Prep q1 = q0;
+                    if (two) q1 = prep(e + 64);
+                    apply(q0);
+                    if (two) apply(q1);
                 }
                 if (__ballot(beyond || !valid)) break;      // the rest of the alignment lies beyond the tile (or there is no rest)
             }

@@ -84,8 +84,9 @@ typedef struct clair_engine clair_engine_t;
 /* -- lifetime: Clair() + Clair.init()  (clair/model.py:58-192, 807-813) ------------------------
  * device: HIP device ordinal.  max_batch: largest n accepted by one predict/submit.
  * n_slots: submits that may be pending at once (clair_submit* .. clair_wait); 1 is enough for the synchronous predict.  A slot owns the
- * input and output buffers of its batch on both sides of the host link.  The forward passes themselves run on min(n_slots, 3) compute
- * LANES (a HIP stream + the inter-kernel workspaces each: three passes in flight fill the chip), slot s on lane s % lanes; with twice as
+ * input and output buffers of its batch on both sides of the host link.  The forward passes themselves run on compute LANES (a HIP stream
+ * + the inter-kernel workspaces each): one per slot up to four slots (the process has four hardware queues), three for a handle with more
+ * slots (the fourth queue is the incoming copy stream's), slot s on lane s % lanes; with twice as
  * many slots as lanes a lane computes one batch of its slots while the copy engine brings the other one in, which is what takes the
  * host-array boundary from half of the HBM-resident rate to within a few per cent of it.  clair_run_resident(slot)
  * runs on the slot's lane. */

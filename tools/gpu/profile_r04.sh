@@ -10,7 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
 [ -f $O/pmc_traffic.json ] || cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json   # merged per batch size, copied back into profiles/ afterwards
 BATCH=1024; for a in "$@"; do [ "$prev" = "--batch" ] && BATCH=$a; prev=$a; done
-timeout 400 python $R/bench.py --steps $STEPS "$@" > $O/r04_${TAG}_bench.json 2> $O/r04_${TAG}_bench.err
 rm -rf $O/prof_r04_${TAG}
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_r04_${TAG} -o bench -- python $R/bench.py --steps $STEPS --no-cpu-baseline "$@" > $O/prof_r04_${TAG}.json 2> $O/prof_r04_${TAG}.log
 W=$(python -c "print(max(0, 256 - 8))")
@@ -23,5 +22,8 @@ python $R/tools/pmc_summary.py traffic $O/pmc_r04_${TAG}_FETCH_SIZE/bench_result
 rm -rf $O/pmc_r04_${TAG}_sq
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/pmc_r04_${TAG}_sq -o bench -- env BENCH_WARM_STEPS=0 CLAIR_AMD_LSTM2_FUSED=0 python $R/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline "$@" > $O/pmc_r04_${TAG}_sq.log 2>&1
 python $R/tools/pmc_summary.py mfma $O/pmc_r04_${TAG}_sq/bench_results.db --batch $BATCH --groups 8 > $O/r04_${TAG}_pmc_mfma_util.txt 2>&1
+# the bench line LAST: its `traffic` fields are reported only from a table measured on exactly these kernel sources, i.e. the passes above
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+timeout 400 python $R/bench.py --steps $STEPS "$@" > $O/r04_${TAG}_bench.json 2> $O/r04_${TAG}_bench.err
 cd $R
 head -c 600 $O/r04_${TAG}_bench.json; echo; tail -12 $O/r04_${TAG}_kernel_stats.txt; cat $O/r04_${TAG}_pmc_hbm_traffic.txt $O/r04_${TAG}_pmc_mfma_util.txt
