@@ -503,6 +503,11 @@ def run_ranked(args, group, json_fd):
             "executed_note": "matmuls run as a 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
             "alone_kernel_ms": round(alone_ms[dom], 5), "alone_frac": round(tf_alone / PEAK_F16_MFMA_TFLOPS, 4),
             "workgroups": wgs[dom], "cu_share": round(cu_share[dom], 4),
+            "frac_of_cus_held": round(tf / PEAK_F16_MFMA_TFLOPS / max(cu_share[dom], 1e-9), 4),
+            "in_flight_note": "`frac` divides by the peak of the WHOLE chip and by a duration measured while %d forward passes share it: a launch that holds "
+                              "%d of the 256 CUs and waits for them behind the other lanes' kernels reads low by construction (3 lanes: shorter launches, lower "
+                              "throughput; profiles/r04_lanes_sweep.txt).  `frac_of_cus_held` = frac / cu_share; `alone_frac` = the same launch with the chip to "
+                              "itself; `roofline_path` = the whole pass against the same peak, which is the figure that moves with `value`" % (streams, min(wgs[dom], 256)),
             "hbm_gbs_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9, 1) if traffic else None,
             "hbm_frac_measured_traffic": round(traffic / (dom_ms_mean * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None,
             "design_bytes_per_launch": design[dom] * batch,

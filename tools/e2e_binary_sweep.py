@@ -16,7 +16,7 @@ from clair_amd import synth, tensor_binary, weights
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
 sizes = [int(a) for a in sys.argv[2:]] or [1024, 4096]
 os.makedirs("gpurun_out", exist_ok=True)
-prefix = "gpurun_out/e2e_model"
+prefix = "/tmp/e2e_model"
 weights.save_weights(prefix, weights.synthetic_weights(seed=20250928, head_gain=4.0))
 base = min(n, 200000)
 raw, infos = synth.synthetic_candidates(base, "ont", seed=77)

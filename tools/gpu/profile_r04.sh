@@ -22,6 +22,7 @@ python $R/tools/pmc_summary.py traffic $O/pmc_r04_${TAG}_FETCH_SIZE/bench_result
 rm -rf $O/pmc_r04_${TAG}_sq
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $O/pmc_r04_${TAG}_sq -o bench -- env BENCH_WARM_STEPS=0 CLAIR_AMD_LSTM2_FUSED=0 python $R/bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline "$@" > $O/pmc_r04_${TAG}_sq.log 2>&1
 python $R/tools/pmc_summary.py mfma $O/pmc_r04_${TAG}_sq/bench_results.db --batch $BATCH --groups 8 > $O/r04_${TAG}_pmc_mfma_util.txt 2>&1
+rm -rf $O/prof_r04_${TAG} $O/pmc_r04_${TAG}_FETCH_SIZE $O/pmc_r04_${TAG}_WRITE_SIZE $O/pmc_r04_${TAG}_sq     # the tables above are what is kept (gpurun_out/ comes back only below 64 MiB)
 # the bench line LAST: its `traffic` fields are reported only from a table measured on exactly these kernel sources, i.e. the passes above
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
 timeout 400 python $R/bench.py --steps $STEPS "$@" > $O/r04_${TAG}_bench.json 2> $O/r04_${TAG}_bench.err
