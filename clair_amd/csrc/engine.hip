@@ -122,6 +122,7 @@ struct clair_engine {
     std::vector<std::unique_ptr<Lane>> lanes;
     std::vector<hipStream_t> copy_streams;   // owned here; the slots point into it
     int copy_mode = 3;                  // CLAIR_AMD_COPY_STREAMS=slot|two|lane|in (0, 1, 2, 3): see clair_engine_create
+    bool convert_on_lane = true;        // CLAIR_AMD_CONVERT=copy: the int16 -> float32 conversion behind the copy on the incoming stream instead of on the lane
     bool d2h_kernel = true;             // CLAIR_AMD_D2H=sdma: results fetched by the copy engine instead of written to page-locked host memory by a kernel
     // the staging worker (clair_submit* on pageable memory): the copy of the caller's batch into page-locked memory and the enqueue of its
     // transfers and kernels run on this thread, so that the submitting thread is free after a few microseconds, as the reference's
@@ -562,18 +563,25 @@ int enqueue_request(clair_engine *e, int slot_index, const clair_engine::Request
         memcpy(s.h_centre, q.centre, (size_t)n * 2);
         HIP_TRY(e, hipMemcpyAsync(s.d_centre, s.h_centre, (size_t)n * 2, hipMemcpyHostToDevice, s.cin));
     }
-    {   // int16 counts -> the float32 tensor: behind the copy on the incoming stream, i.e. off the lane, which is computing another batch
+    // int16 counts -> the float32 tensor.  On the LANE, in front of LSTM1 (default): a kernel of 1 056 small workgroups on the incoming stream has to
+    // find CUs of its own among lanes whose recurrent workgroups hold whole CUs (one wave per SIMD, every register), and now and then it waits for
+    // them long enough to leave a lane without input -- 5.3-5.5 instead of 7.2-7.6 M candidates/s in one run out of four (profiles/r04_convert_stream.txt);
+    // on the lane it costs its own ~4 us per pass and nothing else.  CLAIR_AMD_CONVERT=copy puts it back behind the copy.
+    auto launch_convert = [&](hipStream_t st) {
         const int n_quads = n * (CLAIR_INPUT_FLOATS / 4);
         if (convert == DENSE)
-            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.cin, (const short4 *)convert_from, (f32x4 *)s.d_x, n_quads);
+            hipLaunchKernelGGL(counts_to_input_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, st, (const short4 *)convert_from, (f32x4 *)s.d_x, n_quads);
         else if (convert == STRIDED)
-            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, s.cin, convert_from, stride, (f32x4 *)s.d_x, n_quads);
-    }
+            hipLaunchKernelGGL(counts_to_input_strided_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, st, convert_from, stride, (f32x4 *)s.d_x, n_quads);
+    };
+    const bool convert_on_lane = e->convert_on_lane && !same_in;
+    if (!convert_on_lane) launch_convert(s.cin);
     if (!same_in) HIP_TRY(e, hipEventRecord(s.ev_in, s.cin));
     {
         std::unique_lock<std::mutex> g(l.order, std::defer_lock);
         if (!same_in) g.lock();
         if (!same_in) HIP_TRY(e, hipStreamWaitEvent(l.stream, s.ev_in, 0));
+        if (convert_on_lane) launch_convert(l.stream);
         if (enqueue_forward(e, l, s.d_x, s.d_out, n, slot_index)) return 1;
         if (q.calls && enqueue_decode(e, l, s, n)) return 1;
         if (same_out) return enqueue_results(e, l, s, n, q.calls != nullptr, want_probs);      // in line with the kernels, under the lane's lock
@@ -699,6 +707,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
     { const char *t = getenv("CLAIR_AMD_ASYNC_STAGING"); if (t && t[0] == '0') e->staging_threads = 0; }
     { const char *t = getenv("CLAIR_AMD_COPY_STREAMS"); if (t) e->copy_mode = !strcmp(t, "slot") ? 0 : !strcmp(t, "two") ? 1 : !strcmp(t, "lane") ? 2 : 3; }
     { const char *t = getenv("CLAIR_AMD_D2H"); if (t) e->d2h_kernel = !strcmp(t, "kernel"); }
+    { const char *t = getenv("CLAIR_AMD_CONVERT"); if (t) e->convert_on_lane = strcmp(t, "copy") != 0; }
     for (int i = 0; i < n_lanes; ++i) e->lanes.emplace_back(new Lane());
     e->slots.resize(n_slots);
     const size_t mp = e->max_pad;
