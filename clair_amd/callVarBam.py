@@ -661,7 +661,7 @@ def normalise(args):
 
 def load_model(args):
     from .model import Clair
-    batch = args.batch_size or param.predictBatchSize
+    batch = args.batch_size or param.engineBatchSize
     try:
         m = Clair(device=args.device, max_batch=batch, n_slots=param.pipeline_slots())
         m.init()
@@ -688,7 +688,7 @@ def call_region(args, m, prepared=None):
     writer = cv.VcfWriter(args.call_fn, args.sampleName, args.ref_fn, args.output_for_ensemble)
     device_fe = prepared
     try:
-        batch = args.batch_size or param.predictBatchSize
+        batch = args.batch_size or param.engineBatchSize
         source = None
         workers, lo, hi = front_end_workers(args)
         if wants_device_front_end(args):
@@ -766,7 +766,7 @@ def build_parser():
     add('-w', '--workers', type=int, default=8, help="kept for flag compatibility")
     add('--output_for_ensemble', action='store_true', help="write probabilities for ensembling instead of a VCF")
     # additions of this implementation
-    add('--batch_size', type=int, default=None, help="candidates per forward pass, default: %d" % param.predictBatchSize)
+    add('--batch_size', type=int, default=None, help="candidates per forward pass, default: %d" % param.engineBatchSize)
     add('--front_end_workers', type=int, default=None,
         help="run the candidate search and the pileup over this many consecutive sub-ranges at once (threads, one pair of samtools streams each; "
              "0 = half the usable CPUs, at most 8; at least 50 kb per sub-range).  Default 1: the single pass.  The split run yields the single "

@@ -821,7 +821,7 @@ def Run(args):
             # (clair/model.py:1053-1062), so log_activation returns immediately (call_var.py:1239-1245)
             return
         from clair_amd.model import Clair
-        batch = args.batch_size or param.predictBatchSize
+        batch = args.batch_size or param.engineBatchSize
         try:
             m = Clair(device=args.device, max_batch=batch, n_slots=param.pipeline_slots())
             m.init()
@@ -871,7 +871,7 @@ def build_parser():
     parser.add_argument('--output_for_ensemble', action='store_true', help="Output for ensemble")
     # additions of this implementation
     parser.add_argument('--batch_size', type=int, default=None,
-                        help="Candidates per forward pass, default: %d" % param.predictBatchSize)
+                        help="Candidates per forward pass, default: %d" % param.engineBatchSize)
     parser.add_argument('--device', type=int, default=0, help="HIP device ordinal, default: %(default)s")
     parser.add_argument('--arith', type=str, default="legacy", choices=("legacy", "numpy2"),
                         help="QUAL/AF arithmetic: float64 as under the reference's NumPy 1.x (legacy) or float32 (numpy2)")

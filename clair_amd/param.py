@@ -8,6 +8,9 @@ flankingBaseNum = 16        # shared/param.py:9
 matrixRow = 8               # shared/param.py:10
 matrixNum = 4               # shared/param.py:11
 predictBatchSize = 1000     # shared/param.py:16
+engineBatchSize = 4096      # candidates per forward pass when --batch_size is not given: results do not depend on it, and at the reference's 1 000 the
+                            # host side of call_var (queues, ctypes calls, one NumPy view per batch) keeps the engine at half its rate
+                            # (3.0-4.1 against 5.3-6.7 M candidates/s inside call_variants, profiles/r04_e2e_binary.txt)
 no_of_positions = 2 * flankingBaseNum + 1
 input_tensor_size = no_of_positions * matrixRow * matrixNum  # 1056
 
