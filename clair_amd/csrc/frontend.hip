@@ -465,7 +465,10 @@ struct Candidates {
     // --stop_consider_left_edge only (NULL otherwise): what reads that START inside a window added to the tables under it -- per
     // window and column 8 read-base rows, M per strand, D per strand -- and the tuples per window as range additions over the index
     uint32_t *late;              // [n_candidates][33][12]
-    int *tuple_diff;             // [n_candidates + 1]
+    int *tuple_diff;             // [n_candidates + 1]  (per-base pass 2, CLAIR_AMD_FE_PASS2=base: range additions over the candidate index)
+    // per-operation pass 2: the same totals as SECOND differences over the centre value u (index u - lo, n + 2 entries; 64-bit two's complement):
+    // tuples(u) = sum over p <= u of (u - p + 1) d2[p]; what falls left of the tables goes into fold[0] = sum v, fold[1] = sum v p
+    unsigned long long *d2, *fold;
 };
 constexpr int LATE_ROW = 12;
 
@@ -598,6 +601,162 @@ __global__ __launch_bounds__(256) void fe_windows_per_op_kernel(Region g, SlabVi
         if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned long long *)&s.tuples[r], v);
         todo &= ~__ballot(mine);
     }
+}
+
+// ---- pass 2 WITHOUT left-edge windows, per operation (round 4; per base: fe_windows_per_base_kernel above, kept as the checker) ----
+// A base at rp of an alignment that starts at POS lies in the windows of centres u in [max(rp - 17, POS + 17), rp + 17] (rp + 16 for a deleted
+// or inserted base): the lower clamp is "a read opens only the windows whose first column it walks".  Per operation over rp = A..B:
+//   * the alignment's tuple count is again a difference of running sums of the candidate prefix, the clamped part (rp < POS + 34) a
+//     multiple of one prefix value;
+//   * the tuples PER WINDOW are a trapezoid over u (a ramp of min(length, window width) centres up, a plateau, the same ramp down), cut off
+//     below POS + 17: six second-difference entries over the centre VALUE instead of two range additions per base over the candidate index;
+//     two running sums over the positions and a gather at the centres give the totals (fe_tuple_scan_*, fe_window_totals_at_kernel).
+__device__ inline void d2_add(const Region &g, const Candidates &c, int64_t u, long long v) {
+    const int64_t i = u - g.lo;
+    if (i < 0) { atomicAdd(&c.fold[0], (unsigned long long)v); atomicAdd(&c.fold[1], (unsigned long long)(v * u)); }
+    else if (i <= g.n + 1) atomicAdd(&c.d2[i], (unsigned long long)v);
+}
+// tuples a run of bases rp = A..B adds to the window of centre u, for u >= c0: #{rp: rp - 17 <= u <= rp + reach}
+__device__ inline void d2_add_run(const Region &g, const Candidates &c, int64_t A, int64_t B, int reach, int64_t c0) {
+    if (B < A || B + reach < c0) return;
+    const int64_t L = B - A + 1, W = 17 + reach + 1, m = L < W ? L : W;
+    int64_t from = INT64_MIN / 4;
+    if (A - 17 < c0) {            // the window of c0 and its right neighbours only: a step up to T(c0), then the rest of the shape
+        const int64_t hi = B < c0 + 17 ? B : c0 + 17, lo = A > c0 - reach ? A : c0 - reach;
+        const long long t0 = hi >= lo ? hi - lo + 1 : 0;
+        if (t0) { d2_add(g, c, c0, t0); d2_add(g, c, c0 + 1, -t0); }
+        from = c0 + 1;
+    }
+    const int64_t u0 = A - 17 > from ? A - 17 : from, u1 = A - 17 + m - 1;            // first differences +1
+    if (u0 <= u1) { d2_add(g, c, u0, 1); d2_add(g, c, u1 + 1, -1); }
+    const int64_t w0 = B + reach + 2 - m > from ? B + reach + 2 - m : from, w1 = B + reach + 1;   // first differences -1
+    if (w0 <= w1) { d2_add(g, c, w0, -1); d2_add(g, c, w1 + 1, 1); }
+}
+
+__global__ __launch_bounds__(256) void fe_windows_per_op_noleft_kernel(Region g, SlabView s, Candidates c) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    uint32_t read = 0xffffffffu;
+    unsigned long long nc = 0;
+    if (j < s.n_ops) {
+        const clair_op_t op = s.ops[j];
+        const clair_read_t r = s.reads[op.read];
+        if (r.flags & CLAIR_READ_PILE) {
+            read = op.read;
+            const uint32_t code = op.code_len & 3u;
+            const int64_t len = op.code_len >> 2, pos0 = r.pos0, c0 = pos0 + 17;
+            int64_t a = pos0 + op.ref_off, b = a + len - 1;          // first and last reference position of the run (I: both the same)
+            auto below = [&](int64_t A, int64_t B) -> unsigned long long {      // sum over rp = A..B of the prefix at max(rp - 18, POS + 16)
+                unsigned long long v = 0;
+                const int64_t r1 = B < pos0 + 33 ? B : pos0 + 33;
+                if (r1 >= A) v += (unsigned long long)(r1 - A + 1) * before_at(g, c, pos0 + 16 - g.lo);
+                const int64_t a2 = A > pos0 + 34 ? A : pos0 + 34;
+                if (B >= a2) v += prefix_sum_at(g, c, B - 18) - prefix_sum_at(g, c, a2 - 19);
+                return v;
+            };
+            if (code == CLAIR_OP_M) {
+                nc += (prefix_sum_at(g, c, b + 17) - prefix_sum_at(g, c, a + 16)) - below(a, b);
+                d2_add_run(g, c, a, b, 17, c0);
+            } else if (code == CLAIR_OP_D) {
+                if (a == pos0) ++a;                                    // offered before any window is open
+                if (b >= a) {
+                    nc += (prefix_sum_at(g, c, b + 16) - prefix_sum_at(g, c, a + 15)) - below(a, b);
+                    d2_add_run(g, c, a, b, 16, c0);
+                }
+            } else if (a > pos0) {
+                const int64_t lo_u = a - 17 > c0 ? a - 17 : c0;
+                if (lo_u <= a + 16) {
+                    nc += (unsigned long long)len * (before_at(g, c, a + 16 - g.lo) - before_at(g, c, lo_u - 1 - g.lo));
+                    d2_add(g, c, lo_u, len); d2_add(g, c, lo_u + 1, -len);
+                    d2_add(g, c, a + 17, -len); d2_add(g, c, a + 18, len);
+                }
+                const int so = (r.flags & CLAIR_READ_REVERSE) ? 4 : 0;
+                const int64_t first = a - 15 > c0 ? a - 15 : c0;
+                const uint32_t i0 = before_at(g, c, first - 1 - g.lo), i1 = before_at(g, c, a + 16 - g.lo);
+                for (int64_t k = 0; k < len && i1 > i0; ++k) {         // generate_tensor :51-53: column min(idx + k, 32), channel 1
+                    if (op.q_off + k >= r.seq_len) break;
+                    const uint8_t row = BASES.pile[s.seq[r.seq0 + op.q_off + k]];
+                    if (row == 255) continue;
+                    for (uint32_t i = i0; i < i1; ++i) {
+                        const int64_t col = a - c.centre[i] + 17 + k;
+                        atomicAdd(&c.ins[((size_t)i * N_POS + (col < N_POS - 1 ? col : N_POS - 1)) * N_ROW + row + so], 1u);
+                    }
+                }
+            }
+        }
+    }
+    unsigned long long todo = __ballot(nc != 0);                       // one atomic per run of equal reads in the wave
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t r = __shfl(read, leader, 64);
+        const bool mine = nc != 0 && read == r;
+        unsigned long long v = mine ? nc : 0;
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned long long *)&s.tuples[r], v);
+        todo &= ~__ballot(mine);
+    }
+}
+
+// what the first 32 walked positions of an alignment put into the tables belongs to none of the windows it starts inside (centres rp - 15 ..
+// POS + 16): collected per window and column, the assembly takes it out again.  One thread per alignment: at most 32 positions of it.
+__global__ __launch_bounds__(256) void fe_late_starters_kernel(Region g, SlabView s, Candidates c, uint32_t n_reads) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_reads) return;
+    const clair_read_t r = s.reads[i];
+    if (!(r.flags & CLAIR_READ_PILE)) return;
+    const int so = (r.flags & CLAIR_READ_REVERSE) ? 4 : 0;
+    const uint32_t j1 = before_at(g, c, r.pos0 + 16 - g.lo);
+    for (uint32_t o = 0; o < r.n_ops; ++o) {
+        const clair_op_t op = s.ops[r.op0 + o];
+        if (op.ref_off > 31) break;
+        const uint32_t code = op.code_len & 3u;
+        if (code == CLAIR_OP_I) continue;
+        const int64_t len = op.code_len >> 2;
+        for (int64_t k = 0; k < len && op.ref_off + k <= 31; ++k) {
+            const int64_t rp = r.pos0 + op.ref_off + k;
+            if (code == CLAIR_OP_D && rp <= r.pos0) continue;
+            uint8_t row = 255;
+            if (code == CLAIR_OP_M) {
+                const uint32_t qp = op.q_off + (uint32_t)k;
+                if (qp < r.seq_len) row = BASES.pile[s.seq[r.seq0 + qp]];
+                if (row == 255) continue;
+            }
+            for (uint32_t j = before_at(g, c, rp - 15 - 1 - g.lo); j < j1; ++j) {
+                uint32_t *cell = c.late + ((size_t)j * N_POS + (rp - c.centre[j] + 17)) * LATE_ROW;
+                if (code == CLAIR_OP_M) { atomicAdd(cell + row + so, 1u); atomicAdd(cell + 8 + (so >> 2), 1u); }
+                else atomicAdd(cell + 10 + (so >> 2), 1u);
+            }
+        }
+    }
+}
+
+__device__ inline unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long *total);   // below, with the candidate prefix's running sum
+
+// running sums of a 64-bit array in place, twice in a row: d2 -> first differences (seeded with fold[0]) -> tuples per centre value (seeded with
+// the tuples of u = lo - 1: lo fold[0] - fold[1]).  Two's complement throughout: signed sums come out right modulo 2^64.
+__global__ __launch_bounds__(256) void fe_tuple_scan_sums_kernel(const unsigned long long *v, int64_t n, unsigned long long *block_sum) {
+    const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long x = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (at + i < n) x += v[at + i];
+    unsigned long long total;
+    (void)block_exclusive_scan64(x, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void fe_tuple_scan_write_kernel(unsigned long long *v, int64_t n, const unsigned long long *block_sum, const unsigned long long *fold,
+                                                                  int second, int64_t lo) {
+    const int64_t at = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long f[SCAN_ITEMS], x = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) { f[i] = at + i < n ? v[at + i] : 0; x += f[i]; }
+    unsigned long long total;
+    const unsigned long long seed = second ? (unsigned long long)lo * fold[0] - fold[1] : fold[0];
+    unsigned long long run = seed + block_sum[blockIdx.x] + block_exclusive_scan64(x, &total);
+    for (int i = 0; i < SCAN_ITEMS && at + i < n; ++i) { run += f[i]; v[at + i] = run; }
+}
+__global__ __launch_bounds__(256) void fe_window_totals_at_kernel(const unsigned long long *tuples_at, const int64_t *centre, int64_t n_candidates, int64_t lo, int64_t n,
+                                                                  uint64_t *window_tuples) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_candidates) return;
+    const int64_t at = centre[i] - lo;
+    window_tuples[i] = at >= 0 && at <= n + 1 ? tuples_at[at] : 0;
 }
 
 // before[0..n] -> before_sum (inclusive running sum, 64 bit): block sums, one workgroup over them, write
@@ -1059,6 +1218,8 @@ struct clair_frontend {
     TextState text_state{};
     TextState *d_text_state = nullptr;
     uint32_t *d_span = nullptr;          // the longest reference reach of the slab being tallied (fe_slab_span_kernel)
+    unsigned long long *d_d2 = nullptr, *d_fold = nullptr;   // --stop_consider_left_edge, pass 2 per operation: tuples per window as second differences over positions
+    bool pass2_per_base = false;         // CLAIR_AMD_FE_PASS2=base when the handle was created: --stop_consider_left_edge's pass 2 by fe_windows_per_base_kernel
     bool tally_per_base = false;         // CLAIR_AMD_FE_TALLY=atomic when the handle was created: pass 1 by fe_tally_kernel (one device atomic per base)
     std::string error;
 
@@ -1163,6 +1324,7 @@ int clair_frontend_create(int device, const char *ref_seq, int64_t ref_len, int6
     if (device < 0 || device >= n_dev) return fe_fail(nullptr, "device %d out of range [0,%d)", device, n_dev);
     clair_frontend *f = new clair_frontend;
     { const char *t = getenv("CLAIR_AMD_FE_TALLY"); f->tally_per_base = t && !strcmp(t, "atomic"); }
+    { const char *t = getenv("CLAIR_AMD_FE_PASS2"); f->pass2_per_base = t && !strcmp(t, "base"); }
     f->device = device;
     auto bail = [&](const char *what, hipError_t err) {
         fe_fail(nullptr, "%s failed: %s", what, hipGetErrorString(err));
@@ -1206,7 +1368,7 @@ void clair_frontend_destroy(clair_frontend_t *f) {
     free_candidates(f);
     (void)hipFree(f->d_ref); (void)hipFree(f->g.pq); (void)hipFree(f->g.misc); (void)hipFree(f->g.anomalies);
     (void)hipFree(f->d_flags); (void)hipFree(f->d_before); (void)hipFree(f->d_block_sum); (void)hipFree(f->d_total); (void)hipFree(f->d_bed);
-    (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state); (void)hipFree(f->d_span);
+    (void)hipFree(f->d_ctg); (void)hipFree(f->d_text_state); (void)hipFree(f->d_span); (void)hipFree(f->d_d2); (void)hipFree(f->d_fold);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
@@ -1498,26 +1660,50 @@ int clair_frontend_build_windows_ex(clair_frontend_t *f, int min_coverage, int d
         FE_TRY(f, hipMemsetAsync(f->d_tuple_diff, 0, ((size_t)room + 1) * sizeof(int), f->stream));
     }
     uint32_t *late = consider_left_edge ? nullptr : f->d_late;
-    if (consider_left_edge && nc) {      // the running sum of the candidate prefix: what lets pass 2 go operation by operation
+    const bool per_op = consider_left_edge || !f->pass2_per_base;
+    const int64_t m2 = f->g.n + 2;
+    if (per_op && nc) {      // the running sum of the candidate prefix: what lets pass 2 go operation by operation
         const int64_t m = f->g.n + 1;
-        const unsigned nb = blocks_for(m, SCAN_BLOCK);
+        const unsigned nb = blocks_for(m2, SCAN_BLOCK);
         if (!f->d_before_sum) {
             FE_TRY(f, hipMalloc((void **)&f->d_before_sum, (size_t)m * sizeof(unsigned long long)));
             FE_TRY(f, hipMalloc((void **)&f->d_prefix_block_sum, ((size_t)nb + 1) * sizeof(unsigned long long)));
         }
-        hipLaunchKernelGGL(fe_prefix_block_sums_kernel, dim3(nb), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, f->d_prefix_block_sum);
-        hipLaunchKernelGGL(fe_prefix_scan_sums_kernel, dim3(1), dim3(256), 0, f->stream, f->d_prefix_block_sum, (int64_t)nb);
-        hipLaunchKernelGGL(fe_prefix_write_kernel, dim3(nb), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, (const unsigned long long *)f->d_prefix_block_sum, f->d_before_sum);
+        hipLaunchKernelGGL(fe_prefix_block_sums_kernel, dim3(blocks_for(m, SCAN_BLOCK)), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, f->d_prefix_block_sum);
+        hipLaunchKernelGGL(fe_prefix_scan_sums_kernel, dim3(1), dim3(256), 0, f->stream, f->d_prefix_block_sum, (int64_t)blocks_for(m, SCAN_BLOCK));
+        hipLaunchKernelGGL(fe_prefix_write_kernel, dim3(blocks_for(m, SCAN_BLOCK)), dim3(256), 0, f->stream, (const uint32_t *)f->d_before, m, (const unsigned long long *)f->d_prefix_block_sum, f->d_before_sum);
+        if (!consider_left_edge) {
+            if (!f->d_d2) {
+                FE_TRY(f, hipMalloc((void **)&f->d_d2, (size_t)m2 * sizeof(unsigned long long)));
+                FE_TRY(f, hipMalloc((void **)&f->d_fold, 2 * sizeof(unsigned long long)));
+            }
+            FE_TRY(f, hipMemsetAsync(f->d_d2, 0, (size_t)m2 * sizeof(unsigned long long), f->stream));
+            FE_TRY(f, hipMemsetAsync(f->d_fold, 0, 2 * sizeof(unsigned long long), f->stream));
+        }
     }
-    Candidates c{f->d_centre, f->d_before, f->d_ins, f->d_before_sum, late, consider_left_edge ? nullptr : f->d_tuple_diff};
+    Candidates c{f->d_centre, f->d_before, f->d_ins, f->d_before_sum, late, consider_left_edge ? nullptr : f->d_tuple_diff, f->d_d2, f->d_fold};
     for (Slab &s : f->slabs) {
         FE_TRY(f, hipMemsetAsync(s.tuples, 0, (size_t)s.n_reads * sizeof(uint64_t), f->stream));
         if (!s.n_elem || !nc) continue;
         if (consider_left_edge) hipLaunchKernelGGL(fe_windows_per_op_kernel, dim3(blocks_for(s.n_ops, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
-        else hipLaunchKernelGGL(fe_windows_per_base_kernel, dim3(blocks_for(s.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
+        else if (per_op) {
+            hipLaunchKernelGGL(fe_windows_per_op_noleft_kernel, dim3(blocks_for(s.n_ops, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
+            hipLaunchKernelGGL(fe_late_starters_kernel, dim3(blocks_for(s.n_reads, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c, (uint32_t)s.n_reads);
+        } else hipLaunchKernelGGL(fe_windows_per_base_kernel, dim3(blocks_for(s.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(s), c);
+    }
+    if (nc && late && per_op) {          // second differences -> first differences -> tuples per centre value -> per window
+        const unsigned nb = blocks_for(m2, SCAN_BLOCK);
+        for (int second = 0; second < 2; ++second) {
+            hipLaunchKernelGGL(fe_tuple_scan_sums_kernel, dim3(nb), dim3(256), 0, f->stream, (const unsigned long long *)f->d_d2, m2, f->d_prefix_block_sum);
+            hipLaunchKernelGGL(fe_prefix_scan_sums_kernel, dim3(1), dim3(256), 0, f->stream, f->d_prefix_block_sum, (int64_t)nb);
+            hipLaunchKernelGGL(fe_tuple_scan_write_kernel, dim3(nb), dim3(256), 0, f->stream, f->d_d2, m2, (const unsigned long long *)f->d_prefix_block_sum,
+                               (const unsigned long long *)f->d_fold, second, f->g.lo);
+        }
+        hipLaunchKernelGGL(fe_window_totals_at_kernel, dim3(blocks_for(nc, 256)), dim3(256), 0, f->stream, (const unsigned long long *)f->d_d2, (const int64_t *)f->d_centre, nc,
+                           f->g.lo, f->g.n, f->d_window_tuples);
     }
     WindowRule rule{min_coverage, drop_non_iupac_centre, late};
-    if (nc && late) hipLaunchKernelGGL(fe_window_totals_kernel, dim3(1), dim3(256), 0, f->stream, (const int *)f->d_tuple_diff, nc, f->d_window_tuples);
+    if (nc && late && !per_op) hipLaunchKernelGGL(fe_window_totals_kernel, dim3(1), dim3(256), 0, f->stream, (const int *)f->d_tuple_diff, nc, f->d_window_tuples);
     if (nc) hipLaunchKernelGGL(fe_window_flags_kernel, dim3(blocks_for(nc, 256)), dim3(256), 0, f->stream, f->g, (const int64_t *)f->d_centre, nc, rule, f->d_keep, f->d_window_tuples);
     FE_TRY(f, hipGetLastError());
     int64_t kept = 0;

@@ -129,6 +129,40 @@ def test_tiled_tally_equals_the_per_base_tally(margin, text, monkeypatch):
         assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2])) and np.array_equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("inner", [False, True], ids=["whole_span", "tables_start_inside_the_reads"])
+def test_pass_two_per_operation_without_left_edge_windows_equals_the_per_base_pass(inner, monkeypatch):
+    """--stop_consider_left_edge: tuples per alignment from running sums of the candidate prefix, tuples per window as second differences over the
+    centre value (two running sums, a gather), late starters per alignment -- against the per-base kernel (CLAIR_AMD_FE_PASS2=base) and the
+    sequential stage.  With the tables starting INSIDE the alignments (a region of a larger run) the trapezoids that begin left of the tables
+    go through the fold."""
+    for seed, kw in ((8, dict(n_reads=900, ref_len=4000, ins_rate=0.12, del_rate=0.1, cand_step=(1, 6))),
+                     (9, dict(n_reads=1500, ref_len=20000, read_len=(200, 3000), cand_step=(1, 30))),
+                     (5, dict(n_reads=600, ref_len=3000, dup_burst=6))):
+        case = fc.synth(seed, **kw)
+        lo, hi = (case["ref0"] + 700, case["ref0"] + len(case["ref"]) - 600) if inner else (case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
+        cands = case["candidates"][(case["candidates"] > lo + 40) & (case["candidates"] < hi - 40)]
+        hc, hs, hcounts = fc.host_windows(case, candidates=cands, consider_left_edge=False)
+        got = {}
+        for mode in ("base", "op"):
+            if mode == "base":
+                monkeypatch.setenv("CLAIR_AMD_FE_PASS2", "base")
+            else:
+                monkeypatch.delenv("CLAIR_AMD_FE_PASS2", raising=False)
+            f = _capi.Frontend(0, case["ref"], case["ref0"], lo, hi)
+            p = _hostapi.SamPacker(case["ctg"])
+            assert p.feed(case["sam"], final=True) == b""
+            f.add_slab(p)
+            f.set_candidates(cands)
+            f.build_windows(min_coverage=0, drop_non_iupac_centre=False, consider_left_edge=False)
+            assert f.stats()["anomalies"] == 0
+            got[mode] = (windows_of(f), f.read_tuples(0), f.window_tuples())
+            f.close()
+        a, b = got["base"], got["op"]
+        assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0])) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1]) and int(b[2][1].sum()) > 0
+        assert np.array_equal(hc, b[0][0]) and np.array_equal(hs, b[0][1]) and np.array_equal(hcounts, b[0][2]) and len(hc) > 50
+
+
 def test_candidates_then_windows_equal_the_two_sequential_stages():
     """The whole front end: one packed stream, candidate search on the tallies, windows at those candidates -- against the finder and the
     builder run one after the other on the text, with a region (the two stages then see different alignments) and a bed file."""
