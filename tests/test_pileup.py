@@ -484,3 +484,16 @@ def test_submodule_dispatcher():
     assert r.returncode != 0 and "outside this build" in r.stderr
     r = subprocess.run([sys.executable, "-m", "clair_amd", "nope"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode != 0 and "not found" in r.stderr
+
+
+def test_set_order_follows_the_interpreter_the_reference_would_run_under(monkeypatch):
+    """clair/callVarBam.py starts the pileup script with --pypy (default pypy3): insertion-ordered sets; any other interpreter name means CPython."""
+    monkeypatch.delenv("CLAIR_AMD_SET_ORDER", raising=False)
+    assert ct.set_order_of(None) == ct.set_order_of("pypy3") == ct.set_order_of("/opt/pypy3.6/bin/pypy3") == "ascending"
+    assert ct.set_order_of("python3") == ct.set_order_of("/usr/bin/python") == "cpython"
+    monkeypatch.setenv("CLAIR_AMD_SET_ORDER", "cpython")
+    assert ct.set_order_of("pypy3") == "cpython"
+    with pytest.raises(ValueError):
+        ct.PileupBuilderPy("c", "ACGT", 0, [], set_order="sorted")
+    with pytest.raises(ValueError):
+        _hostapi.PileupBuilder("c", "ACGT", 0, [], set_order="sorted")
