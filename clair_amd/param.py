@@ -18,7 +18,9 @@ input_tensor_size = no_of_positions * matrixRow * matrixNum  # 1056
 def pipeline_slots():
     """Batches the callers keep in flight at the engine's host boundary (clair_submit* / clair_wait).  Three compute lanes fill the
     chip; twice as many slots keep every lane fed while its other batch is on the host link.  CLAIR_AMD_SLOTS
-    overrides (1 and 2 select the fused layer-2 launch of one- and two-lane handles)."""
+    overrides (1 and 2 select the fused layer-2 launch of one- and two-lane handles; up to 4 slots get a lane each -- the configuration of a
+    caller whose batches are already in HBM -- and 4 slots fed from the host are the one bad choice: four lanes and the copy stream are five
+    streams on four hardware queues)."""
     import os
     try:
         return max(1, min(64, int(os.environ.get("CLAIR_AMD_SLOTS", "6"))))
