@@ -207,7 +207,7 @@ class GpuStateSampler(object):
         except OSError:
             pass
         try:
-            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_state_sampler.py"), card, self.path, "1"], stdin=subprocess.PIPE)
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_state_sampler.py"), card, self.path, os.environ.get("BENCH_SAMPLER_MS", "1")], stdin=subprocess.PIPE)
         except OSError:
             pass
 
@@ -410,12 +410,15 @@ def run_ranked(args, group, json_fd):
     times = eng.kernel_times()
     phases.append(["HIP events on every kernel, %d lanes in flight" % streams, steps])
     iso_steps = min(steps, 32)
-    eng.timing_reset()
-    for i in range(iso_steps):
-        eng.run_resident(0, xd, od, (i % nuniq) * batch, batch)
-    eng.sync()
-    times_iso = eng.kernel_times()
-    phases.append(["alone on one stream (alone_ms)", iso_steps])
+    times_iso = None
+    for _ in range(2):                     # twice, the smaller mean per kernel: one hiccup in 32 launches (a 4 ms stall was seen once) must not pick the "dominant" kernel
+        eng.timing_reset()
+        for i in range(iso_steps):
+            eng.run_resident(0, xd, od, (i % nuniq) * batch, batch)
+        eng.sync()
+        t_iso = eng.kernel_times()
+        times_iso = t_iso if times_iso is None else {k: (min(t_iso[k], times_iso[k], key=lambda v: v[0] / v[1] if v[1] else float("inf"))) for k in t_iso}
+    phases.append(["alone on one stream (alone_ms), twice", 2 * iso_steps])
     wgs = eng.kernel_workgroups(batch)
     active = [k for k in _capi.KERNEL_NAMES if times_iso[k][1]]
     cu_share = {k: min(1.0, wgs[k] / 256.0) if wgs[k] else 1.0 for k in active}

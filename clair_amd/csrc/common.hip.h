@@ -23,11 +23,6 @@ constexpr int L4_SPLITS = 8;   // split-K factor of the 7680->192 GEMM: one part
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// sigmoid / tanh as the LSTMBlockCell gate non-linearities (TF 1.13 lstm_ops; reached from
-// clair/model.py:301).  Both saturate cleanly: exp -> inf gives rcp -> 0.
-__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
-__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
-
 // clair/selu.py:26-30 : scale * where(x >= 0, x, alpha * elu(x))
 // elu needs expm1, not exp - 1: near 0 the subtraction leaves 6e-8 ABSOLUTE, i.e. 1e-5 relative on an activation of
 // 0.01 -- visible as 1e-5 on the probabilities once a layer with small outputs feeds one with large weights
@@ -67,11 +62,6 @@ __device__ __forceinline__ f32x2 selu_scaled2(f32x2 x, float k) {
     return em1 * (alpha * scale * k) + xp * (scale * k);
 }
 
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-    // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col=l&15,row=(l>>4)*4+reg
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
 // ---- 2-way fp16 split of fp32 values (gemm_split.hip.h, lstm32.hip.h, dense.hip.h) ------------------------------------
 // x ~= x1 + x2 with x1 = fp16(x), x2 = fp16(x - x1): 22 significand bits (relative error <= 2^-22, absolute
 // error <= 3e-8 once x2 falls into the fp16 subnormal range), round-to-nearest-even both times.  Products of
@@ -105,11 +95,6 @@ __device__ __forceinline__ void split2_pk4(const float (&x)[4], uint2 &hi, uint2
     asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[3]) : "v"(x[3]), "v"(hi.y));
     asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo.x) : "v"(r[0]), "v"(r[1]));
     asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo.y) : "v"(r[2]), "v"(r[3]));
-}
-
-__device__ __forceinline__ f32x4 mfma16h(f16x8 a, f16x8 b, f32x4 c) {
-    // v_mfma_f32_16x16x32_f16: lane (i = l&15, q = l>>4) supplies A[i][8q..8q+7] / B[8q..8q+7][i]; C/D as mfma16
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
