@@ -171,15 +171,25 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
         }
     asm volatile("" : "+v"(bias16[0]), "+v"(bias16[1]));
     // piece j = 0..15 of a tile's output: activation block ni = j >> 3, gate block mi = (j >> 2) & 1, quad a = j & 3; each accumulator
-    // block is four contiguous 1 KiB pieces of the recurrent kernel's layout
-    auto store_piece = [&](const f32x16 (&acc)[2][2], int xt, int j) {
-        const int ni = j >> 3, mi = (j >> 2) & 1, a = j & 3;
+    // block is four contiguous 1 KiB pieces of the recurrent kernel's layout.  The address is wave-uniform but for lane * 16 bytes: the
+    // part that belongs to the wave's gate block is computed once per kernel, the part that belongs to the activation block (one integer
+    // division) once per tile -- per piece it was 25 scalar instructions and a branch in front of every store, a third of what a store
+    // phase cost beyond its MFMAs (tools/gpu/gemm_stamps.py, profiles/r04_gemm_stamps.txt).
+    size_t gate_off[2];   // elements: ((d * ntiles) * 33 * 16 + wb) * 1024 of gate block mi
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int gblk = slice * 2 + mi;   // = (d*4 + w)*4 + b
+        gate_off[mi] = ((size_t)(gblk >> 4) * p.ntiles * T_POS * 16 + (gblk & 15)) * 1024;
+    }
+    auto tile_off = [&](int xt, int ni) -> size_t {          // elements: ((tile * 33 + t) * 16) * 1024 of activation block ni of tile xt
         const int xblk = xt * 2 + ni;      // = t * ntiles + tile
         const int t = xblk / p.ntiles, tile = xblk - t * p.ntiles;
-        const int gblk = slice * 2 + mi;   // = (d*4 + w)*4 + b
-        const int d = gblk >> 4, wb = gblk & 15;
-        float *dst = p.C + ((((size_t)(d * p.ntiles + tile) * T_POS + t) * 16 + wb) * 1024) + lane * 4 + a * 256;
-        __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, (f32x4 *)dst);
+        return ((size_t)tile * T_POS + t) * 16 * 1024;
+    };
+    auto store_piece = [&](const f32x16 (&acc)[2][2], const size_t (&toff)[2], int j) {
+        const int ni = j >> 3, mi = (j >> 2) & 1, a = j & 3;
+        f32x4 *dst = (f32x4 *)(p.C + gate_off[mi] + toff[ni] + a * 256) + lane;
+        __builtin_nontemporal_store((f32x4){acc[mi][ni][4 * a], acc[mi][ni][4 * a + 1], acc[mi][ni][4 * a + 2], acc[mi][ni][4 * a + 3]}, dst);
     };
     // fused: this wave's ticket words of the two candidate tiles of activation tile xt
     auto publish = [&](int xt) {
@@ -191,10 +201,12 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
             __hip_atomic_store(fw + T_POS * 8, fz.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    auto run_tile = [&](auto set_c, int it) {
+    auto run_tile = [&](auto set_c, auto first_c, int it) {
         constexpr int SET = decltype(set_c)::value;
+        constexpr bool FIRST_TILE = decltype(first_c)::value;      // nothing to store yet: no branch in front of the stores of the others
         f32x16 (&acc)[2][2] = accs[SET];
-        const int xt_prev = xt_of(it > 0 ? it - 1 : 0);
+        const int xt_prev = xt_of(FIRST_TILE ? 0 : it - 1);
+        const size_t toff[2] = {tile_off(xt_prev, 0), tile_off(xt_prev, 1)};
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
             const int P = it * 4 + ph;
@@ -221,7 +233,7 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
             // fused: at most phase P+2's four pieces are outstanding here, so in phase 3 the previous tile's stores (issued in phases
             // 0 and 1) have retired -- its blocks are in L2; the two ticket stores are older than this slab's DMA pieces, so the
             // counts above hold
-            if (FUSED && ph == 3 && it > 0) publish(xt_prev);
+            if (FUSED && ph == 3 && !FIRST_TILE) publish(xt_prev);
             // ---- second slab: the next phase's first fragments (one per shadow), the previous tile's output (eight pieces in each of
             //      the first two phases), then phase P+3 into the slot phase P-1 has left
 #pragma unroll
@@ -231,25 +243,28 @@ __device__ __forceinline__ void gemm_split_body(const GemmSplitArgs &p, const in
                 __builtin_amdgcn_sched_barrier(0);
                 CLAIR_DBG_FENCE();
                 if (m < 8) fread1(xa, (ph + 1) & 3, 0, m);
-                if (ph < 2 && m >= 1 && m <= 8 && it > 0) store_piece(accs[SET ^ 1], xt_prev, ph * 8 + m - 1);
+                // (four pieces in every phase instead of eight in the first two were measured: the same 8 270 cycles per tile, tools/gpu/gemm_stamps.py)
+                if (!FIRST_TILE && ph < 2 && m >= 1 && m <= 8) store_piece(accs[SET ^ 1], toff, ph * 8 + m - 1);
                 if (m >= 10 && m < 18 && (m & 1) == 0) dma(P + 3, (m - 10) >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    for (int it = 0; it < n_my; it += 2) {
-        run_tile(std::integral_constant<int, 0>(), it);
-        if (it + 1 < n_my) run_tile(std::integral_constant<int, 1>(), it + 1);
+    run_tile(std::integral_constant<int, 0>(), std::true_type(), 0);
+    for (int it = 1; it < n_my; it += 2) {
+        run_tile(std::integral_constant<int, 1>(), std::false_type(), it);
+        if (it + 1 < n_my) run_tile(std::integral_constant<int, 0>(), std::false_type(), it + 1);
     }
     // the last tile's output (12 wait states between the last MFMA and the first read of its result); only this one can be ragged
     {
         const int last = n_my - 1, xt = xt_of(last);
+        const size_t toff[2] = {tile_off(xt, 0), tile_off(xt, 1)};
         asm volatile("s_nop 11" : "+v"(accs[0][0][0]), "+v"(accs[0][0][1]), "+v"(accs[0][1][0]), "+v"(accs[0][1][1]),
                                   "+v"(accs[1][0][0]), "+v"(accs[1][0][1]), "+v"(accs[1][1][0]), "+v"(accs[1][1][1]));
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if ((xt * 2 + (j >> 3)) * 32 >= p.m_rows) continue;
-            if (last & 1) store_piece(accs[1], xt, j); else store_piece(accs[0], xt, j);
+            if (last & 1) store_piece(accs[1], toff, j); else store_piece(accs[0], toff, j);
         }
     }
     CLAIR_VMWAIT(0);   // the clamped prefetches past the end still target this workgroup's LDS
