@@ -102,15 +102,18 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
         // the group-major tensor (lane l: row 32*piece + l/2, 16-byte slot l%2).  Slot s of a row holds channel half s ^ ((cand >> 3) & 1): the
         // fragment gather reads 16 bytes of every 32-byte row, and the swizzle puts candidates c and c + 8 on different banks.
         // Candidates beyond n_pad (the ragged half of the last block) re-read the last row; their partials are never used.
+        // A wave's pieces are w, w + 4, ...: always the same half of the 64 candidates (piece parity = w & 1), so the per-lane part of the source
+        // address is one 32-bit offset for the kernel's life and a piece costs scalar arithmetic only (glds16_s: wave-uniform base in SGPRs).
+        const int dcand = (w & 1) * 32 + (lane >> 1);
+        const unsigned lane_off = (unsigned)((min(n0 + dcand, p.n_pad - 1) * L34_CH + (((lane & 1) ^ ((dcand >> 3) & 1)) * 4)) * (int)sizeof(float));
         auto issue_tile = [&](int cg) {
-            constexpr int NPIECE = T_POS * L34_CAND / 32;   // 66
-            for (int piece = w; piece < NPIECE; piece += 4) {
-                const int q = piece * 32 + (lane >> 1);
-                const int t = q >> 6, cand = q & 63;
-                const int half = (lane & 1) ^ ((cand >> 3) & 1);
-                const int row = min(n0 + cand, p.n_pad - 1);
-                const float *src = p.a2 + (((size_t)cg * T_POS + t) * p.n_pad + row) * L34_CH + half * 4;
-                glds16((const f32x4 *)src, lds_a2 + piece * 1024);
+            constexpr int NPIECE = T_POS * L34_CAND / 32;   // 66: piece = 2 t + (candidate half)
+            const char *base = (const char *)(p.a2 + ((size_t)cg * T_POS + (w >> 1)) * p.n_pad * L34_CH);
+            const size_t step = (size_t)2 * p.n_pad * L34_CH * sizeof(float);          // two positions on
+            for (int piece = w, i = 0; piece < NPIECE; piece += 4, ++i) {
+                const size_t at = (size_t)(base + (size_t)i * step);        // wave-uniform by construction; said so to the register allocator
+                const void *sbase = (const void *)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)at));
+                glds16_s(lane_off, sbase, lds_a2 + piece * 1024);
             }
         };
         const int cand = mb3 * 32 + l32;
