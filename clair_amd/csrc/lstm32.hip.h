@@ -327,6 +327,9 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
     //   reused as 1+e (A), its reciprocal (R) and k = K2 - 2 K2 rg (K); cell state c' = rf c' + ri k (T, C);
     //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HP, D, LP).  The last gap packs the lane's four h
     //   values into one 8-byte LDS store per plane.
+    //   Not two elements per instruction: v_pk_add/mul/fma_f32 wait for the matrix pipe -- after an MFMA one of them costs the wave 53 cycles
+    //   where four v_fma_f32 cost 33 (tools/ubench/mfma_gap_mix.hip, profiles/r04_mfma_gap_mix.txt); tried here, a block went 940 -> 1200 cycles.
+    //   The wave is issue-bound: 12.9 cycles per MFMA + 8 per transcendental + 4 per other op, floor 32.8 per gap (same table).
     // Placement control.  A sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that
     // opens its gap; pinning its OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking
     // below the MFMA that closes it.  (Pinning inputs as well costs an s_nop per op: hipcc pads every asm output
@@ -387,6 +390,10 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
 #define L32_AFTER_MFMA(M, NM, B)                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     CLAIR_DBG_FENCE();                                                                                            \
+    if ((B) == 0 && (M) % 3 == 0 && (M) / 3 + 2 < 8) {   /* the fragments of k-step M/3 + 2 */                    \
+        hf[(M) / 3 + 2][0] = *(const f16x8 *)&hbuf[(s + 1) & 1][0][cand][((M) / 3 + 2) * 16 + hq * 8];           \
+        hf[(M) / 3 + 2][1] = *(const f16x8 *)&hbuf[(s + 1) & 1][1][cand][((M) / 3 + 2) * 16 + hq * 8];           \
+    }                                                                                                             \
     if (FUSED && (B) == 0 && (M) == 2) { flag_wait(s + 1); flag_fetch(s + 2); }                                   \
     if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
     if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, ((B) > 0 ? (B) - 1 : 0))                                                     \
@@ -463,8 +470,11 @@ _Pragma("unroll")                                                               
     }
 
     for (int s = 0; s < T_POS; ++s) {
+        // h_{s-1} fragments: the first two k-steps now, the others two k-steps ahead of their MFMAs inside block 0 (L32_AFTER_MFMA).  All sixteen
+        // reads in front of the block were 530 cycles per step during which no MFMA could issue: four waves x 16 KiB through the CU's 128 B/clk
+        // of LDS (tools/gpu/lstm_stamps.py, profiles/r04_lstm_stamps.txt).
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) hf[kk][pl] = *(const f16x8 *)&hbuf[(s + 1) & 1][pl][cand][kk * 16 + hq * 8];
         const int s_prev = s > 0 ? s - 1 : 0;
