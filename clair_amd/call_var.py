@@ -24,8 +24,9 @@ Design differences (results identical, pinned by tests/golden/* minted from the 
 Arithmetic mode.  The reference's QUAL (:568-586) and AF (:1151) formulas promote float32
 scalars to float64 under the NumPy 1.18 it pins (README.md:127) and stay float32 under NumPy 2.
 ``arith="legacy"`` (default) computes them in float64 as the pinned reference does;
-``arith="numpy2"`` reproduces the reference as it runs in the build container, which is what
-the byte-for-byte goldens were minted with.
+``arith="numpy2"`` reproduces the reference as it runs in the build container (tests/golden/decode_rows.json.gz).
+The default is pinned by tests/golden/decode_rows_legacy.json.gz: the reference's own writer with float32 scalars
+promoted as NumPy 1.x did (tools/make_ref_goldens.py: L32 / LArr).
 """
 import logging
 import math

@@ -84,6 +84,40 @@ def test_legacy_arithmetic_differs_only_in_qual_and_af(decode_cases):
     assert ndiff < len(a) // 10
 
 
+def legacy_fixture():
+    """(cases file, config name, rows) of tests/golden/decode_rows_legacy.json.gz: the reference's writer run with float32 scalars promoted
+    as NumPy 1.x did (tools/make_ref_goldens.py: L32 / LArr) -- the cases of decode_cases.npz, plus cases at read depth 160 and calls of
+    probability exactly 1, where that arithmetic and NumPy 2's part (or NumPy 2 raises)."""
+    with gzip.open(os.path.join(GOLD, "decode_rows_legacy.json.gz"), "rt") as f:
+        doc = json.load(f)
+    assert "NumPy 1.x" in doc["meta"]["minted_with"]
+    out = []
+    for fn, names in (("decode_cases.npz", ("default", "showref_qual", "haploid_sensitive", "debug")), ("decode_cases_legacy.npz", ("extra_default", "extra_showref_qual"))):
+        with np.load(os.path.join(GOLD, fn)) as z:
+            X, P, infos = z["x"].astype(np.float32), z["probs"], json.loads(str(z["infos"]))
+        out += [(X, P, infos, name, doc["rows"][name]) for name in names]
+    return out
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_default_arithmetic_reproduces_the_reference_rows_minted_with_numpy1_promotion(native):
+    """The shipped default (`--arith legacy`) against the reference itself: call_var.py:568-586 (QUAL) and :1151 (AF) run in float64 from
+    the first operation that meets a Python number, as under the pinned NumPy 1.18.  Byte-identical rows, Python and native decode."""
+    parted = 0
+    for X, P, infos, name, rows in legacy_fixture():
+        cfg = cvar.OutputConfig(*CONFIGS[name.replace("extra_", "")])
+        want = [ln for per in rows for ln in per]
+        got = cvar.VariantDecoder(cfg, arith="legacy", native=native).decode_batch(X, infos, _split(P))
+        assert got == want
+        if name == "extra_showref_qual":
+            keep = [i for i in range(len(infos)) if P[i].max() < 1.0]      # NumPy 2 raises on a call of probability 1 (below)
+            a = cvar.VariantDecoder(cfg, arith="numpy2", native=native).decode_batch(X[keep], [infos[i] for i in keep], _split(P[keep]))
+            b = [ln for i in keep for ln in rows[i]]
+            parted = sum(x != y for x, y in zip(a, b))
+            assert any("9096930" in ln.split("\t")[5] or int(ln.split("\t")[5]) > 9000000 for ln in want)      # the certain calls
+    assert parted >= 10      # the fixture does tell the two arithmetics apart
+
+
 def test_legacy_quality_handles_certain_calls():
     g = np.zeros(21, np.float32)
     g[task.GT21_INDEX["AA"]] = 1.0

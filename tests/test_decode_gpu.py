@@ -39,6 +39,19 @@ def test_device_records_equal_the_host_records_bit_for_bit(engine, platform, pea
         assert _hostapi.format_calls(got, infos, *cfg, False) == _hostapi.decode_rows(x, infos, Y, *cfg, False)
 
 
+def test_device_records_format_to_the_reference_rows_minted_with_numpy1_promotion(engine):
+    """The default arithmetic end to end on the device side: clair_decode's records -> clair_host_format_calls (float64 QUAL / AF) == the
+    reference's rows under NumPy 1.x's scalar promotion (tests/golden/decode_rows_legacy.json.gz), read depth 160 and certain calls included."""
+    from test_decode import CONFIGS, legacy_fixture
+    for X, P, infos, name, rows in legacy_fixture():
+        if name.endswith("debug"):      # the debug lines are the Python writer's
+            continue
+        show_ref, _debug, hp, hs, _ens, qual = CONFIGS[name.replace("extra_", "")]
+        Y = [np.ascontiguousarray(P[:, 0:21]), np.ascontiguousarray(P[:, 21:24]), np.ascontiguousarray(P[:, 24:57]), np.ascontiguousarray(P[:, 57:90])]
+        got = engine.decode(X, Y, _hostapi.centre_bytes(infos))
+        assert _hostapi.format_calls(got, infos, show_ref, hp, hs, qual, False) == [ln for per in rows for ln in per]
+
+
 def test_products_that_underflow_keep_their_denormal_bits(engine):
     """Tiny probabilities: products in the float32 denormal range (and below: exact zeros by underflow) must tie and order exactly as
     on the host, where SSE arithmetic keeps denormals."""

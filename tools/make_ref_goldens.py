@@ -19,7 +19,9 @@ NumPy note: this container has NumPy 2.2; the reference pins NumPy 1.18 (README.
 NumPy 2 `quality_score_from` (call_var.py:568-586) and the AF division (:1151) run in float32 instead
 of float64.  The goldens therefore pin clair_amd's decode in its ``numpy2`` arithmetic mode
 byte-for-byte; the shipped default (``legacy``) differs only in those two formulas (float64, as
-NumPy 1.x promotes) -- see clair_amd/call_var.py.
+NumPy 1.x promotes) -- see clair_amd/call_var.py -- and is pinned by
+  tests/golden/decode_rows_legacy.json.gz + decode_cases_legacy.npz   the reference's writer with NumPy 1.x's scalar promotion put back
+                                                          (L32 / LArr below; `--legacy-decode-only` mints just these).
 """
 import gc
 import gzip
@@ -177,6 +179,117 @@ def decode_goldens():
     print("decode goldens: rows per kind", cover, "GT histogram", gts)
 
 
+# ---- the decode as the reference's pinned NumPy (1.18, README.md:127) would run it ------------------------------------------------------
+# NumPy 2 (NEP 50) changed ONE thing the decode can see: a float32 SCALAR combined with a Python int / float stays float32, where NumPy 1.x
+# promoted it to float64 (NEP 50's own table: `np.float32(3) + 3.` was float64; Python ints counted as int64, and int64 with float32 is
+# float64).  Arrays never promoted on a Python scalar, float32 with float32 stays float32, in both.  L32 / LArr below put exactly that rule
+# back under the REFERENCE's own code: every float32 scalar the reference takes out of its tensors or probabilities is an L32, whose
+# arithmetic with Python numbers and float64 yields float64.  What comes out is the reference's control flow and formulas with NumPy 1.x's
+# scalar promotion restated by hand -- not a run under NumPy 1.18 (not installable here), and the fixture says so.
+class L32(np.float32):
+    def _with(self, other, op, swapped):
+        if isinstance(other, np.float32):           # float32 with float32 (L32 included): float32, in every NumPy
+            r = op(np.float32(other), np.float32(self)) if swapped else op(np.float32(self), np.float32(other))
+            return L32(r)
+        if isinstance(other, (bool, int, float, np.float64, np.integer)):
+            a, b = np.float64(float(self)), np.float64(float(other))
+            return op(b, a) if swapped else op(a, b)
+        return NotImplemented
+
+    def __add__(self, o): return self._with(o, lambda a, b: a + b, False)
+    def __radd__(self, o): return self._with(o, lambda a, b: a + b, True)
+    def __sub__(self, o): return self._with(o, lambda a, b: a - b, False)
+    def __rsub__(self, o): return self._with(o, lambda a, b: a - b, True)
+    def __mul__(self, o): return self._with(o, lambda a, b: a * b, False)
+    def __rmul__(self, o): return self._with(o, lambda a, b: a * b, True)
+    def __truediv__(self, o): return self._with(o, lambda a, b: a / b, False)
+    def __rtruediv__(self, o): return self._with(o, lambda a, b: a / b, True)
+    def __neg__(self): return L32(-np.float32(self))
+
+
+class LArr(np.ndarray):
+    """float32 array whose scalars come out as L32 (indexing and iteration)."""
+    def __getitem__(self, key):
+        r = np.ndarray.__getitem__(self, key)
+        if isinstance(r, np.float32) and not isinstance(r, L32):
+            return L32(r)
+        return r
+
+    def __iter__(self):
+        for i in range(self.shape[0]):
+            yield self[i]
+
+
+def legacy_decode_goldens():
+    """tests/golden/decode_rows_legacy.json.gz: the cases of decode_cases.npz through the reference's writer with NumPy 1.x's scalar promotion
+    (L32 / LArr above).  Sanity checks here: the emulator is inert where NumPy 2 and 1.x agree (same rows except QUAL / AF), and it does
+    change what it should (some QUAL / AF values differ)."""
+    with np.load(os.path.join(GOLD, "decode_cases.npz")) as z:
+        X = z["x"].astype(np.float32)
+        P = z["probs"]
+        infos = json.loads(str(z["infos"]))
+    with gzip.open(os.path.join(GOLD, "decode_rows.json.gz"), "rt") as f:
+        plain = json.load(f)
+    assert type(L32(np.float32(0.5)) * np.float32(0.5)) is L32 and type(1.0 - L32(0.25)) is np.float64 and type(0 + L32(3)) is np.float64
+    assert type(sum(X[0, 16, :, 0].view(LArr))) is np.float64 and type(X.view(LArr)[0, 16, 0, 0]) is L32
+    rows = {}
+    for name in ("default", "showref_qual", "haploid_sensitive", "debug"):
+        per, _ = reference_rows(X.view(LArr), infos, P.view(LArr), CONFIGS[name])
+        rows[name] = per
+        changed = 0
+        assert len(per) == len(plain[name])
+        for a, b in zip(per, plain[name]):
+            assert len(a) == len(b)
+            for ra, rb in zip(a, b):
+                ca, cb = ra.split("\t"), rb.split("\t")
+                if name != "debug":
+                    assert ca[:5] == cb[:5] and ca[6:9] == cb[6:9] and ca[9].split(":")[0] == cb[9].split(":")[0] and ca[9].split(":")[2] == cb[9].split(":")[2]
+                changed += ra != rb
+        print("legacy decode goldens [%s]: %d rows, %d differ from the NumPy-2 rows" % (name, sum(len(a) for a in per), changed))
+    # Cases in which the two arithmetics part: read depth 160 (s / 160 sits on a %.4f rounding tie for 32 values of s, and float32 / float64
+    # fall on different sides of it) and calls the network is certain of (p = 1: QUAL from the 1e-300 guards; the reference under NumPy 2
+    # raises there, which is why decode_cases.npz caps its probabilities at 0.99999).
+    rng = np.random.default_rng(160)
+    n = 192
+    raw, xinfos = synth.synthetic_candidates(n, "ont", seed=160)
+    for i, inf in enumerate(xinfos):
+        inf[1] = str(900000 + 13 * i)
+    XE = synth.to_model_input(raw)
+    for i in range(n):      # centre column: depth = sum(delete + reference channels) = 160 exactly
+        d = float(np.sum(XE[i, 16, :, 2] + XE[i, 16, :, 0]))
+        XE[i, 16, 0, 0] += 160.0 - d
+    assert all(float(np.sum(XE[i, 16, :, 2] + XE[i, 16, :, 0])) == 160.0 for i in range(n))
+    PE, _ = crafted_probabilities(rng, n)
+    for i in range(0, n, 12):     # every twelfth: a certain reference call / a certain homozygous SNP
+        PE[i] = 0
+        PE[i, [0, 4, 7, 9][(i // 12) % 4]] = 1.0      # gt21: AA, CC, GG, TT
+        PE[i, 21 + (0 if "ACGT"[(i // 12) % 4] == xinfos[i][2][16] else 2)] = 1.0
+        PE[i, 24 + 16] = 1.0
+        PE[i, 57 + 16] = 1.0
+    extra = {}
+    for name in ("default", "showref_qual"):
+        per, _ = reference_rows(XE.view(LArr), xinfos, PE.view(LArr), CONFIGS[name])
+        extra[name] = per
+    plain_rows = None
+    try:
+        plain_rows, _ = reference_rows(XE, xinfos, PE, CONFIGS["showref_qual"])
+    except (ValueError, ZeroDivisionError) as exc:
+        print("legacy decode goldens: the reference under NumPy %s raises on the certain calls (%s: %s), as expected" % (np.__version__, type(exc).__name__, exc))
+    keep = [i for i in range(n) if i % 12]
+    a, _ = reference_rows(XE[keep].view(LArr), [xinfos[i] for i in keep], PE[keep].view(LArr), CONFIGS["showref_qual"])
+    b, _ = reference_rows(XE[keep], [xinfos[i] for i in keep], PE[keep], CONFIGS["showref_qual"])
+    ndiff = sum(x != y for x, y in zip(a, b))
+    print("legacy decode goldens [extra]: %d rows (showref_qual), %d of the %d candidates without a certain call give different rows under NumPy 2"
+          % (sum(len(r) for r in extra["showref_qual"]), ndiff, len(keep)))
+    assert ndiff >= 10
+    np.savez_compressed(os.path.join(GOLD, "decode_cases_legacy.npz"), x=XE.astype(np.int16), probs=PE, infos=np.array(json.dumps(xinfos)))
+    rows["extra_default"], rows["extra_showref_qual"] = extra["default"], extra["showref_qual"]
+    meta = {"minted_with": "the reference's clair/call_var.py (batch_output) under NumPy %s with float32 scalars promoted as NumPy 1.x did "
+                           "(tools/make_ref_goldens.py: L32 / LArr); not a run under the pinned NumPy 1.18" % np.__version__}
+    with gzip.open(os.path.join(GOLD, "decode_rows_legacy.json.gz"), "wt") as f:
+        json.dump({"meta": meta, "rows": rows}, f, separators=(",", ":"))
+
+
 def header_goldens():
     for tag, fai in (("nofai", None), ("fai", "chr20\t64444167\t7\t60\t61\nchr21\t46709983\t65518251\t60\t61\n")):
         with tempfile.TemporaryDirectory() as td:
@@ -239,9 +352,13 @@ def e2e_goldens():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if "--legacy-decode-only" in sys.argv:
+        legacy_decode_goldens()
+        return
     ingest_goldens()
     header_goldens()
     decode_goldens()
+    legacy_decode_goldens()
     e2e_goldens()
 
 
