@@ -904,8 +904,10 @@ __global__ __launch_bounds__(256) void fe_assemble_kernel(Region g, const int64_
 
 // ---- `samtools view` text parsed on the device: the line handling of clair_host_sampack_* (hostsrc/host_sampack.cpp), one thread per line ---
 // What the host packer does per line -- split on whitespace, FLAG / RNAME / POS / MAPQ / CIGAR / SEQ, the two stages' filters, the CIGAR
-// reduced to M / I / D operations -- with the text left where it is: a read's bases are addressed inside the text slab (seq0 = offset of
-// SEQ), so nothing is copied and the host only moves bytes from the pipe to the device.  The per-read state the scripts carry from line
+// reduced to M / I / D operations -- on the text where the copy from the pipe left it; the host only moves bytes.  Of the text only the
+// SEQ columns of the kept alignments stay resident (fe_text_seq_kernel packs them, 4-byte aligned per alignment, into the slab's `seq`):
+// QNAME, QUAL and the tags are more than half of a line, and a region's text is what fills the HBM first (64 B per position of tables
+// against ~75 B of text per position at 30x).  The per-read state the scripts carry from line
 // to line (--dcov, sortedness) is recovered from the sorted start positions (a read's rank among the pileup reads of its start
 // position is its index minus the lower bound of that position) and carried from chunk to chunk by the host.
 struct TextOptions {
@@ -1083,23 +1085,24 @@ __global__ __launch_bounds__(256) void fe_text_keep_kernel(const TextLine *lines
 
 // one workgroup: exclusive sums of the kept lines' operation and element counts, sortedness, counters, the state for the next chunk
 __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *lines, int64_t n_lines, const int64_t *kept, int64_t n_kept, const int64_t *cand, int64_t n_cand,
-                                                              uint32_t *op0, uint32_t *elem0, uint64_t *totals, TextState carry, TextState *state) {
+                                                              uint32_t *op0, uint32_t *elem0, uint32_t *seq0, uint64_t *totals, TextState carry, TextState *state) {
     __shared__ uint64_t s_ops, s_elems;
     __shared__ uint32_t s_anom, s_reach;
     __shared__ unsigned long long s_evc, s_pile;
     __shared__ unsigned long long s_last_evc;                                 // 1 + index (among the kept lines) of the last one the candidate search accepts
     if (threadIdx.x == 0) { s_ops = 0; s_elems = 0; s_anom = 0; s_reach = 0; s_evc = 0; s_pile = 0; s_last_evc = 0; }
     __syncthreads();
-    uint64_t carry_ops = 0, carry_elems = 0;
+    uint64_t carry_ops = 0, carry_elems = 0, carry_seq = 0;
     uint32_t anom = 0, reach = 0;                 // reach: the longest alignment in elements (no reference span is longer)
     unsigned long long evc = 0, pile = 0;
     for (int64_t at = 0; at < n_kept; at += 256) {
         const int64_t i = at + threadIdx.x;
-        uint32_t a = 0, b = 0;
+        uint32_t a = 0, b = 0, c = 0;
         if (i < n_kept) {
             const TextLine ln = lines[kept[i]];
             a = ln.n_ops;
             b = ln.n_elem;
+            c = (ln.seq_len + 3u) & ~3u;          // the alignment's bases in the packed buffer: a whole number of dwords
             reach = max(reach, b);
             const int64_t before = i > 0 ? lines[kept[i - 1]].pos0 : (carry.have_last ? carry.last_pos : ln.pos0);
             if (ln.pos0 < before) anom |= CLAIR_FE_UNSORTED;
@@ -1122,12 +1125,14 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
             evc += (ln.flags & CLAIR_READ_EVC) ? 1 : 0;
             pile += (ln.flags & CLAIR_READ_PILE) ? 1 : 0;
         }
-        uint32_t ta, tb;
+        uint32_t ta, tb, tc;
         const uint32_t ea = block_exclusive_scan(a, &ta);
         const uint32_t eb = block_exclusive_scan(b, &tb);
-        if (i < n_kept) { op0[i] = (uint32_t)(carry_ops + ea); elem0[i] = (uint32_t)(carry_elems + eb); }
+        const uint32_t ec = block_exclusive_scan(c, &tc);
+        if (i < n_kept) { op0[i] = (uint32_t)(carry_ops + ea); elem0[i] = (uint32_t)(carry_elems + eb); seq0[i] = (uint32_t)(carry_seq + ec); }
         carry_ops += ta;
         carry_elems += tb;
+        carry_seq += tc;
     }
     atomicOr(&s_anom, anom);
     atomicMax(&s_reach, reach);
@@ -1139,6 +1144,7 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
         totals[1] = carry_elems;
         totals[2] = s_reach;
         totals[3] = n_kept ? (uint64_t)lines[kept[0]].pos0 : 0;       // where the slab begins (the kept lines are sorted, or CLAIR_FE_UNSORTED is raised)
+        totals[4] = carry_seq;                                        // bytes of the packed bases
         TextState st = carry;
         st.anomalies = carry.anomalies | s_anom;
         st.malformed = state->malformed;
@@ -1161,8 +1167,8 @@ __global__ __launch_bounds__(256) void fe_text_offsets_kernel(const TextLine *li
 }
 
 __global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, const TextLine *lines, const int64_t *kept, int64_t n_kept, const uint32_t *op0,
-                                                           const uint32_t *elem0, clair_read_t *reads, clair_op_t *ops, uint32_t *op_elem, uint64_t total_ops,
-                                                           uint64_t total_elems) {
+                                                           const uint32_t *elem0, const uint32_t *seq0, clair_read_t *reads, clair_op_t *ops, uint32_t *op_elem,
+                                                           uint64_t total_ops, uint64_t total_elems) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i == 0) op_elem[total_ops] = (uint32_t)total_elems;
     if (i >= n_kept) return;
@@ -1171,13 +1177,30 @@ __global__ __launch_bounds__(256) void fe_text_emit_kernel(const uint8_t *text, 
                      nullptr);
     clair_read_t r;
     r.pos0 = ln.pos0;
-    r.seq0 = ln.seq_off;
+    r.seq0 = seq0[i];
     r.seq_len = ln.seq_len;
     r.op0 = op0[i];
     r.n_ops = ln.n_ops;
     r.flags = ln.flags & (CLAIR_READ_REVERSE | CLAIR_READ_EVC | CLAIR_READ_PILE | CLAIR_READ_FLUSH);
     r.reserved = 0;
     reads[i] = r;
+}
+
+// The SEQ column of every kept line into the slab's packed buffer: a wave per alignment, a dword per lane and step.  The source starts at any
+// byte of the text: two aligned dwords and v_alignbyte give the four bytes from there (the text buffer is allocated 16 bytes longer than the text).
+__global__ __launch_bounds__(256) void fe_text_seq_kernel(const uint8_t *text, const TextLine *lines, const int64_t *kept, int64_t n_kept, const uint32_t *seq0, uint8_t *seq) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_kept) return;
+    const int lane = threadIdx.x & 63;
+    const TextLine ln = lines[kept[i]];
+    const uint32_t n_dw = (ln.seq_len + 3u) >> 2;
+    const uint32_t *src = (const uint32_t *)(text + (ln.seq_off & ~3u));
+    const uint32_t shift = ln.seq_off & 3u;
+    uint32_t *dst = (uint32_t *)(seq + seq0[i]);
+    for (uint32_t k = (uint32_t)lane; k < n_dw; k += 64) {
+        const uint32_t lo = src[k], hi = src[k + 1];
+        dst[k] = __builtin_amdgcn_alignbyte(hi, lo, shift);
+    }
 }
 
 int fe_fail(clair_frontend *f, const char *fmt, ...);
@@ -1464,11 +1487,10 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
         std::vector<void *> p;
         ~Temp() { for (void *x : p) (void)hipFree(x); }
         hipError_t get(void **out, size_t bytes) { hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16)); if (e == hipSuccess) p.push_back(*out); return e; }
-        void keep(void *x) { p.erase(std::remove(p.begin(), p.end(), x), p.end()); }
     } tmp;
     uint8_t *d_text = nullptr;
     uint32_t *block_sum = nullptr, *d_count = nullptr;
-    FE_TRY(f, tmp.get((void **)&d_text, (size_t)len));
+    FE_TRY(f, tmp.get((void **)&d_text, (size_t)len + 16));            // fe_text_seq_kernel reads whole dwords
     FE_TRY(f, tmp.get((void **)&block_sum, ((size_t)blocks_for(len + 1, SCAN_BLOCK) + 2) * sizeof(uint32_t)));
     FE_TRY(f, tmp.get((void **)&d_count, 4 * sizeof(uint32_t)));
     FE_TRY(f, hipMemcpyAsync(d_text, sam, (size_t)len, hipMemcpyHostToDevice, f->stream));
@@ -1500,15 +1522,16 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
     if (scan_count(f, keep, n_lines, line_sum, d_count + 2, &n_kept)) return 1;
     FE_TRY(f, tmp.get((void **)&kept, (size_t)n_kept * sizeof(int64_t)));
     if (scan_write(f, keep, n_lines, line_sum, d_count + 2, nullptr, kept, 0)) return 1;
-    uint32_t *op0 = nullptr, *elem0 = nullptr;
+    uint32_t *op0 = nullptr, *elem0 = nullptr, *seq0 = nullptr;
     uint64_t *d_totals = nullptr;
     FE_TRY(f, tmp.get((void **)&op0, (size_t)n_kept * sizeof(uint32_t)));
     FE_TRY(f, tmp.get((void **)&elem0, (size_t)n_kept * sizeof(uint32_t)));
-    FE_TRY(f, tmp.get((void **)&d_totals, 4 * sizeof(uint64_t)));
+    FE_TRY(f, tmp.get((void **)&seq0, (size_t)n_kept * sizeof(uint32_t)));
+    FE_TRY(f, tmp.get((void **)&d_totals, 5 * sizeof(uint64_t)));
     hipLaunchKernelGGL(fe_text_offsets_kernel, dim3(1), dim3(256), 0, f->stream, (const TextLine *)lines, n_lines, (const int64_t *)kept, n_kept, (const int64_t *)cand, n_cand,
-                       op0, elem0, d_totals, carry, f->d_text_state);
+                       op0, elem0, seq0, d_totals, carry, f->d_text_state);
     FE_TRY(f, hipGetLastError());
-    uint64_t totals[4] = {0, 0, 0, 0};
+    uint64_t totals[5] = {0, 0, 0, 0, 0};
     TextState after{};
     FE_TRY(f, hipMemcpyAsync(totals, d_totals, sizeof totals, hipMemcpyDeviceToHost, f->stream));
     FE_TRY(f, hipMemcpyAsync(&after, f->d_text_state, sizeof after, hipMemcpyDeviceToHost, f->stream));
@@ -1518,23 +1541,24 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
                    "the column", after.malformed - 1, (long long)f->text_state.lines);
         return 2;
     }
-    if (totals[0] > 0xfffffff0ull || totals[1] > 0xfffffff0ull) return fe_fail(f, "text chunk too dense for 32-bit offsets: feed smaller chunks");
+    if (totals[0] > 0xfffffff0ull || totals[1] > 0xfffffff0ull || totals[4] > 0xfffffff0ull) return fe_fail(f, "text chunk too dense for 32-bit offsets: feed smaller chunks");
     after.malformed = 0;
     f->text_state = after;
     if (n_kept == 0 || totals[0] == 0) return 0;
     Slab s;
-    s.n_reads = n_kept; s.n_ops = (int64_t)totals[0]; s.n_elem = (int64_t)totals[1]; s.seq_bytes = len;
+    s.n_reads = n_kept; s.n_ops = (int64_t)totals[0]; s.n_elem = (int64_t)totals[1]; s.seq_bytes = (int64_t)totals[4];
     FE_TRY(f, hipMalloc((void **)&s.reads, (size_t)n_kept * sizeof(clair_read_t)));
     f->slabs.push_back(s);
     Slab &d = f->slabs.back();
     FE_TRY(f, hipMalloc((void **)&d.ops, (size_t)d.n_ops * sizeof(clair_op_t)));
     FE_TRY(f, hipMalloc((void **)&d.op_elem, ((size_t)d.n_ops + 1) * sizeof(uint32_t)));
     FE_TRY(f, hipMalloc((void **)&d.tuples, (size_t)n_kept * sizeof(uint64_t)));
-    d.seq = d_text;                     // the bases stay where samtools printed them
-    tmp.keep(d_text);
+    FE_TRY(f, hipMalloc((void **)&d.seq, (size_t)std::max<uint64_t>(totals[4], 16)));      // the bases only: the text itself is released when this call returns
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_kept * sizeof(uint64_t), f->stream));
     hipLaunchKernelGGL(fe_text_emit_kernel, dim3(blocks_for(n_kept, 256)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
-                       (const uint32_t *)op0, (const uint32_t *)elem0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+                       (const uint32_t *)op0, (const uint32_t *)elem0, (const uint32_t *)seq0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
+    hipLaunchKernelGGL(fe_text_seq_kernel, dim3(blocks_for(n_kept, 4)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
+                       (const uint32_t *)seq0, d.seq);
     if (launch_tally(f, d, (int64_t)totals[3], after.last_pos + (int64_t)totals[2])) return 1;
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));

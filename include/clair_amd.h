@@ -261,7 +261,7 @@ int clair_frontend_add_reads(clair_frontend_t *f, const struct clair_read *reads
                              const uint32_t *op_elem, const uint8_t *seq, int64_t seq_bytes);
 /* ... or hand over the `samtools view` TEXT and let the device do the packing as well: the line handling of both scripts
  * (ExtractVariantCandidates.py:266-295, CreateTensor.py:251-287) one thread per line, exactly what clair_host_sampack_* produces
- * (arguments of _text_options as clair_host_sampack_create), with the bases left where samtools printed them.  `sam` holds whole
+ * (arguments of _text_options as clair_host_sampack_create); of the text only the SEQ columns of the kept alignments stay on the device.  `sam` holds whole
  * lines (the caller keeps an unfinished last line for the next call), at most 2 GB at a time; the --dcov and sortedness state runs on
  * across calls.  Returns 2 when a line is malformed (too few columns, a non-integer FLAG / POS / MAPQ): clair_host_sampack_feed on
  * the same text reports it the way the host path does.  _text_stats: stats[0..3] = lines, candidate-search alignments, pileup

@@ -359,6 +359,10 @@ def test_text_parsed_on_the_device_gives_the_host_packers_alignments(opt, chunks
     assert ts == dict(lines=st["lines"], evc_reads=st["evc_reads"], pile_reads=st["pile_reads"], anomalies=st["anomalies"])
     assert len(got) == len(r) and np.array_equal(got["pos0"], r["pos0"]) and np.array_equal(got["flags"], r["flags"])
     assert np.array_equal(got["seq_len"], r["seq_len"]) and np.array_equal(got["n_ops"], r["n_ops"])
+    # only the SEQ columns stay on the device, packed a whole number of dwords per alignment (fe_text_seq_kernel): not offsets into the text
+    for sr in f.slab_reads:
+        assert (sr["seq0"] % 4 == 0).all() and sr["seq0"][0] == 0
+        assert np.array_equal(sr["seq0"][1:], np.cumsum((sr["seq_len"][:-1].astype(np.int64) + 3) // 4 * 4))
     # ... and everything downstream of them: tallies -> candidates, windows, tuple counts
     g = _capi.Frontend(0, case["ref"], case["ref0"], case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64)
     g.add_arrays(r, o, e, q)
