@@ -549,7 +549,8 @@ def run_ranked(args, group, json_fd):
                        "device_warm_steps": device_warm,
                        "device_warm_note": "untimed steps before the contract's --warmup (clock ramp, first touch); BENCH_WARM_STEPS=0 removes them",
                        "collective": "none on the data path; RCCL (clair_comm_*) for the weight broadcast, barrier and timers" if world > 1 else "none (1 rank)",
-                       "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None},
+                       "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None,
+                       "rccl_failure": getattr(group, "rccl_failure", None)},
             "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None}
                          for r, (s_, c_, t_) in enumerate(zip(per_rank_steps, per_rank_candidates, per_rank_s))],
             "boundary": boundary,

@@ -13,7 +13,8 @@ counters and timers -- goes through ``NodeGroup``:
 * transport ``"rccl"``: the C ABI's communicator (include/clair_amd.h: clair_comm_*, a direct
   binding of librccl.so; xGMI between the GPUs of the node).  One GPU per rank is required.
 * transport ``"tcp"``: the same operations over the bootstrap sockets on 127.0.0.1 (pure
-  Python).  It is what the CPU tests run, and it carries the RCCL unique id during start-up.
+  Python).  It is what the CPU tests run, it carries the RCCL unique id during start-up, and it is what every rank falls back to
+  (loudly: stderr, ``rccl_failure``) when RCCL's own start-up fails on any of them.
 
 Rendezvous (one node): rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it in a
 file every rank can name: ``$CLAIR_AMD_RDZV`` when set (bench.py's own spawner sets it), else
@@ -24,6 +25,7 @@ No torch anywhere in this module.
 import os
 import socket
 import struct
+import sys
 import tempfile
 import time
 
@@ -297,6 +299,7 @@ class NodeGroup(object):
         if not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
         self.transport = "none"
+        self.rccl_failure = None          # why an asked-for RCCL communicator is not there (then transport == "tcp")
         self._lib = None
         self._comm = None
         self.timeout = timeout
@@ -321,19 +324,36 @@ class NodeGroup(object):
             if bad:
                 self._star.close()
                 raise _capi.EngineError("RCCL start-up refused on %d of %d ranks -- %s" % (len(bad), self.world, "; ".join(bad)))
+            # From here on a failure is RCCL's own start-up (no usable bootstrap interface, a library / driver mismatch): every rank learns
+            # of it over the sockets and ALL of them go on with the "tcp" transport -- the data path has no collective, what is carried is
+            # the timing barrier, one max and the 9.5 MB of weights.  Said on stderr and in bench.py's line (`config.transport`,
+            # `config.rccl_failure`); a rank that HANGS inside ncclCommInitRank still ends the job at `timeout`.
             uid = (ctypes.c_uint8 * 128)()
-            if self.rank == 0 and lib.clair_comm_unique_id(uid) != 0:
-                err = lib.clair_comm_last_error(None).decode()
-                self._star.allgather(("error", err))
-                raise _capi.EngineError("clair_comm_unique_id failed: %s" % err)
-            got = self._star.allgather(("id", bytes(uid)) if self.rank == 0 else None)[0]
+            first = None
+            if self.rank == 0:
+                ok = lib.clair_comm_unique_id(uid) == 0
+                first = ("id", bytes(uid)) if ok else ("error", lib.clair_comm_last_error(None).decode())
+            got = self._star.allgather(first)[0]
             if got[0] != "id":
-                raise _capi.EngineError("rank 0 could not create the RCCL unique id: %s" % got[1])
+                self._fall_back("rank 0 could not create the RCCL unique id: %s" % got[1])
+                return
             uid = (ctypes.c_uint8 * 128).from_buffer_copy(got[1])
             h = ctypes.c_void_p()
-            if lib.clair_comm_create(self.local_rank, self.rank, self.world, uid, ctypes.byref(h)) != 0:
-                raise _capi.EngineError("clair_comm_create failed on rank %d: %s" % (self.rank, lib.clair_comm_last_error(None).decode()))
+            mine = "" if lib.clair_comm_create(self.local_rank, self.rank, self.world, uid, ctypes.byref(h)) == 0 else lib.clair_comm_last_error(None).decode()
+            status = self._star.allgather(mine)
+            bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
+            if bad:
+                if not mine:
+                    lib.clair_comm_destroy(h)
+                self._fall_back("clair_comm_create failed on %d of %d ranks -- %s" % (len(bad), self.world, "; ".join(bad)))
+                return
             self._lib, self._comm = lib, h
+
+    def _fall_back(self, why):
+        self.transport, self.rccl_failure = "tcp", why
+        if self.rank == 0:
+            print("[clair_amd.shard] RCCL start-up failed (%s): barrier, reductions and the weight broadcast of this run go over the bootstrap "
+                  "sockets on 127.0.0.1 instead" % why, file=sys.stderr)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _check(self, rc, what):

@@ -247,6 +247,53 @@ def test_rccl_start_up_is_refused_on_every_rank_when_one_rank_cannot_start(tmp_p
     assert "refused on 2 of 2 ranks" in out and "rank 1: no HIP device" in out
 
 
+RCCL_FAILS_WORKER = textwrap.dedent("""
+    import ctypes, sys
+    sys.path.insert(0, %(root)r)
+    from clair_amd import _capi, shard
+
+    class Lib(object):
+        '''A HIP library whose devices are fine and whose RCCL start-up fails %(where)s.'''
+        destroyed = 0
+        def clair_device_count(self): return 2
+        def clair_comm_preflight(self, local_rank): return 0
+        def clair_comm_unique_id(self, uid): return 1 if %(where)r == "at the unique id" else 0
+        def clair_comm_create(self, local_rank, rank, world, uid, h):
+            if rank == 1: return 1
+            h._obj.value = 1234
+            return 0
+        def clair_comm_destroy(self, h): Lib.destroyed += 1
+        def clair_comm_last_error(self, comm): return b"no socket interface found"
+    lib = Lib()
+    _capi.load = lambda *a, **k: lib
+    g = shard.NodeGroup(transport="rccl", timeout=30.0)
+    g.barrier()
+    top = g.max_float(10.0 + g.rank)
+    both = g.gather_floats(float(g.rank))
+    with open(%(out)r + str(g.rank), "w") as f:
+        print("RANK", g.rank, g.transport, top, both, Lib.destroyed, "|", g.rccl_failure, file=f)
+    g.close()
+""")
+
+
+@pytest.mark.parametrize("where", ["at the unique id", "in the communicator of rank 1"])
+def test_a_failing_rccl_start_up_sends_every_rank_to_the_socket_transport(tmp_path, where):
+    """RCCL with more than one rank has never run on hardware here: if its own start-up fails (rank 0's unique id, or ncclCommInitRank on any
+    rank), every rank hears of it over the bootstrap sockets, the communicators that did come up are destroyed, and the job goes on over
+    the "tcp" transport -- said on stderr and kept in `rccl_failure` for bench.py's line."""
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_FAILS_WORKER % {"root": ROOT, "where": where, "out": str(tmp_path / "rank")})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 2)
+    assert [p.wait(timeout=60) for p in procs] == [0, 0]
+    for r in (0, 1):
+        line = (tmp_path / ("rank%d" % r)).read_text()
+        assert line.startswith("RANK %d " % r)
+        assert " tcp 11.0 [0.0, 1.0] " in line and "no socket interface found" in line
+        assert ("rank 0 could not create the RCCL unique id" in line) == (where == "at the unique id")
+        if where != "at the unique id":
+            assert "clair_comm_create failed on 1 of 2 ranks -- rank 1:" in line and (" 1 |" in line) == (r == 0)      # rank 0's communicator was destroyed
+
+
 BENCH_WORKER = textwrap.dedent("""
     import sys, numpy as np
     sys.path.insert(0, %(root)r)

@@ -1,6 +1,6 @@
 """Where a step of the recurrent kernels goes: s_memtime stamps inside the step loop (exp/libclair_probe_lstm.so, tools/gpu/lstm_probe_build.py).
 One batch alone on the chip, one slot, two launches for layer 2.  A step's MFMAs: 120 (layer 1) / 96 (layer 2) x 32 matrix-pipe cycles.
-usage: lstm_stamps.py [batch=1024]"""
+usage: lstm_stamps.py [batch=1024] [probe library = exp/libclair_probe_lstm.so]"""
 import ctypes
 import os
 import sys
@@ -10,8 +10,9 @@ import numpy as np
 sys.path.insert(0, ".")
 from clair_amd import _capi, synth, weights  # noqa: E402
 
-lib_path = os.path.abspath("exp/libclair_probe_lstm.so")
+lib_path = os.path.abspath(sys.argv[2] if len(sys.argv) > 2 else "exp/libclair_probe_lstm.so")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+print("# %s, batch %d" % (os.path.basename(lib_path), n))
 os.environ["CLAIR_AMD_LSTM2_FUSED"] = "0"
 os.environ["CLAIR_AMD_LSTM2_PAIR"] = "0"
 w = weights.synthetic_weights(seed=20250928, head_gain=4.0)
