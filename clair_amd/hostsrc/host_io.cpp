@@ -257,10 +257,7 @@ int clair_host_parse_tensors(const char *buf, int64_t len, int final, int max_ro
     if (nthreads <= 1) {
         for (int li = 0; li < taken; ++li) parse_line(li);
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] { for (int li = t; li < taken; li += nthreads) parse_line(li); });
-        for (auto &th : pool) th.join();
+        clair_host_parallel(nthreads, [&](int t) { for (int li = t; li < taken; li += nthreads) parse_line(li); });      // the persistent pool: no thread is created per batch
     }
     int kept = 0;
     for (int li = 0; li < taken; ++li) {
