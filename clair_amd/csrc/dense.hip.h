@@ -43,8 +43,12 @@ constexpr int L34_A2_BYTES = T_POS * L34_CAND * L34_CH * 4;   // the a2 staging 
 constexpr int L34_L3_BYTES = 2 * L34_CAND * L34_ROW * 2;      // the l3 tile, two planes: 63 488 B
 constexpr int L34_THREADS = 512;
 static_assert(2 * 6 * 64 * 16 * 4 <= L34_L3_BYTES, "the K-half exchange fits the l3 tile's buffer");
-constexpr int L34_SUB = 4 / L34_WALK;            // workgroups that share an XCD's four channel groups for one candidate block (1: the workgroup walks all four)
-static_assert(L34_WALK * L4_SPLITS * L34_CH == 2 * HID && L34_SUB * L34_WALK == 4, "channel groups cover the 256 LSTM2 features; an XCD owns four of them");
+constexpr int L34_SUB = L34_WALK >= 4 ? 1 : 4 / L34_WALK;   // workgroups that share an XCD's four channel groups for one candidate block (1: the workgroup walks all four)
+constexpr int L34_XPS = L34_WALK > 4 ? L34_WALK / 4 : 1;    // XCDs that serve one split (a walk of more than four groups: the split's W4 rows sit in that many L2s, each for its own candidate blocks)
+static_assert(L34_WALK * L4_SPLITS * L34_CH == 2 * HID && (L34_WALK >= 4 ? L34_WALK % 4 == 0 && 8 % L34_XPS == 0 : L34_SUB * L34_WALK == 4),
+              "channel groups cover the 256 LSTM2 features; an XCD owns four of them, or shares a longer walk with its neighbours");
+// workgroups of a launch: per candidate block one per split; with L34_XPS > 1 the blocks are dealt over the XCDs of their split (rounded up to whole rounds of 8)
+__host__ __device__ constexpr int l34_grid(int nblk) { return L34_XPS == 1 ? nblk * L4_SPLITS : (nblk + L34_XPS - 1) / L34_XPS * 8; }
 static_assert(L34_A2_BYTES + L34_L3_BYTES + 16 <= 160 * 1024, "one workgroup per CU");
 // l3 is multiplied by 2^4 before its 2-way fp16 split and the L4 reduction by 2^-4 (folded into TailArgs::l4_scale): a selu output
 // of 0.01 would otherwise have a subnormal low plane (3e-8 absolute = 3e-6 relative); 2^4 keeps 22 bits down to |y| ~ 0.008 and
@@ -83,10 +87,12 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
     const int l32 = lane & 31, hq = lane >> 5;
     // XCD-aware order (workgroups go round-robin over the 8 XCDs by linear id): XCD x owns split x = channel groups 4x .. 4x+3 for every
     // candidate block, so each L2 holds only its own 1/8 of the W4 fragments (740 KB) instead of every L2 streaming all 5.9 MB.
-    const int xcd = blockIdx.x & 7, sub = (blockIdx.x >> 3) % L34_SUB, blk = (blockIdx.x >> 3) / L34_SUB;
+    const int xcd = blockIdx.x & 7;
     const int nblk = (p.n_pad + L34_CAND - 1) / L34_CAND;
+    const int blk = L34_XPS == 1 ? (int)(blockIdx.x >> 3) / L34_SUB : (int)(blockIdx.x >> 3) * L34_XPS + xcd % L34_XPS;
+    const int split = L34_XPS == 1 ? xcd * L34_SUB + (int)(blockIdx.x >> 3) % L34_SUB : xcd / L34_XPS;
+    if (blk >= nblk) return;                       // the last round of a launch whose blocks do not fill it (L34_XPS > 1 only)
     const int n0 = blk * L34_CAND;
-    const int split = xcd * L34_SUB + sub;
     const int cg0 = split * L34_WALK;
     if (tid == 0) psync = 0u;
 

@@ -365,7 +365,7 @@ int enqueue_forward(clair_engine *e, Lane &s, const float *x_dev, float *out_dev
         KernelTimer kt(e, s, CLAIR_K_L4);
         L3L4Args a{s.a2, e->w3s, e->w4s, s.l4part, n_pad, std::ldexp(1.0f, -e->w3_shift), e->tap_l3 ? s.zx : nullptr,
                    e->l34_stamps ? (unsigned long long *)s.zx : nullptr};   // zx is dead by now
-        hipLaunchKernelGGL(l3l4_kernel, dim3(((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS), dim3(L34_THREADS), 0, s.stream, a);
+        hipLaunchKernelGGL(l3l4_kernel, dim3(l34_grid((n_pad + L34_CAND - 1) / L34_CAND)), dim3(L34_THREADS), 0, s.stream, a);
     }
     {
         KernelTimer kt(e, s, CLAIR_K_TAIL);
@@ -1158,7 +1158,7 @@ int clair_kernel_workgroups(clair_engine_t *e, int n, int *workgroups) {
         workgroups[CLAIR_K_LSTM2] = 32 * e->fused_groups + 32 * ((ntiles / 2 + 7) / 8);
         workgroups[CLAIR_K_PROJ2] = 0;
     }
-    workgroups[CLAIR_K_L4] = ((n_pad + L34_CAND - 1) / L34_CAND) * L4_SPLITS;
+    workgroups[CLAIR_K_L4] = l34_grid((n_pad + L34_CAND - 1) / L34_CAND);
     workgroups[CLAIR_K_TAIL] = n_pad / TAIL_TILE;
     workgroups[CLAIR_K_DECODE] = (n + 3) / 4;       // launched only by clair_submit_ex with call records asked for
     return 0;

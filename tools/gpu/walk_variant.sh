@@ -4,6 +4,13 @@
 # exp/libclair_walk2.so = the production sources with L4_SPLITS = 16 (sed; the kernels are written for either).
 # usage (build container): walk_variant.sh build        (GPU box): walk_variant.sh
 cd "$(dirname "$0")/../.."
+if [ "$1" = build8 ]; then      # EIGHT groups per workgroup (64 workgroups at batch 1024, split-K 4): exp/libclair_walk8.so, timed with ab_libs.sh (profiles/r04_ab_walk8.txt)
+  rm -rf exp/csrc_walk8 && mkdir -p exp/csrc_walk8 && cp clair_amd/csrc/* exp/csrc_walk8/
+  sed -i 's|^constexpr int L4_SPLITS = 8; |constexpr int L4_SPLITS = 4; |' exp/csrc_walk8/common.hip.h
+  grep -c "L4_SPLITS = 4" exp/csrc_walk8/common.hip.h
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC exp/csrc_walk8/engine.hip exp/csrc_walk8/comm.hip exp/csrc_walk8/frontend.hip -o exp/libclair_walk8.so -ldl
+  exit $?
+fi
 if [ "$1" = build ]; then
   rm -rf exp/csrc_walk2 && mkdir -p exp/csrc_walk2 && cp clair_amd/csrc/* exp/csrc_walk2/
   sed -i 's|^constexpr int L4_SPLITS = 8; |constexpr int L4_SPLITS = 16;|' exp/csrc_walk2/common.hip.h
