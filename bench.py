@@ -104,6 +104,10 @@ def load_pmc(batch, fused):
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
 PEAK_F16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: f16/bf16 MFMA dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+# energy roofline of the 2-way fp16 split: MFMAs executed per candidate (three per fp32-grade product block of 32 x 32 x 16;
+# L3's K padded 33 -> 48), the joules one costs, the board's power cap and idle draw
+MFMA_PER_CANDIDATE = (64 * 4 * 33 * (120 + 96) + (17301504 + 2 * 1474560 + 2 * 82368) * 1024 * 3 // 32768 + 253440 * 2 * 1024 * 3 * 48 // 33 // 32768) / 1024.0
+NJ_PER_MFMA, BOARD_CAP_W, BOARD_IDLE_W = 23.7, 1385.0, 247.0
 WARM_STEPS = int(os.environ.get("BENCH_WARM_STEPS", "256"))   # untimed device warm-up before the contract's W warm-up steps
 SPLIT_TERMS = 3                         # fp16 MFMAs executed per algorithmic fp32 product (2-way split, common.hip.h)
 PLATFORM = {"ont": "ONT 122HD34", "pacbio_ccs": "PacBio CCS 15", "illumina": "Illumina 12345"}
@@ -564,7 +568,13 @@ def run_ranked(args, group, json_fd):
                               "frac_of_fp32_mfma": round(path_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                               "algorithmic_hbm_gbs": round(value / world * BYTES_PER_CANDIDATE / 1e9, 2),
                               "algorithmic_hbm_frac": round(value / world * BYTES_PER_CANDIDATE / 1e9 / PEAK_HBM_GBS, 6),
-                              "measured_traffic_bytes_per_candidate": round(sum(pmc[k] for k in active if k in pmc) / batch) if pmc else None},
+                              "measured_traffic_bytes_per_candidate": round(sum(pmc[k] for k in active if k in pmc) / batch) if pmc else None,
+                              # the board is at its power cap whatever runs: what the formulation's MFMAs alone would allow
+                              "energy_bound": {"mfma_per_candidate": MFMA_PER_CANDIDATE, "nj_per_mfma": NJ_PER_MFMA, "cap_w": BOARD_CAP_W, "idle_w": BOARD_IDLE_W,
+                                               "candidates_per_s_per_gpu": round((BOARD_CAP_W - BOARD_IDLE_W) / (MFMA_PER_CANDIDATE * NJ_PER_MFMA * 1e-9), 1),
+                                               "frac": round(value / world / ((BOARD_CAP_W - BOARD_IDLE_W) / (MFMA_PER_CANDIDATE * NJ_PER_MFMA * 1e-9)), 4),
+                                               "source": "constants measured once, not in this run: profiles/r04_lstm_energy_variants.txt (nJ per v_mfma_f32_32x32x16_f16), "
+                                                         "profiles/r04_energy_by_kernel_final.txt (socket power at the cap and idle)"}},
             "kernels_in_flight_ms": kern,
             "kernels_alone_ms": kern_iso,
             "parity_max_abs_err": parity,
