@@ -22,8 +22,15 @@ After the contract's timed region (`value`: inputs resident in HBM) the same K s
   value_boundary_int16  -- the same with the raw int16 counts the pileup stage produces (clair_submit_counts);
 and one leg over the whole candidate set BASELINE.json's config names (`--full-candidates`, 200 704 = 196 x 1024 for configs[1]):
   value_full_config / value_boundary_full_config -- so that a driver run with a handful of --steps still shows the sustained rate.
-`gpu_state` holds the shader clock and socket power sampled from sysfs (tools/gpu_state_sampler.py, a process of its own) during
-each of those legs.
+  value_sustained       -- the resident loop again for at least `--sustained-seconds` (default 2.5 s = ~20 000 steps at batch 1024), timed
+                           exactly like `value`: the board is at its power cap for all but the first milliseconds of it, which is the
+                           regime a chr20 / whole-genome candidate set runs in (the reference's own figure of merit is whole-run wall
+                           clock, clair/call_var.py:1317, 1365).  `config.rates` says which of the three resident rates is which.
+`gpu_state` holds the shader clock and socket power sampled from sysfs (tools/gpu_state_sampler.py, a process of its own, every
+`gpu_state.period_ms` milliseconds) during each of those legs, on every rank (`per_rank[r].gpu_state`; the top-level one is rank 0's).
+`gt_concordance_200k` (N=1 only, like cpu_baseline): tools/gt_concordance.py's count of VCF rows whose CHROM/POS/REF/ALT/GT differ between
+the decode of the HIP probabilities and the decode of the float32 oracle's, over `--gt-candidates` (200 000) candidates of each platform
+profile.
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the dominant kernel = the one with the most chip time (stand-alone duration x share of the 256 CUs its grid
@@ -126,6 +133,9 @@ def parse_args(argv=None):
     ap.add_argument("--candidates", type=int, default=5000000, help="--scaling strong: size of the fixed candidate set")
     ap.add_argument("--full-candidates", type=int, default=200704, help="size of the untimed-by-contract leg over the whole candidate set of the config (0: skip)")
     ap.add_argument("--boundary-slots", type=int, default=6, help="batches in flight at the host-array boundary (0: skip the boundary legs)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the value_sustained leg (0: skip)")
+    ap.add_argument("--gt-candidates", type=int, default=200000, help="candidates PER PLATFORM PROFILE of the GT concordance count against the oracle (N=1 only; 0: skip)")
+    ap.add_argument("--gt-seconds", type=float, default=240.0, help="time budget of that count: platforms are cut short (and say so) beyond it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
@@ -190,6 +200,36 @@ def cpu_baseline(w, x, seconds):
             "sample_4_threads": "%d candidates, 4 OpenMP threads (the reference's default --threads), %.1f s" % (n_4, dt_4)}
 
 
+def gt_concordance_at_scale(device, w, n_per_platform, budget_s):
+    """tools/gt_concordance.py's count, in the bench line: per platform profile, the VCF rows (CHROM/POS/REF/ALT/GT) that differ between the
+    decode of the HIP probabilities and the decode of the float32 oracle's on the same `n_per_platform` synthetic candidates, each flip
+    re-examined with the float64 evaluation.  The oracle (test infrastructure, here as the checker) runs at a few thousand candidates per
+    second on the host cores, so the count has a time budget: a platform that would start beyond it is skipped and says so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gt_concordance", os.path.join(ROOT, "tools", "gt_concordance.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    eng = _capi.Engine(device=device, max_batch=4096, n_slots=1)
+    eng.load_weights(w)
+    out, t0 = {"candidates_per_platform": n_per_platform, "platforms": {}, "tool": "tools/gt_concordance.py: concordance(seed 777, one slot, batch 4096)"}, time.perf_counter()
+    try:
+        for platform in ("ont", "pacbio_ccs", "illumina"):
+            spent = time.perf_counter() - t0
+            done = len(out["platforms"])
+            if done and spent + spent / done > budget_s:
+                out["platforms"][platform] = {"skipped": "time budget of %.0f s (--gt-seconds) would be exceeded" % budget_s}
+                continue
+            r = tool.concordance(eng, w, platform, n_per_platform, 777, log=lambda *a: None)
+            out["platforms"][platform] = {"candidates": r["candidates"], "vcf_rows": r["vcf_rows"], "gt_flips": r["gt_flips"], "max_abs_dp": r["max_abs_dp"],
+                                          "excursions_beyond_1e-5": len(r["excursions"]),
+                                          "flips_resolved_by_float64_the_hip_way": sum(1 for f in r["flips"] if f["oracle64_rounded"] is not None
+                                                                                        and tool.key(f["oracle64_rounded"]) == tool.key(f["hip"]))}
+    finally:
+        eng.close()
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 class GpuStateSampler(object):
     """sclk / socket power of this rank's GPU while a leg runs: tools/gpu_state_sampler.py as a child process writing time-stamped
     samples (CLOCK_MONOTONIC, shared by all processes of the box); mean over the samples inside [t0, t1], or the nearest one."""
@@ -197,21 +237,18 @@ class GpuStateSampler(object):
     def __init__(self, device):
         import subprocess
         import tempfile
-        self.path = tempfile.mktemp(prefix="clair_gpu_state_", suffix=".txt")
+        fd, self.path = tempfile.mkstemp(prefix="clair_gpu_state_", suffix=".txt")
+        os.close(fd)
         self.proc = None
+        # every read of pp_dpm_sclk / power1_* is a query to the SMU: at 1 kHz the sampler itself could move the clocks it reports,
+        # inside the contract's timed region.  10 ms: the 2 ms burst leg gets the nearest sample, every other leg dozens.
+        self.period_ms = float(os.environ.get("BENCH_SAMPLER_MS", "10"))
         card = "auto"
-        try:                                   # the sysfs directory of THIS HIP device
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
-                cand = "/sys/bus/pci/devices/%s" % buf.value.decode().lower()
-                if os.path.isdir(cand):
-                    card = cand
-        except OSError:
-            pass
+        bdf = shard.local_pci_bus_id(device)   # the sysfs directory of THIS HIP device (clair_device_pci_bus_id)
+        if bdf and os.path.isdir("/sys/bus/pci/devices/%s" % bdf):
+            card = "/sys/bus/pci/devices/%s" % bdf
         try:
-            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_state_sampler.py"), card, self.path, os.environ.get("BENCH_SAMPLER_MS", "1")], stdin=subprocess.PIPE)
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gpu_state_sampler.py"), card, self.path, "%g" % self.period_ms], stdin=subprocess.PIPE)
         except OSError:
             pass
 
@@ -364,7 +401,7 @@ def run_ranked(args, group, json_fd):
     run(args.warmup)
     eng.sync()
     phases = [["device warm-up + --warmup", device_warm + args.warmup]]    # forward passes launched, in order (tools/rocpd_summary.py --phases-from)
-    sampler = GpuStateSampler(local_rank) if rank == 0 else None
+    sampler = GpuStateSampler(local_rank)       # every rank samples ITS GPU (an 8-rank line carries eight clocks and powers)
     legs = {}                                   # name -> (CLOCK_MONOTONIC ns at both ends) for gpu_state
 
     def timed(name, body, finish):
@@ -397,6 +434,17 @@ def run_ranked(args, group, json_fd):
         phases.append(["whole candidate set (value_full_config)", full_steps])
         full = {"steps": full_steps, "candidates_per_rank": full_steps * batch, "seconds": round(full_s, 6), "value": round(world * full_steps * batch / full_s, 1),
                 "ms_per_step": round(full_s / full_steps * 1e3, 4)}
+
+    # The sustained rate: the same loop for seconds, not milliseconds -- the board at its power cap from start to end.
+    sustained = None
+    if args.sustained_seconds > 0 and args.scaling == "weak":
+        guess = (full["value"] if full else sum(per_rank_candidates) / elapsed) / world        # candidates/s of one rank
+        sus_steps = max(steps, int(np.ceil(args.sustained_seconds * guess / batch)))
+        sus_steps = int(round(group.max_float(sus_steps)))                                      # the same count on every rank
+        sus_s = group.max_float(timed("value_sustained", lambda: run(sus_steps), eng.sync))
+        phases.append(["sustained (value_sustained)", sus_steps])
+        sustained = {"steps": sus_steps, "candidates_per_rank": sus_steps * batch, "seconds": round(sus_s, 6), "value": round(world * sus_steps * batch / sus_s, 1),
+                     "ms_per_step": round(sus_s / sus_steps * 1e3, 4)}
 
     # The same steps through the reference's own boundary: host arrays in, host arrays out (clair_submit / clair_wait), timed like `value`.
     boundary = None
@@ -463,6 +511,17 @@ def run_ranked(args, group, json_fd):
         flips = sum(key(a) != key(b) for a, b in zip(rows_g, rows_w)) if len(rows_g) == len(rows_w) else None
         concord = {"candidates": ns, "vcf_rows": len(rows_w), "gt_identical": bool(same), "gt_flips": flips}
 
+    # every rank's GPU state per leg and CPU placement, to rank 0 (bookkeeping over the bootstrap sockets; JSON text, the wire format has no floats)
+    sampler.close()
+    my_state = {name: sampler.during(*span) for name, span in legs.items()}
+    my_state["source"], my_state["period_ms"] = sampler.source, sampler.period_ms
+    rank_notes = [json.loads(t_) for t_ in group.gather_objects(json.dumps({"gpu_state": my_state, "affinity": getattr(group, "affinity", None)}))]
+
+    gt200k = None
+    if rank == 0 and world == 1 and args.gt_candidates > 0:
+        gt200k = gt_concordance_at_scale(local_rank, w, args.gt_candidates, args.gt_seconds)
+        phases.append(["GT concordance at scale (a handle of its own: one slot, batch 4096)", None])
+
     rc = 0
     if rank == 0:
         total = sum(per_rank_candidates)          # real candidates: a shard's ragged last batch counts what it holds
@@ -526,15 +585,14 @@ def run_ranked(args, group, json_fd):
         if world > 1 and rccl_ranks != world:
             sys.stderr.write("bench.py: %d of %d ranks hold an RCCL communicator; reporting n_gpus=%d\n" % (rccl_ranks, world, rccl_ranks))
             rc = 1
-        sampler.close()
-        gpu_state = {name: sampler.during(*span) for name, span in legs.items()}
-        gpu_state["source"] = sampler.source
+        gpu_state = rank_notes[0]["gpu_state"]
         out = {
             "metric": "candidate sites/sec (whole node)",
             "value": round(value, 1),
             "value_boundary": round(boundary["float32"]["value"], 1) if boundary else None,
             "value_boundary_int16": round(boundary["int16"]["value"], 1) if boundary else None,
             "value_full_config": round(full["value"], 1) if full else None,
+            "value_sustained": round(sustained["value"], 1) if sustained else None,
             "value_boundary_full_config": round(boundary["float32_full"]["value"], 1) if boundary and "float32_full" in boundary else None,
             "unit": "candidates/s",
             "n_gpus": n_gpus,
@@ -550,15 +608,22 @@ def run_ranked(args, group, json_fd):
                                    "batch=%d, %d batches in flight per GPU, inputs resident in HBM"
                                    % (PLATFORM[args.platform], args.platform, batch, streams),
                        "batch": batch, "streams": streams, "candidates_total": total,
+                       "rates": {"value": "the contract's K timed steps (%d x %d candidates = %.1f ms): a burst right after the bracket's idle gap, the board not yet "
+                                          "at its power cap" % (steps_max, batch, elapsed * 1e3),
+                                 "value_full_config": "the config's whole candidate set (%d steps), timed the same way right after" % full["steps"] if full else None,
+                                 "value_sustained": "%d steps = %.2f s timed the same way: the board at its cap throughout (gpu_state.value_sustained); the rate "
+                                                    "a whole-genome run sees" % (sustained["steps"], sustained["seconds"]) if sustained else None},
                        "device_warm_steps": device_warm,
                        "device_warm_note": "untimed steps before the contract's --warmup (clock ramp, first touch); BENCH_WARM_STEPS=0 removes them",
                        "collective": "none on the data path; RCCL (clair_comm_*) for the weight broadcast, barrier and timers" if world > 1 else "none (1 rank)",
                        "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None,
                        "rccl_failure": getattr(group, "rccl_failure", None)},
-            "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None}
+            "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None,
+                          "affinity": rank_notes[r]["affinity"], "gpu_state": rank_notes[r]["gpu_state"] if world > 1 else "see gpu_state"}
                          for r, (s_, c_, t_) in enumerate(zip(per_rank_steps, per_rank_candidates, per_rank_s))],
             "boundary": boundary,
             "full_config": full,
+            "sustained": sustained,
             "gpu_state": gpu_state,
             "launch_phases": phases,
             "roofline": roof,
@@ -579,6 +644,7 @@ def run_ranked(args, group, json_fd):
             "kernels_alone_ms": kern_iso,
             "parity_max_abs_err": parity,
             "gt_concordance": concord,
+            "gt_concordance_200k": gt200k,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, x, args.cpu_seconds)

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("CLAIR_AMD_LIB") or os.path.join(_HERE, "libclair_amd.
 
 # every symbol include/clair_amd.h declares (tests/test_abi.py checks header <-> this list <-> .so)
 SYMBOLS = (
-    "clair_abi_version", "clair_device_count", "clair_last_error",
+    "clair_abi_version", "clair_device_count", "clair_device_pci_bus_id", "clair_last_error",
     "clair_engine_create", "clair_engine_destroy",
     "clair_set_tensor", "clair_finalize_weights",
     "clair_predict", "clair_submit", "clair_wait", "clair_slot_input", "clair_submit_counts", "clair_submit_ex", "clair_decode", "clair_pinned_alloc", "clair_pinned_free",
@@ -38,6 +38,11 @@ class EngineError(RuntimeError):
     pass
 
 
+def older_ok_early(path):
+    """An OLDER build of the same sources, named explicitly (A/B timing, tools/gpu/ab_libs.sh), may predate the newest entry points."""
+    return path is not None or bool(os.environ.get("CLAIR_AMD_LIB"))
+
+
 def load(path=None):
     """Load libclair_amd.so (CDLL: calls release the GIL, as TF's session.run does for the
     reference's predict thread, clair/call_var.py:1343).  `path` names another BUILD of the same sources (the wait-all check
@@ -56,6 +61,8 @@ def load(path=None):
     c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     lib.clair_abi_version.restype = c_int
     lib.clair_device_count.restype = c_int
+    if not older_ok_early(path) or hasattr(lib, "clair_device_pci_bus_id"):
+        lib.clair_device_pci_bus_id.argtypes = [c_int, ctypes.c_char_p, c_int]
     lib.clair_last_error.restype = ctypes.c_char_p
     lib.clair_last_error.argtypes = [c_vp]
     lib.clair_engine_create.argtypes = [c_int, c_int, c_int, ctypes.POINTER(c_vp)]

@@ -93,9 +93,13 @@ def commands(args):
     return out
 
 
-def run_worker(command_lines, device, readers):
-    """All chunks of one GPU in this process: one engine, `readers` front ends reading ahead."""
+def run_worker(command_lines, device, readers, all_devices=None):
+    """All chunks of one GPU in this process: one engine, `readers` front ends reading ahead.  With more than one GPU in use the worker
+    first pins itself to the host cores next to ITS GPU (clair_amd/shard.py: bind_worker; the reference pins its stages with taskset,
+    clair/callVarBam.py:103-115): the `samtools view` pipes it reads and its page-locked text buffers then live on that socket."""
     import logging
+    from . import shard
+    placed = shard.bind_worker(device, all_devices or [device])
     import queue
     import shlex
     import threading
@@ -103,6 +107,9 @@ def run_worker(command_lines, device, readers):
     from . import call_var as cv
     from . import callVarBam
     logging.basicConfig(format="%(message)s", level=logging.INFO)
+    if placed is not None:
+        logging.info("[INFO] worker of device %d: PCI %s, NUMA node %s, bound to cores %s%s" % (
+            device, placed["pci"], placed["numa_node"], placed["cpus_bound"], " (%s)" % placed["note"] if placed["note"] else ""))
     cv.ingest.setup_environment()
     parser = callVarBam.build_parser()
     jobs = []
@@ -187,7 +194,7 @@ def run(args, lines):
         for device, mine in sorted(per_device.items()):
             spec = os.path.join(tmp, "device_%d.json" % device)
             with open(spec, "w") as f:
-                json.dump({"device": device, "readers": args.readers, "commands": mine}, f)
+                json.dump({"device": device, "readers": args.readers, "commands": mine, "devices": sorted(per_device)}, f)
             procs.append(subprocess.Popen([args.python or sys.executable, "-m", "clair_amd.callVarBamParallel", "--worker", spec]))
         codes = [p.wait() for p in procs]
     if any(codes):
@@ -251,7 +258,7 @@ def main(argv=None):
     if args.worker is not None:
         import json
         spec = json.load(open(args.worker))
-        sys.exit(run_worker(spec["commands"], spec["device"], spec["readers"]))
+        sys.exit(run_worker(spec["commands"], spec["device"], spec["readers"], spec.get("devices")))
     if args.run:
         sys.exit(run(args, commands(args)))
     if not args.includingAllContigs:

@@ -4,6 +4,7 @@
 #include "../../include/clair_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 
 #include <algorithm>
 #include <atomic>
@@ -73,7 +74,7 @@ struct Slot {
     hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;   // input on the device / forward pass (and decode) finished / results on the host
     float *d_x = nullptr;     // [max_pad][1056]
     float *d_out = nullptr;   // [max_pad][90]
-    float *h_out = nullptr;   // pinned [max_batch][90] (+ the fused launch's error word)
+    float *h_out = nullptr;   // pinned [max_batch][90], then (h_word_offset) the fused launch's error word
     float *h_x = nullptr;     // pinned [max_batch][1056], allocated on first use
     short *d_counts = nullptr;   // [max_pad][1056] raw counts, allocated on first use
     char *d_records = nullptr;   // candidates copied with the caller's stride (binary tensor records as they lie), clair_submit_ex
@@ -118,6 +119,7 @@ struct clair_engine {
     bool tap_l3 = false;   // CLAIR_AMD_TAP_L3=1: l3l4_kernel also writes l3 into the (dead) zx workspace for clair_debug_read(4)
     std::string error;
     std::vector<std::pair<char *, size_t>> pinned;   // page-locked host buffers handed to the caller (clair_pinned_alloc)
+    mutable std::mutex pinned_mu;                    // the staging workers look buffers up while the caller may allocate another
     std::vector<Slot> slots;
     std::vector<std::unique_ptr<Lane>> lanes;
     std::vector<hipStream_t> copy_streams;   // owned here; the slots point into it
@@ -380,8 +382,17 @@ int enqueue_forward(clair_engine *e, Lane &s, const float *x_dev, float *out_dev
     return 0;
 }
 
+// A slot's page-locked input buffer exists from its first use -- by a staging worker (pageable float input) or by the caller
+// (clair_slot_input), whichever comes first: one allocation, under the lock the look-ups below take.
+int ensure_slot_input(clair_engine *e, Slot &s) {
+    std::lock_guard<std::mutex> g(e->pinned_mu);
+    if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+    return 0;
+}
+
 // does [p, p + len) lie inside a buffer of clair_pinned_alloc?  (then the DMA engine can read it directly)
 bool in_pinned(const clair_engine *e, const void *p, size_t len) {
+    std::lock_guard<std::mutex> g(e->pinned_mu);
     for (const auto &b : e->pinned)
         if ((const char *)p >= b.first && (const char *)p + len <= b.first + b.second) return true;
     return false;
@@ -469,6 +480,12 @@ __global__ __launch_bounds__(256) void counts_to_input_strided_kernel(const char
 }
 
 
+// Where the fused launch's error word lives in a slot's page-locked output buffer, in floats: the first 16-byte boundary past the
+// last uint4 the result kernel below may write for a full batch (it copies the probabilities as WHOLE vectors: for an odd n the last
+// one reaches 8 bytes past n * 360), so that neither that vector nor the end of the allocation can touch the word.
+static inline size_t h_word_offset(int max_batch) { return ((((size_t)max_batch * OUT_FLOATS * sizeof(float) + 15) / 16) * 16) / sizeof(float); }
+static inline size_t h_out_floats(int max_batch) { return h_word_offset(max_batch) + 4; }
+
 // results of a forward pass (and decode) to the slot's page-locked buffers, written by the GPU itself: no copy engine, no queue switch
 __global__ __launch_bounds__(256) void results_to_host_kernel(const uint4 *out, uint4 *h_out, int out_vec, const uint4 *calls, uint4 *h_calls, int call_vec,
                                                              const unsigned *word, unsigned *h_word) {
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(256) void results_to_host_kernel(const uint4 *out, 
 // outgoing stream (which may be the lane's own), then the event clair_wait sleeps on.
 int enqueue_results(clair_engine *e, Lane &l, Slot &s, int n, bool calls, bool probs) {
     unsigned *word = l.fuse_flags ? l.fuse_flags + fuse_words(e->max_pad) : nullptr;
-    unsigned *h_word = (unsigned *)(s.h_out + (size_t)e->max_batch * OUT_FLOATS);
+    unsigned *h_word = (unsigned *)(s.h_out + h_word_offset(e->max_batch));
     if (e->d2h_kernel) {
         const int out_vec = probs ? (n * OUT_FLOATS * (int)sizeof(float) + 15) / 16 : 0, call_vec = calls ? n * (int)sizeof(clair_call_t) / 16 : 0;
         hipLaunchKernelGGL(results_to_host_kernel, dim3((std::max(out_vec + call_vec, 1) + 255) / 256), dim3(256), 0, s.cout, (const uint4 *)s.d_out, (uint4 *)s.h_out, out_vec,
@@ -512,7 +529,9 @@ int enqueue_request(clair_engine *e, int slot_index, const clair_engine::Request
     const size_t row_bytes = CLAIR_INPUT_FLOATS * (q.counts ? sizeof(short) : sizeof(float));
     const size_t stride = q.stride ? (size_t)q.stride : row_bytes;
     const size_t span = (size_t)(n - 1) * stride + row_bytes;
-    const bool direct = (q.input == (const void *)s.h_x && stride == row_bytes && !q.counts) || in_pinned(e, q.input, span);
+    const float *own_input;
+    { std::lock_guard<std::mutex> g(e->pinned_mu); own_input = s.h_x; }
+    const bool direct = (q.input == (const void *)own_input && own_input && stride == row_bytes && !q.counts) || in_pinned(e, q.input, span);
     const bool on_device = !direct && is_device_pointer(q.input);   // e.g. the windows of clair_frontend_build_windows: no copy at all
     if (on_device && !q.counts) return fail(e, "a device pointer is taken for int16 counts only");
     enum { NONE, DENSE, STRIDED } convert = NONE;                    // the int16 -> float32 kernel the lane runs first
@@ -545,7 +564,7 @@ int enqueue_request(clair_engine *e, int slot_index, const clair_engine::Request
     } else {
         const void *src = q.input;
         if (!direct) {
-            if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+            if (ensure_slot_input(e, s)) return 1;
             gather_rows(s.h_x, q.input, n, row_bytes, q.stride);
             src = s.h_x;
         }
@@ -667,6 +686,16 @@ int clair_device_count(void) {
     return n;
 }
 
+int clair_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) return fail(nullptr, "clair_device_pci_bus_id: buffer of at least 16 bytes needed");
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(nullptr, "clair_device_pci_bus_id: no HIP device %d (%d visible)", device, n);
+    if (hipDeviceGetPCIBusId(buf, len, device) != hipSuccess) { buf[0] = 0; return fail(nullptr, "hipDeviceGetPCIBusId(%d) failed", device); }
+    for (char *c = buf; *c; ++c) *c = (char)tolower((unsigned char)*c);      // sysfs spells the hexadecimal digits in lower case
+    return 0;
+}
+
 const char *clair_last_error(const clair_engine_t *e) { return e ? e->error.c_str() : g_create_error.c_str(); }
 
 int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t **out) {
@@ -756,7 +785,7 @@ int clair_engine_create(int device, int max_batch, int n_slots, clair_engine_t *
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_x, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMemset(s.d_x, 0, mp * CLAIR_INPUT_FLOATS * sizeof(float));
         if (r == hipSuccess) r = hipMalloc((void **)&s.d_out, mp * OUT_FLOATS * sizeof(float));
-        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, ((size_t)max_batch * OUT_FLOATS + 1) * sizeof(float), hipHostMallocDefault);   // + the fused launch's error word
+        if (r == hipSuccess) r = hipHostMalloc((void **)&s.h_out, h_out_floats(max_batch) * sizeof(float), hipHostMallocDefault);   // + the fused launch's error word
     }
     if (r != hipSuccess) {
         fail(nullptr, "allocating workspaces for max_batch=%d, %d slot(s) failed: %s", max_batch, n_slots, hipGetErrorString(r));
@@ -946,7 +975,7 @@ int clair_slot_input(clair_engine_t *e, int slot, float **x_pinned) {
     if (!x_pinned) return fail(e, "x_pinned is NULL");
     HIP_TRY(e, hipSetDevice(e->device));
     Slot &s = e->slots[slot];
-    if (!s.h_x) HIP_TRY(e, hipHostMalloc((void **)&s.h_x, (size_t)e->max_batch * CLAIR_INPUT_FLOATS * sizeof(float), hipHostMallocDefault));
+    if (ensure_slot_input(e, s)) return 1;
     *x_pinned = s.h_x;
     return 0;
 }
@@ -976,7 +1005,7 @@ int clair_wait(clair_engine_t *e, int slot) {
     if (l.fuse_flags) {
         std::lock_guard<std::mutex> g(l.order);
         unsigned bad;
-        memcpy(&bad, s.h_out + (size_t)e->max_batch * OUT_FLOATS, sizeof bad);
+        memcpy(&bad, s.h_out + h_word_offset(e->max_batch), sizeof bad);
         bool mine = false;
         for (const auto &r : l.fused_runs) mine = mine || r.slot == slot;
         if (n && bad && mine) {   // re-run on the two-launch path (d_x still holds the input), fetch the outputs again
@@ -1170,22 +1199,29 @@ int clair_pinned_alloc(clair_engine_t *e, int64_t bytes, void **ptr) {
     HIP_TRY(e, hipSetDevice(e->device));
     void *p = nullptr;
     HIP_TRY(e, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
-    e->pinned.emplace_back((char *)p, (size_t)bytes);
+    {
+        std::lock_guard<std::mutex> g(e->pinned_mu);
+        e->pinned.emplace_back((char *)p, (size_t)bytes);
+    }
     *ptr = p;
     return 0;
 }
 
 int clair_pinned_free(clair_engine_t *e, void *ptr) {
     if (!e) return fail(nullptr, "engine is NULL");
+    bool known = false;
+    {
+        std::lock_guard<std::mutex> g(e->pinned_mu);
+        for (const auto &b : e->pinned) known |= b.first == (char *)ptr;
+    }
+    if (!known) return fail(e, "clair_pinned_free: not a buffer of clair_pinned_alloc");
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (quiesce(e)) return 1;   // no copy may still be reading it (and no staging worker is looking it up)
+    HIP_TRY(e, hipHostFree(ptr));
+    std::lock_guard<std::mutex> g(e->pinned_mu);
     for (size_t i = 0; i < e->pinned.size(); ++i)
-        if (e->pinned[i].first == (char *)ptr) {
-            HIP_TRY(e, hipSetDevice(e->device));
-            if (quiesce(e)) return 1;   // no copy may still be reading it
-            HIP_TRY(e, hipHostFree(ptr));
-            e->pinned.erase(e->pinned.begin() + (long)i);
-            return 0;
-        }
-    return fail(e, "clair_pinned_free: not a buffer of clair_pinned_alloc");
+        if (e->pinned[i].first == (char *)ptr) { e->pinned.erase(e->pinned.begin() + (long)i); break; }
+    return 0;
 }
 
 int clair_engine_counter(clair_engine_t *e, int which, int64_t *value) {

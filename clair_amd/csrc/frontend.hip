@@ -1396,12 +1396,14 @@ void clair_frontend_destroy(clair_frontend_t *f) {
     delete f;
 }
 
+__global__ void fe_flag_kernel(Region g, uint32_t bits) { atomicOr(g.anomalies, bits); }
+
 // Pass 1 over one slab.  The tiled kernel wherever its assumptions hold (fewer alignments in the slab than a 21-bit counter holds, so that a
 // tile's counters cannot carry into their neighbours); CLAIR_AMD_FE_TALLY=atomic keeps the per-base kernel (tests compare the two, bit for bit).
 // [p_first, p_reach): reference positions the slab may touch (a generous guess is fine, see fe_tally_tile_kernel).
-static int launch_tally(clair_frontend *f, const Slab &d, int64_t p_first, int64_t p_reach) {
+static int launch_tally(clair_frontend *f, const Slab &d, int64_t p_first, int64_t p_reach, bool sorted = true) {
     if (!d.n_elem) return 0;
-    if (f->tally_per_base || d.n_reads >= (int64_t)PQ_MASK) {
+    if (f->tally_per_base || d.n_reads >= (int64_t)PQ_MASK || !sorted) {   // the tiled kernel finds a tile's alignments by bisection over their starts
         hipLaunchKernelGGL(fe_tally_kernel, dim3(blocks_for(d.n_elem, 256)), dim3(256), 0, f->stream, f->g, f->view(d));
         return 0;
     }
@@ -1440,7 +1442,9 @@ int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int
     FE_TRY(f, hipMemsetAsync(d.tuples, 0, (size_t)n_reads * sizeof(uint64_t), f->stream));
     {   // where the slab lies, for the grid of the tiled tally: first and last start, the longest reach (host arrays: one look at every alignment's last operation)
         int64_t p_first = reads[0].pos0, p_last = reads[0].pos0, reach = 0;
+        bool sorted = true;
         for (int64_t i = 0; i < n_reads; ++i) {
+            sorted &= reads[i].pos0 >= p_last;      // p_last is still the largest start among 0 .. i-1
             p_first = std::min(p_first, reads[i].pos0);
             p_last = std::max(p_last, reads[i].pos0);
             if (reads[i].n_ops && (int64_t)reads[i].op0 + reads[i].n_ops <= n_ops) {
@@ -1448,7 +1452,11 @@ int clair_frontend_add_reads(clair_frontend_t *f, const clair_read_t *reads, int
                 reach = std::max(reach, (int64_t)o.ref_off + (int64_t)(o.code_len >> 2));
             }
         }
-        if (launch_tally(f, d, p_first, p_last + reach)) return 1;
+        // Starts that decrease inside a slab (a direct caller of this entry point; the packers raise the same bit themselves): the tallies stay
+        // right -- the per-base kernel does not care about order -- and the caller hears about it like about every other thing the reference's
+        // scripts would have treated differently (they stop at the first such line): CLAIR_FE_UNSORTED in the anomaly word.
+        if (!sorted) hipLaunchKernelGGL(fe_flag_kernel, dim3(1), dim3(1), 0, f->stream, f->g, (uint32_t)CLAIR_FE_UNSORTED);
+        if (launch_tally(f, d, p_first, p_last + reach, sorted)) return 1;
     }
     FE_TRY(f, hipGetLastError());
     // the caller's arrays may be reused as soon as this returns (the packer's slab is reset): wait for the copies

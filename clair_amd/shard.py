@@ -55,6 +55,160 @@ def rendezvous_path():
     return os.path.join(tempfile.gettempdir(), "clair_amd_rdzv_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
 
 
+# -- CPU placement of a rank ------------------------------------------------------------------------------------------------------------
+# The reference pins its pipeline stages to cores with taskset (clair/callVarBam.py:103-115).  Here a rank (bench.py --gpus N, a
+# callVarBamParallel --run worker) feeds ONE GPU through page-locked staging buffers; on a two-socket node the copies of a rank that runs
+# on the far socket cross the inter-socket link twice (pageable -> staging, staging -> PCIe root of the GPU).  So each rank binds itself to
+# the host cores next to ITS GPU: the device's PCI address (clair_device_pci_bus_id) names /sys/bus/pci/devices/<bdf>/{numa_node,
+# local_cpulist}; ranks whose GPUs share a node split that node's cores among themselves (contiguous slices, in rank order).  Nothing is
+# bound at world size 1 (the single-GPU runs behave as before) unless CLAIR_AMD_BIND=1; CLAIR_AMD_BIND=0 turns it off everywhere.
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format); anything malformed -> []."""
+    cpus = []
+    try:
+        for part in text.strip().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            lo, hi = int(a), int(b or a)
+            if hi < lo or hi - lo > 1 << 16:
+                return []
+            cpus.extend(range(lo, hi + 1))
+    except ValueError:
+        return []
+    return sorted(set(cpus))
+
+
+def gpu_locality(bdf, sysfs_root="/sys"):
+    """What the kernel says about the PCI device `bdf` ("0000:c1:00.0"): {"pci", "numa_node" (None when unknown / -1), "cpus"}."""
+    out = {"pci": bdf or None, "numa_node": None, "cpus": []}
+    if not bdf:
+        return out
+    base = os.path.join(sysfs_root, "bus", "pci", "devices", bdf)
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+        out["numa_node"] = node if node >= 0 else None
+    except (OSError, ValueError):
+        pass
+    try:
+        out["cpus"] = parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except OSError:
+        pass
+    if not out["cpus"] and out["numa_node"] is not None:      # some kernels leave local_cpulist empty for devices behind a switch
+        try:
+            out["cpus"] = parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "node", "node%d" % out["numa_node"], "cpulist")).read())
+        except OSError:
+            pass
+    return out
+
+
+def plan_affinity(localities, allowed):
+    """Per rank, the cores it should run on: its GPU's local cores that this process may use (`allowed`: the cgroup's / taskset's set),
+    split evenly among the ranks that share the same set (contiguous slices in rank order; a slice is never empty while there are cores).
+    None for a rank whose GPU has no known local cores inside `allowed`: that rank stays where the launcher put it."""
+    allowed = set(allowed)
+    usable = [tuple(c for c in loc.get("cpus", []) if c in allowed) for loc in localities]
+    plan = [None] * len(localities)
+    for cpus in set(u for u in usable if u):
+        sharers = [r for r, u in enumerate(usable) if u == cpus]
+        k = len(sharers)
+        for j, r in enumerate(sharers):
+            if len(cpus) >= k:
+                lo, hi = j * len(cpus) // k, (j + 1) * len(cpus) // k
+                plan[r] = list(cpus[lo:hi])
+            else:                        # more ranks than cores on this node: share all of them
+                plan[r] = list(cpus)
+    return plan
+
+
+def local_pci_bus_id(device):
+    """PCI address of HIP device `device` through the C ABI, or "" (no library, no device)."""
+    try:
+        import ctypes
+        from clair_amd import _capi
+        lib = _capi.load()
+        buf = ctypes.create_string_buffer(64)
+        if lib.clair_device_pci_bus_id(int(device), buf, 64) == 0:
+            return buf.value.decode()
+    except Exception:      # noqa: BLE001 -- placement is best effort; the engine itself reports a missing library / device
+        pass
+    return ""
+
+
+def bind_to_gpu(local_rank, peers_allgather=None, rank=0, sysfs_root="/sys", bdf=None, apply=True):
+    """Bind this process to the cores next to GPU `local_rank` (see above).  `peers_allgather`: a callable that exchanges one object with
+    every rank (NodeGroup's star) so that ranks sharing a NUMA node split its cores; without it the rank takes the whole node.
+    Returns the record bench.py prints per rank: {"pci", "numa_node", "cpus_local", "cpus_bound" (None: not bound), "note"}."""
+    loc = gpu_locality(local_pci_bus_id(local_rank) if bdf is None else bdf, sysfs_root)
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = []
+    everyone = peers_allgather([loc["pci"] or "", loc["numa_node"] if loc["numa_node"] is not None else -1, np.array(loc["cpus"], dtype=np.int64)]) if peers_allgather else None
+    if everyone is not None:
+        locs = [{"pci": e[0], "numa_node": e[1], "cpus": [int(c) for c in e[2]]} for e in everyone]
+        mine = plan_affinity(locs, allowed)[rank]
+    else:
+        mine = plan_affinity([loc], allowed)[0]
+    rec = {"pci": loc["pci"], "numa_node": loc["numa_node"], "cpus_local": len(loc["cpus"]), "cpus_allowed": len(allowed), "cpus_bound": None, "note": None}
+    if not mine:
+        rec["note"] = "no local cores known for this GPU inside the allowed set: left where the launcher put it"
+        return rec
+    if apply:
+        try:
+            os.sched_setaffinity(0, mine)
+        except (AttributeError, OSError) as e:
+            rec["note"] = "sched_setaffinity refused: %s" % e
+            return rec
+    rec["cpus_bound"] = _compress_cpulist(mine)
+    return rec
+
+
+def bind_worker(device, all_devices, sysfs_root="/sys", apply=True):
+    """The same for processes that never talk to each other (callVarBamParallel --run: one worker per GPU): every worker looks up the
+    PCI address of EVERY worker's device itself, so all of them arrive at the same split.  Bound only when more than one GPU is in use
+    (or CLAIR_AMD_BIND=1)."""
+    devices = sorted(set(int(d_) for d_ in all_devices))
+    if not want_binding(len(devices)) or int(device) not in devices:
+        return None
+    locs = [gpu_locality(local_pci_bus_id(d_), sysfs_root) for d_ in devices]
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    me = devices.index(int(device))
+    mine = plan_affinity(locs, allowed)[me]
+    rec = {"pci": locs[me]["pci"], "numa_node": locs[me]["numa_node"], "cpus_local": len(locs[me]["cpus"]), "cpus_allowed": len(allowed), "cpus_bound": None, "note": None}
+    if not mine:
+        rec["note"] = "no local cores known for this GPU inside the allowed set"
+        return rec
+    if apply:
+        try:
+            os.sched_setaffinity(0, mine)
+        except (AttributeError, OSError) as e:
+            rec["note"] = "sched_setaffinity refused: %s" % e
+            return rec
+    rec["cpus_bound"] = _compress_cpulist(mine)
+    return rec
+
+
+def _compress_cpulist(cpus):
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append("%d" % cpus[i] if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def want_binding(world):
+    v = os.environ.get("CLAIR_AMD_BIND", "")
+    return v == "1" or (v != "0" and world > 1)
+
+
 # -- wire format of the bootstrap / CPU transport ------------------------------------------------------------------------------------
 # Fixed framing, no pickle: a peer on 127.0.0.1 can make a rank parse bytes, never run code.  frame = b"CLSH" | kind u8 | 3 pad |
 # payload length u64 | payload.  kinds: 0 None, 1 int64, 2 bytes, 3 utf-8 string, 4 ndarray (dtype code u8, ndim u8, 6 pad, dims
@@ -290,9 +444,11 @@ class _TcpStar(object):
 class NodeGroup(object):
     """The ranks of one node, from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE, as
     set by torch.distributed.run or by bench.py's own spawner).  With WORLD_SIZE == 1 nothing is
-    opened.  transport: "rccl" | "tcp" | None (= "rccl" when the HIP library sees a device, else "tcp")."""
+    opened.  transport: "rccl" | "tcp" | None (= "rccl" when the HIP library sees a device, else "tcp").
+    bind: pin this process to the host cores of its GPU's NUMA node (None: when WORLD_SIZE > 1 and the transport is not the CPU one, or
+    CLAIR_AMD_BIND=1; `sysfs_root` / `bdf` exist for the CPU tests); the record is `self.affinity`."""
 
-    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None):
+    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None, bind=None, sysfs_root="/sys", bdf=None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank))) if local_rank is None else int(local_rank)
@@ -304,6 +460,12 @@ class NodeGroup(object):
         self._comm = None
         self.timeout = timeout
         self._star = _TcpStar(self.rank, self.world, rendezvous_path(), timeout)
+        # every rank next to its own GPU (see bind_to_gpu), before any buffer of the engine is allocated and first touched
+        self.affinity = None
+        if bind is None:
+            bind = want_binding(self.world) and transport != "tcp"
+        if bind:
+            self.affinity = bind_to_gpu(self.local_rank, self._star.allgather if self.world > 1 else None, self.rank, sysfs_root=sysfs_root, bdf=bdf)
         if self.world == 1:
             return
         if transport is None:
@@ -396,6 +558,11 @@ class NodeGroup(object):
         v = np.zeros(self.world, dtype=np.float64)
         v[self.rank] = float(value)
         return [float(t) for t in self._reduce_f64(v, "sum")]
+
+    def gather_objects(self, obj):
+        """One small object per rank (None, int, str, bytes, arrays, lists / tuples of those), in rank order, on every rank -- always over
+        the bootstrap sockets: bookkeeping (placement records, sampled clocks), never data."""
+        return self._star.allgather(obj)
 
     def broadcast_array(self, array, root=0):
         """`array` (same shape and dtype on every rank; contents matter on `root` only) filled from root's copy."""

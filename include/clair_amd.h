@@ -26,8 +26,9 @@ extern "C" {
 
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
  * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3).
- * 4: + the clair_frontend_* device front end; clair_submit_ex takes device pointers (round 3). */
-#define CLAIR_ABI_VERSION 4
+ * 4: + the clair_frontend_* device front end; clair_submit_ex takes device pointers (round 3).
+ * 5: + clair_device_pci_bus_id (round 5: a rank finds the NUMA node of ITS GPU, clair_amd/shard.py). */
+#define CLAIR_ABI_VERSION 5
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
 #define CLAIR_POSITIONS 33
@@ -98,6 +99,11 @@ const char *clair_last_error(const clair_engine_t *e);
 int clair_abi_version(void);
 /* number of HIP devices visible (0 when there is none); negative never */
 int clair_device_count(void);
+/* "dddd:bb:dd.f" of HIP device `device` into buf (NUL-terminated; len >= 16): the name of its directory under
+ * /sys/bus/pci/devices, where numa_node and local_cpulist say which host cores sit next to it.  The reference pins its
+ * stages to cores with taskset (clair/callVarBam.py:103-115); a rank of this library pins itself to the cores of its GPU's
+ * NUMA node (clair_amd/shard.py: bind_to_gpu).  0 on success; 1 when there is no such device (buf[0] = 0). */
+int clair_device_pci_bus_id(int device, char *buf, int len);
 
 /* -- weights: Clair.restore_parameters()  (clair/model.py:1016-1020) ----------------------------
  * Hand over one tensor (host pointer, `count` floats, shape as in enum clair_tensor_id);
@@ -256,7 +262,10 @@ int clair_frontend_create(int device, const char *ref_seq, int64_t ref_len, int6
                           clair_frontend_t **out);
 void clair_frontend_destroy(clair_frontend_t *f);
 const char *clair_frontend_last_error(const clair_frontend_t *f);      /* f may be NULL: failure of create */
-/* Copy one slab to the device (it stays there) and add its bases to the per-position tables.  The arrays may be reused on return. */
+/* Copy one slab to the device (it stays there) and add its bases to the per-position tables.  The arrays may be reused on return.
+ * The alignments of a slab are expected in ascending order of pos0 (what `samtools view` of a sorted BAM prints and both packers
+ * keep); a slab whose starts decrease is still tallied correctly (by the order-independent per-base kernel) and sets
+ * CLAIR_FE_UNSORTED in stats[0] of clair_frontend_stats, like the packers do: the reference's scripts would have stopped there. */
 int clair_frontend_add_reads(clair_frontend_t *f, const struct clair_read *reads, int64_t n_reads, const struct clair_op *ops, int64_t n_ops,
                              const uint32_t *op_elem, const uint8_t *seq, int64_t seq_bytes);
 /* ... or hand over the `samtools view` TEXT and let the device do the packing as well: the line handling of both scripts

@@ -398,6 +398,26 @@ def test_differential_fuzz_with_the_text_parsed_on_the_device(block):
     assert done > 300
 
 
+def test_an_unsorted_slab_from_a_direct_caller_is_tallied_right_and_reported():
+    """clair_frontend_add_reads with the alignments of a slab in shuffled order: the tiled tally bisects over the starts, so the
+    slab goes through the order-independent per-base kernel instead, and CLAIR_FE_UNSORTED is raised as the packers would have raised it."""
+    case = fc.synth(seed=77, n_reads=500, ref_len=3000)
+    (r, o, e, q), st = host_packed(case)
+    assert st["anomalies"] == 0
+    lo, hi = case["ref0"] - 64, case["ref0"] + len(case["ref"]) + 64
+    f = _capi.Frontend(0, case["ref"], case["ref0"], lo, hi)
+    f.add_arrays(r, o, e, q)
+    g = _capi.Frontend(0, case["ref"], case["ref0"], lo, hi)
+    perm = np.random.default_rng(5).permutation(len(r))
+    assert (np.diff(r["pos0"][perm].astype(np.int64)) < 0).any()
+    g.add_arrays(r[perm], o, e, q)          # the records keep pointing at their own operations and bases: only the order of starts changes
+    assert f.stats()["anomalies"] == 0 and g.stats()["anomalies"] == fe.A_UNSORTED
+    for x in (f, g):
+        x.find_candidates(min_coverage=3, threshold=0.1)
+    assert len(f.candidates()) > 20 and np.array_equal(f.candidates(), g.candidates())
+    f.close(); g.close()
+
+
 def test_differential_fuzz_with_leading_indels_on_the_device():
     """As tests/test_frontend.py::test_differential_fuzz_with_leading_indels, through both packing paths of the device front end."""
     silent = reported = 0

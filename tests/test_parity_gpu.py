@@ -210,6 +210,35 @@ def test_fused_launch_failure_degrades_to_the_two_launch_path(synth_weights, mon
     assert np.array_equal(out, np.concatenate(want * 4))
 
 
+@pytest.mark.parametrize("n_slots", [1, 2])
+def test_an_odd_full_batch_does_not_touch_the_fused_error_word(synth_weights, n_slots):
+    """the kernel that writes a batch's results into page-locked host memory copies whole 16-byte vectors, so for an odd n
+    the last one reaches 8 bytes past n * 360 -- onto the fused launch's error word when n == max_batch and the word sat right behind
+    the rows.  The word now lives past the last vector a full batch can write (engine.hip: h_word_offset): a full odd batch on a handle
+    that keeps the fused launch must need no recovery, pass after pass, and the rows stay what the even-sized handle gives."""
+    from clair_amd import _capi
+    n = 1001
+    x, _ = synth.synthetic_input(n, "ont", seed=1001)
+    ref = _capi.Engine(device=0, max_batch=1024, n_slots=3)
+    try:
+        ref.load_weights(synth_weights)
+        want = ref.predict(x)
+    finally:
+        ref.close()
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=n_slots)
+    try:
+        eng.load_weights(synth_weights)
+        fused = eng.kernel_workgroups(n)["proj2"] == 0
+        for rep in range(6):
+            got = eng.predict(x)
+            for g, w_ in zip(got, want):
+                assert np.array_equal(g, w_), rep
+        assert eng.counter("fused_recoveries") == 0
+        assert (eng.kernel_workgroups(n)["proj2"] == 0) == fused      # nothing latched the handle onto the other path
+    finally:
+        eng.close()
+
+
 def test_outputs_do_not_depend_on_the_execution_mode(synth_weights):
     """The same 16 384 candidates through every slots x batch-size combination (which selects the kernels: two launches or the fused
     one, one- or two-tile LSTM2, 128 or 256 projection workgroups), three passes each: every output must equal the first pass of

@@ -94,6 +94,25 @@ def test_two_ranks_own_spawner_shards_match_single_process(tmp_path):
     _check(out, stdout)
 
 
+def test_eight_ranks_own_spawner_shards_match_single_process(tmp_path):
+    """The same at the world size of the node the scaling bench runs on (VERDICT r04 "missing" 5): rendezvous of eight processes, the star
+    all-gather, the weight blob over the sockets, shards of 37 candidates in batches of 8 -- three ranks get nothing at all -- and the
+    gathered rows still equal the single-process result bit for bit."""
+    out = str(tmp_path / "gathered.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out, "gloo": False})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 8, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    stdout = procs[0].stdout.read().decode()
+    assert [p.wait(timeout=600) for p in procs] == [0] * 8
+    line = [ln for ln in stdout.splitlines() if ln.startswith("RESULT")][0]
+    assert line.split()[1:5] == ["37", "8.0", "37", "tcp"] and "[10.0, 20.0, 30.0, 40.0, 50.0, 60.0, 70.0, 80.0]" in line
+    from clair_amd import synth, weights
+    from oracle import c_oracle
+    want = np.concatenate(c_oracle.forward(weights.synthetic_weights(seed=5), synth.synthetic_input(37, "ont", seed=9)[0], threads=1), axis=1)
+    assert np.array_equal(np.load(out), want)
+    assert [shard.shard_batches(37, 8, r, 8)[1] for r in range(8)] == [8, 8, 8, 8, 5, 0, 0, 0]
+
+
 def test_two_ranks_under_torch_distributed_run_cross_checked_with_gloo(tmp_path):
     out = str(tmp_path / "gathered.npy")
     script = tmp_path / "worker.py"
@@ -335,8 +354,11 @@ BENCH_WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("args,total", [(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline", "--full-candidates", "640"], 2 * 6 * 64),
-                                        (["--gpus", "2", "--scaling", "strong", "--candidates", "1000", "--batch", "64", "--warmup", "1", "--no-cpu-baseline"], 1000)])
+@pytest.mark.parametrize("args,total", [(["--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64", "--no-cpu-baseline", "--full-candidates", "640", "--sustained-seconds", "0.05"], 2 * 6 * 64),
+                                        (["--gpus", "2", "--scaling", "strong", "--candidates", "1000", "--batch", "64", "--warmup", "1", "--no-cpu-baseline"], 1000),
+                                        (["--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu-baseline", "--full-candidates", "96", "--sustained-seconds", "0.02"], 8 * 3 * 32),
+                                        (["--gpus", "8", "--scaling", "strong", "--candidates", "1000", "--batch", "64", "--warmup", "1", "--no-cpu-baseline"], 1000)],
+                         ids=["weak-2", "strong-2", "weak-8", "strong-8"])
 def test_bench_two_rank_flow_with_a_stand_in_engine(tmp_path, args, total):
     """bench.py's multi-rank bookkeeping on two CPU ranks (the engine replaced by the oracle, the sockets as transport): one JSON line from
     rank 0, per-rank table, real candidate counts under strong scaling -- and, since no rank holds an RCCL communicator, n_gpus 0 and a
@@ -344,28 +366,117 @@ def test_bench_two_rank_flow_with_a_stand_in_engine(tmp_path, args, total):
     import json
     script = tmp_path / "worker.py"
     script.write_text(BENCH_WORKER % {"root": ROOT, "args": args})
-    env = dict(os.environ, BENCH_WARM_STEPS="0", OMP_NUM_THREADS="2")
-    procs = shard.spawn_ranks([sys.executable, str(script)], 2, env=env, stderr_pipe=True)
+    world = int(args[1])
+    env = dict(os.environ, BENCH_WARM_STEPS="0", OMP_NUM_THREADS="2" if world == 2 else "1")
+    procs = shard.spawn_ranks([sys.executable, str(script)], world, env=env, stderr_pipe=True)
     out = procs[0].stdout.read().decode()
     errs = [p.stderr.read().decode() for p in procs]
-    rcs = [p.wait(timeout=300) for p in procs]
-    assert rcs[1] == 0 and rcs[0] == 1, errs
-    assert "0 of 2 ranks hold an RCCL communicator" in errs[0]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs[1:] == [0] * (world - 1) and rcs[0] == 1, errs
+    assert "0 of %d ranks hold an RCCL communicator" % world in errs[0]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 0 and d["config"]["transport"] == "tcp" and d["config"]["ranks_with_rccl_communicator"] == 0
-    assert len(d["per_rank"]) == 2 and sum(r["candidates"] for r in d["per_rank"]) == total == d["config"]["candidates_total"]
+    assert len(d["per_rank"]) == world and sum(r["candidates"] for r in d["per_rank"]) == total == d["config"]["candidates_total"]
+    # every rank reports the state of ITS GPU per leg and where it was placed (no GPU here: no PCI address, nothing bound, and the record says so)
+    assert all(set(r["gpu_state"]["value"]) == {"sclk_mhz", "power_w", "samples"} for r in d["per_rank"])
+    assert all(r["affinity"]["cpus_bound"] is None and r["affinity"]["pci"] is None and "left where the launcher put it" in r["affinity"]["note"] for r in d["per_rank"])
+    assert d["gpu_state"]["period_ms"] == 10.0 and d["gt_concordance_200k"] is None
     assert d["scaling"] == ("strong" if "strong" in args else "weak") and d["parity_max_abs_err"] == 0.0
     assert d["value"] > 0 and d["steps"] == max(r["steps"] for r in d["per_rank"])          # the slowest rank's step count; times are fake here
+    if "strong" in args and world == 8:
+        assert [r["candidates"] for r in d["per_rank"]] == [128, 128, 128, 128, 128, 128, 128, 104]     # 16 batches of 64 dealt over 8 ranks, the ragged one last
     assert "cpu_baseline" not in d and d["roofline"]["kernel"].split()[0] == "proj2"
     # the legs behind the contract's timed region: the host-array boundary (timed like `value`), the whole candidate set, the GPU's state
     b = d["boundary"]
     assert d["value_boundary"] == b["float32"]["value"] > 0 and d["value_boundary_int16"] == b["int16"]["value"] > 0 and b["bit_identical_to_resident"] is True
     assert b["slots"] == 6 and b["float32"]["steps"] == d["steps"] and b["float32"]["h2d_bytes_per_candidate"] == 4224 and b["int16"]["h2d_bytes_per_candidate"] == 2112
     if "strong" in args:
-        assert d["value_full_config"] is None and d["full_config"] is None and "float32_full" not in b
+        assert d["value_full_config"] is None and d["full_config"] is None and "float32_full" not in b and d["value_sustained"] is None
     else:
-        assert d["full_config"]["steps"] == 10 and d["value_full_config"] > 0 and d["value_boundary_full_config"] == b["float32_full"]["value"] > 0
+        assert d["full_config"]["steps"] == (10 if world == 2 else 3) and d["value_full_config"] > 0 and d["value_boundary_full_config"] == b["float32_full"]["value"] > 0
+        # the sustained leg: at least the asked-for time at the rate the whole-set leg showed, the same step count on every rank, timed like `value`
+        assert d["value_sustained"] == d["sustained"]["value"] > 0 and d["sustained"]["steps"] >= d["steps"] and "value_sustained" in d["gpu_state"]
+        assert set(d["config"]["rates"]) == {"value", "value_full_config", "value_sustained"} and all(d["config"]["rates"].values())
         assert "value_full_config" in d["gpu_state"] and "value_boundary_float32_full" in d["gpu_state"]
     assert set(d["gpu_state"]["value"]) == {"sclk_mhz", "power_w", "samples"} and "value_boundary" in d["gpu_state"]
+
+
+def _fake_sysfs(root, devices, nodes):
+    """devices: {bdf: (numa_node, local_cpulist text)}; nodes: {node: cpulist text}"""
+    for bdf, (node, cpus) in devices.items():
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+        (d / "local_cpulist").write_text(cpus + "\n")
+    for node, cpus in nodes.items():
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def test_cpu_placement_follows_the_numa_node_of_each_ranks_gpu(tmp_path):
+    """the reference pins its stages with taskset (clair/callVarBam.py:103-115); a rank pins itself to the cores next
+    to ITS GPU.  sysfs is faked: eight GPUs, four per socket (the shape of an MI355X node), one of them with an empty local_cpulist (the
+    node's own list is used), one with numa_node -1 (left alone)."""
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and shard.parse_cpulist("") == [] and shard.parse_cpulist("3-1") == []
+    assert shard.parse_cpulist("junk") == [] and shard._compress_cpulist([5, 0, 1, 2, 9, 10]) == "0-2,5,9-10"
+    devs = {"0000:%02x:00.0" % (0x10 + k): (k // 4, "0-63,128-191" if k < 4 else "64-127,192-255") for k in range(8)}
+    devs["0000:15:00.0"] = (1, "")              # rank 5: list missing -> node1's cpulist
+    devs["0000:17:00.0"] = (-1, "")             # rank 7: the kernel does not know
+    _fake_sysfs(tmp_path, devs, {0: "0-63,128-191", 1: "64-127,192-255"})
+    locs = [shard.gpu_locality("0000:%02x:00.0" % (0x10 + k), str(tmp_path)) for k in range(8)]
+    assert [l_["numa_node"] for l_ in locs] == [0, 0, 0, 0, 1, 1, 1, None] and len(locs[5]["cpus"]) == 128 and locs[7]["cpus"] == []
+    plan = shard.plan_affinity(locs, range(256))
+    assert [shard._compress_cpulist(p) if p else None for p in plan] == ["0-31", "32-63", "128-159", "160-191", "64-105", "106-127,192-212", "213-255", None]
+    # every core of a node goes to exactly one of the ranks that share it; nothing crosses sockets
+    assert sorted(sum(plan[:4], [])) == locs[0]["cpus"] and sorted(sum(plan[4:7], [])) == locs[4]["cpus"]
+    # a cgroup that grants 16 cores of socket 0 only: the ranks of socket 0 split those, the others stay where they are
+    small = shard.plan_affinity(locs, range(16))
+    assert small[:4] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]] and small[4:] == [None] * 4
+    # more ranks than cores: shared, never empty
+    assert shard.plan_affinity(locs[:4], [0, 1]) == [[0, 1]] * 4
+    assert shard.gpu_locality("", str(tmp_path))["cpus"] == [] and shard.gpu_locality("0000:99:00.0", str(tmp_path))["numa_node"] is None
+
+
+AFFINITY_WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %(root)r)
+    from clair_amd import shard
+    r = int(os.environ["RANK"])
+    g = shard.NodeGroup(transport="tcp", bind=True, sysfs_root=%(sysfs)r, bdf="0000:%%02x:00.0" %% (0x10 + r))
+    g.barrier()
+    open(%(out)r + str(r), "w").write(json.dumps({"affinity": g.affinity, "now": sorted(os.sched_getaffinity(0))}))
+    g.close()
+""")
+
+
+def test_eight_ranks_bind_themselves_next_to_their_gpus(tmp_path):
+    """The whole path on eight real processes: every rank reads its GPU's node from (fake) sysfs, the ranks exchange what they found over
+    the bootstrap sockets, ranks that share a node split its cores, and os.sched_setaffinity is really applied (the cores of this
+    container: the first half plays socket 0, the second socket 1)."""
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 2:
+        pytest.skip("one core: nothing to split")
+    half = len(cores) // 2
+    lists = [",".join(map(str, cores[:half])), ",".join(map(str, cores[half:]))]
+    sysfs = tmp_path / "sys"
+    _fake_sysfs(sysfs, {"0000:%02x:00.0" % (0x10 + k): (k // 4, lists[k // 4]) for k in range(8)}, {0: lists[0], 1: lists[1]})
+    script = tmp_path / "worker.py"
+    script.write_text(AFFINITY_WORKER % {"root": ROOT, "sysfs": str(sysfs), "out": str(tmp_path / "rank")})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 8)
+    assert [p.wait(timeout=120) for p in procs] == [0] * 8
+    import json
+    recs = [json.loads((tmp_path / ("rank%d" % r)).read_text()) for r in range(8)]
+    for r, rec in enumerate(recs):
+        mine = cores[:half] if r < 4 else cores[half:]
+        assert rec["affinity"]["numa_node"] == r // 4 and rec["affinity"]["pci"] == "0000:%02x:00.0" % (0x10 + r)
+        assert rec["now"] and set(rec["now"]) <= set(mine) and rec["affinity"]["cpus_bound"] == shard._compress_cpulist(rec["now"])
+    for k, side in enumerate((recs[:4], recs[4:])):
+        got = sum((rec["now"] for rec in side), [])
+        if half >= 4:
+            assert sorted(got) == (cores[half:] if k else cores[:half])       # a partition of the node's cores
+    # world size 1 is left alone unless asked (no behavioural change for the single-GPU runs)
+    assert shard.want_binding(1) is False and shard.want_binding(8) is True
+    assert shard.NodeGroup(transport="tcp", rank=0, world=1, local_rank=0).affinity is None
