@@ -23,6 +23,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;     // optional: tear-down that does not wait for peers
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
@@ -50,6 +51,7 @@ Rccl &rccl() {
         CLAIR_SYM(AllReduce, "ncclAllReduce")
         CLAIR_SYM(AllGather, "ncclAllGather")
 #undef CLAIR_SYM
+        q.CommAbort = (decltype(q.CommAbort))dlsym(q.handle, "ncclCommAbort");
         return q;
     }();
     return r;
@@ -166,6 +168,17 @@ void clair_comm_destroy(clair_comm_t *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// Tear-down of a communicator whose peers may never have come up (one rank's ncclCommInitRank failed while this one's succeeded):
+// ncclCommDestroy is collective in effect -- it flushes outstanding work and may wait for a peer that is not there -- ncclCommAbort is not.
+void clair_comm_abort(clair_comm_t *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)(rccl().CommAbort ? rccl().CommAbort(c->comm) : rccl().CommDestroy(c->comm));
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

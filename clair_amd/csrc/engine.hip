@@ -103,10 +103,13 @@ struct clair_engine {
     unsigned timing_mask = 0;   // bit k: kernel id k is bracketed by HIP events (clair_timing_enable)
     int lstm2_pair = -1;       // LSTM2 as two tiles per workgroup (lstm32_pair.hip.h): -1 = from 64 tiles (2048 candidates) on, where it wins
                                // 1-2 % (profiles/r02_lstm2_pair_by_batch.txt; at 1024 the kernel's own latency, 128 vs 81 us, costs 5 %); CLAIR_AMD_LSTM2_PAIR=0/1 forces
-    std::atomic<int> lstm2_fused{-1};      // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h): -1 = on handles with one or
-                               // two slots for 512 .. 2048 candidates (one slot: 104 us instead of 47 + 78 at batch 1024, +8 % per pass; two slots:
-                               // 6.86 against 6.4 M/s; profiles/r02_lstm2_fused.txt); with three batches in flight the two launches pack
-                               // better (7.5 against 7.4 M/s).  CLAIR_AMD_LSTM2_FUSED=0/1 forces
+    std::atomic<int> lstm2_fused{0};       // layer 2 as ONE launch, projection and recurrence side by side (lstm2_fused.hip.h).  OPT-IN since round 5
+                               // (CLAIR_AMD_LSTM2_FUSED=1): its zx hand-off is ordered by the L2 of ONE XCD -- the producer's stores retired into it, then
+                               // its ticket -- which is how the hardware works and what every launch checks its placement for, but it is not a release
+                               // the HIP memory model has a name for, and the release it does have (buffer_wbl2 per publication) costs more than the
+                               // launch saves (0.5 us per write-back and XCD; even one per (direction, t) group leaves the launch
+                               // slower than the two it replaces).  The default path of every handle is therefore the two launches, ordered by the
+                               // stream.  What the fused launch bought on one- and two-slot handles: 104 us instead of 47 + 78 at batch 1024.
     int fused_groups = 4;      // projection workgroup groups per XCD inside the fused launch (CLAIR_AMD_FUSED_GROUPS)
     int64_t fused_launches = 0;   // fused launches of this handle so far
     int64_t fused_fault_at = 0;   // test hook CLAIR_AMD_FUSED_FAULT=k: the k-th fused launch finds logical id 0 already claimed (the kernel
@@ -309,7 +312,7 @@ int drain_timers(clair_engine *e) {
     return 0;
 }
 
-bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1 || (e->lstm2_fused < 0 && e->lanes.size() <= 2); }
+bool fused_possible(const clair_engine *e) { return e->lstm2_fused == 1; }
 bool use_lstm2_fused(const clair_engine *e, int ntiles) {   // pairs of tiles share a 64-row activation tile: even tile counts only
     if ((ntiles & 1) || !fused_possible(e)) return false;
     return e->lstm2_fused == 1 || (ntiles >= 16 && ntiles <= 64);   // 512 .. 2048 candidates: beyond, every kernel fills the chip by itself and

@@ -94,6 +94,77 @@ __device__ __forceinline__ void mfma32_vv_first(f32x16 &acc, const f16x8 &a, con
 }
 
 constexpr float GATE_K2 = 2.0f * 1.44269504088896340736f;
+constexpr float GATE_BIG = 0x1p63f;   // clamp of 2^(2 log2(e) g): beyond it tanh(g) = 1 in float32 anyway, and (e - 1) / ((1 + e)(...)) stays inf-free
+
+// ---- Gate arithmetic of one block (4 hidden units of one candidate per lane), shared by lstm32_body and lstm32_pair_kernel ----
+// The block's accumulator Z holds v_exp_f32 arguments (pre-scaled rows, see the header): 2^Z = e^-i, e^2g, e^-f, e^-o.  Round 5
+// ("arithmetic v2"): EIGHT transcendentals per hidden unit and step instead of ten -- each product of a
+// sigmoid and a tanh takes ONE reciprocal:
+//     K2 sig(i) tanh(g) = K2 (eg - 1) / ((1 + ei)(1 + eg))          c' <- c' / (1 + ef) + that        (c' = K2 c, K2 = 2 log2 e)
+//     h = sig(o) tanh(c) = (ec - 1) / ((1 + eo)(1 + ec)),  ec = 2^c'
+// What keeps inf and NaN out: eg is clamped to 2^63 (tanh is 1 in float32 long before; without it inf / inf), every other
+// exponential may be inf -- it only ever sits in a denominator whose numerator is finite: (1 + ei) = inf gives rcp = 0 and
+// K2 (eg - 1) * 0 = 0, the limit; ec <= 2^96 because |c| <= 33 (one unit per step at most).  A denominator that overflows
+// although the value is representable (ei > 2^65 with eg at its clamp) returns 0 for something below 2^-65.
+// Static schedule of 23 "gaps" (gap G is issued right after MFMA G of the block that follows): inside a gap the instructions
+// are independent, every operand is at least one gap old, at most three are transcendental, the accumulator is read in gaps
+// 1-6 only, and every gap costs at most 24 issue cycles (8 per transcendental, 4 per other instruction; tools/ubench/
+// mfma_gap_mix.hip).  Registers: eg ei ef eo tt ng hh (4 each) + hp lp (2 each); eg / ei / ng are reused along the way:
+//   E  2^Z             MN eg = min(eg, 2^63)     NG ng = K2 eg - K2        A  x += 1
+//   P  eg = (1+eg)(1+ei)    R rcp                T  tt = ng / P            C  c' = c' rcp(1+ef) + tt
+//   X  ei = 2^c'       AC eg = ei + 1            NC ng = ei - 1            Q  eg = (1+ec)(1+eo)       H  h = ng rcp(eg)
+//   HP / D / LP: the fp16 split of h, two elements per instruction (v_cvt_pk_f16_f32; the residual h - float(hi) is one
+//   v_fma_mix_f32 that converts the selected half on the fly).  The last gap stores the lane's four h values, 8 bytes per plane.
+// Placement: a sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that opens its gap; pinning its
+// OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking below the MFMA that closes it.
+// Not two elements per instruction: v_pk_add/mul/fma_f32 wait for the matrix pipe (a block went 940 -> 1200 cycles, round 4).
+#define CG_PIN(x) asm volatile("" : "+v"(x));
+#define CG_E(R, C, e) { R[e] = __builtin_amdgcn_exp2f(Z[4 * (e) + (C)]); CG_PIN(R[e]) }
+#define CG_MN(e) asm volatile("v_min_f32 %0, %1, %0" : "+v"(eg[e]) : "s"(GATE_BIG));
+#define CG_NG(e) { ng[e] = fmaf(eg[e], GATE_K2, -GATE_K2); CG_PIN(ng[e]) }
+#define CG_A(R, e) { R[e] += 1.0f; CG_PIN(R[e]) }
+#define CG_P(e) { eg[e] = eg[e] * ei[e]; CG_PIN(eg[e]) }
+#define CG_R(R, e) { R[e] = fast_rcp(R[e]); CG_PIN(R[e]) }
+#define CG_T(e) { tt[e] = ng[e] * eg[e]; CG_PIN(tt[e]) }
+#define CG_C(e) { C_[e] = fmaf(ef[e], C_[e], tt[e]); CG_PIN(C_[e]) }
+#define CG_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); CG_PIN(ei[e]) }
+#define CG_AC(e) { eg[e] = ei[e] + 1.0f; CG_PIN(eg[e]) }
+#define CG_NC(e) { ng[e] = ei[e] - 1.0f; CG_PIN(ng[e]) }
+#define CG_Q(e) { eg[e] = eg[e] * eo[e]; CG_PIN(eg[e]) }
+#define CG_H(e) { hh[e] = ng[e] * eg[e]; CG_PIN(hh[e]) }
+#define CG_HP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[q]) : "v"(hh[2 * (q)]), "v"(hh[2 * (q) + 1]));
+#define CG_D(e) { if ((e) & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); \
+                  else asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); }
+#define CG_LP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp[q]) : "v"(tt[2 * (q)]), "v"(tt[2 * (q) + 1]));
+// in scope at the point of use: Z (the block's accumulator), C_ (its four cell states), eg ei ef eo tt ng hh hp lp; STORE = the two LDS stores
+#define CLAIR_GATE_GAP(G, STORE)                                                                                  \
+        switch (G) {                                                                                              \
+            case 1: CG_E(eg, 1, 0) CG_E(eg, 1, 1) CG_E(eg, 1, 2) break;                                           \
+            case 2: CG_E(eg, 1, 3) CG_E(ei, 0, 0) CG_E(ei, 0, 1) break;                                           \
+            case 3: CG_E(ei, 0, 2) CG_E(ei, 0, 3) CG_E(ef, 2, 0) break;                                           \
+            case 4: CG_E(ef, 2, 1) CG_E(ef, 2, 2) CG_E(ef, 2, 3) break;                                           \
+            case 5: CG_E(eo, 3, 0) CG_E(eo, 3, 1) CG_E(eo, 3, 2) break;                                           \
+            case 6: CG_E(eo, 3, 3) CG_MN(0) CG_MN(1) CG_MN(2) CG_MN(3) break;                                     \
+            case 7: CG_A(ei, 0) CG_A(ei, 1) CG_A(ei, 2) CG_A(ei, 3) CG_NG(0) CG_A(eg, 0) break;                   \
+            case 8: CG_NG(1) CG_A(eg, 1) CG_NG(2) CG_A(eg, 2) CG_NG(3) CG_A(eg, 3) break;                         \
+            case 9: CG_P(0) CG_P(1) CG_P(2) CG_P(3) CG_A(ef, 0) CG_A(ef, 1) break;                                \
+            case 10: CG_A(ef, 2) CG_A(ef, 3) CG_R(eg, 0) CG_R(eg, 1) break;                                       \
+            case 11: CG_R(eg, 2) CG_R(eg, 3) CG_R(ef, 0) break;                                                   \
+            case 12: CG_R(ef, 1) CG_R(ef, 2) CG_R(ef, 3) break;                                                   \
+            case 13: CG_T(0) CG_T(1) CG_T(2) CG_T(3) CG_A(eo, 0) CG_A(eo, 1) break;                               \
+            case 14: CG_C(0) CG_C(1) CG_C(2) CG_C(3) CG_A(eo, 2) CG_A(eo, 3) break;                               \
+            case 15: CG_X(0) CG_X(1) CG_X(2) break;                                                               \
+            case 16: CG_X(3) CG_AC(0) CG_AC(1) CG_AC(2) CG_NC(0) break;                                           \
+            case 17: CG_AC(3) CG_Q(0) CG_Q(1) CG_Q(2) CG_NC(1) CG_NC(2) break;                                    \
+            case 18: CG_Q(3) CG_NC(3) CG_R(eg, 0) CG_R(eg, 1) break;                                              \
+            case 19: CG_R(eg, 2) CG_R(eg, 3) CG_H(0) CG_H(1) break;                                               \
+            case 20: CG_H(2) CG_H(3) CG_HP(0) break;                                                              \
+            case 21: CG_HP(1) CG_D(0) CG_D(1) break;                                                              \
+            case 22: CG_D(2) CG_D(3) CG_LP(0) break;                                                              \
+            default: CG_LP(1)   /* gap 23 */                                                                       \
+                     STORE                                                                                        \
+                     break;                                                                                       \
+        }
 
 // Hand-off words of the fused layer-2 kernel (lstm2_fused.hip.h): the projection workgroups publish "this (direction, tile, t)
 // block is written" per producing wave, the recurrent workgroups wait for them a step ahead of their seed loads.
@@ -319,71 +390,13 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
     }
     __syncthreads();   // zeros, Wx1 fragments, bias quads and the first two input tiles visible
 
-    // Gate math of one block (4 elements per lane), as a static schedule of 23 "gaps" of 3-5 instructions: gap G
-    // is issued right after MFMA G of the next block.  Within a gap all instructions are independent, every
-    // operand was produced at least one gap earlier (no dependency stalls for the in-order wave) and at most
-    // three are transcendental.
-    //   acc holds exp2 arguments (pre-scaled rows): 2^-i, 2^(2 g), 2^-f, 2^-o  ->  registers eg/ei/ef/eo are
-    //   reused as 1+e (A), its reciprocal (R) and k = K2 - 2 K2 rg (K); cell state c' = rf c' + ri k (T, C);
-    //   h = ro (1 - 2 rc) (X, A, R, M, H), then its fp16 split (HP, D, LP).  The last gap packs the lane's four h
-    //   values into one 8-byte LDS store per plane.
-    //   Not two elements per instruction: v_pk_add/mul/fma_f32 wait for the matrix pipe -- after an MFMA one of them costs the wave 53 cycles
-    //   where four v_fma_f32 cost 33 (tools/ubench/mfma_gap_mix.hip, profiles/r04_mfma_gap_mix.txt); tried here, a block went 940 -> 1200 cycles.
-    //   The wave is issue-bound: 12.9 cycles per MFMA + 8 per transcendental + 4 per other op, floor 32.8 per gap (same table).
-    // Placement control.  A sched_barrier on both sides of every MFMA keeps an op from rising above the MFMA that
-    // opens its gap; pinning its OUTPUT (an empty asm volatile, ordered with the asm MFMAs) keeps it from sinking
-    // below the MFMA that closes it.  (Pinning inputs as well costs an s_nop per op: hipcc pads every asm output
-    // that the next VALU touches.)
-#define L32_PIN(x) asm volatile("" : "+v"(x));
-#define L32_EXP2(x) __builtin_amdgcn_exp2f(x)
-#define L32_RCP(x) fast_rcp(x)
-#define L32_OP_E(R, C, e) { R[e] = L32_EXP2(Z[4 * (e) + (C)]); L32_PIN(R[e]) }
-#define L32_OP_A(R, e) { R[e] += 1.0f; L32_PIN(R[e]) }
-#define L32_OP_R(R, e) { R[e] = L32_RCP(R[e]); L32_PIN(R[e]) }
-#define L32_OP_K(e) { eg[e] = fmaf(eg[e], -2.0f * GATE_K2, GATE_K2); L32_PIN(eg[e]) }
-#define L32_OP_T(e) { tt[e] = ei[e] * eg[e]; L32_PIN(tt[e]) }
-#define L32_OP_C(e) { C_[e] = fmaf(ef[e], C_[e], tt[e]); L32_PIN(C_[e]) }
-#define L32_OP_M(e) { m2[e] = -2.0f * eo[e]; L32_PIN(m2[e]) }
-#define L32_OP_X(e) { ei[e] = L32_EXP2(C_[e]); L32_PIN(ei[e]) }
-#define L32_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); L32_PIN(hh[e]) }
-    // fp16 split of h, two elements per instruction: v_cvt_pk_f16_f32 yields the packed pair the LDS store wants, the residual
-    // h - float(hi) is one v_fma_mix_f32 that converts the selected half on the fly
-#define L32_OP_HP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[q]) : "v"(hh[2 * (q)]), "v"(hh[2 * (q) + 1]));
-#define L32_OP_D(e) { if ((e) & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); \
-                      else asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); }
-#define L32_OP_LP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp[q]) : "v"(tt[2 * (q)]), "v"(tt[2 * (q) + 1]));
+    // Gate math of block PB in gap G of the block that follows it: the shared schedule above (CLAIR_GATE_GAP)
 #define L32_GAP(G, PB)                                                                                            \
     {                                                                                                             \
         const f32x16 &Z = L32_ACC(PB);                                                                            \
         float (&C_)[4] = cst[PB];                                                                                 \
-        switch (G) {                                                                                              \
-            case 1: L32_OP_E(eg, 1, 0) L32_OP_E(eg, 1, 1) L32_OP_E(eg, 1, 2) break;                               \
-            case 2: L32_OP_E(eg, 1, 3) L32_OP_E(ei, 0, 0) L32_OP_E(ei, 0, 1) L32_OP_A(eg, 0) break;               \
-            case 3: L32_OP_E(ei, 0, 2) L32_OP_E(ei, 0, 3) L32_OP_A(eg, 1) L32_OP_A(eg, 2) break;                  \
-            case 4: L32_OP_E(ef, 2, 0) L32_OP_E(ef, 2, 1) L32_OP_A(eg, 3) L32_OP_A(ei, 0) break;                  \
-            case 5: L32_OP_E(ef, 2, 2) L32_OP_E(ef, 2, 3) L32_OP_A(ei, 1) L32_OP_A(ei, 2) break;                  \
-            case 6: L32_OP_E(eo, 3, 0) L32_OP_E(eo, 3, 1) L32_OP_R(eg, 0) L32_OP_A(ei, 3) break;                  \
-            case 7: L32_OP_E(eo, 3, 2) L32_OP_E(eo, 3, 3) L32_OP_R(eg, 1) L32_OP_A(ef, 0) break;                  \
-            case 8: L32_OP_R(eg, 2) L32_OP_R(eg, 3) L32_OP_A(ef, 1) L32_OP_A(ef, 2) break;                        \
-            case 9: L32_OP_R(ei, 0) L32_OP_R(ei, 1) L32_OP_A(ef, 3) L32_OP_A(eo, 0) break;                        \
-            case 10: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_A(eo, 1) L32_OP_A(eo, 2) break;                       \
-            case 11: L32_OP_R(ef, 0) L32_OP_R(ef, 1) L32_OP_A(eo, 3) L32_OP_K(0) break;                           \
-            case 12: L32_OP_R(ef, 2) L32_OP_R(ef, 3) L32_OP_K(1) L32_OP_K(2) break;                               \
-            case 13: L32_OP_R(eo, 0) L32_OP_R(eo, 1) L32_OP_K(3) L32_OP_T(0) break;                               \
-            case 14: L32_OP_R(eo, 2) L32_OP_R(eo, 3) L32_OP_T(1) L32_OP_T(2) break;                               \
-            case 15: L32_OP_T(3) L32_OP_C(0) L32_OP_C(1) L32_OP_M(0) L32_OP_M(1) break;                           \
-            case 16: L32_OP_C(2) L32_OP_C(3) L32_OP_X(0) L32_OP_X(1) L32_OP_M(2) break;                           \
-            case 17: L32_OP_X(2) L32_OP_X(3) L32_OP_A(ei, 0) L32_OP_A(ei, 1) L32_OP_M(3) break;                   \
-            case 18: L32_OP_A(ei, 2) L32_OP_A(ei, 3) L32_OP_R(ei, 0) L32_OP_R(ei, 1) break;                       \
-            case 19: L32_OP_R(ei, 2) L32_OP_R(ei, 3) L32_OP_H(0) L32_OP_H(1) break;                               \
-            case 20: L32_OP_H(2) L32_OP_H(3) L32_OP_HP(0) break;                                                  \
-            case 21: L32_OP_HP(1) L32_OP_D(0) L32_OP_D(1) break;                                                  \
-            case 22: L32_OP_D(2) L32_OP_D(3) L32_OP_LP(0) break;                                                  \
-            default: L32_OP_LP(1)   /* gap 23 */                                                                   \
-                     *(uint2 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(hp[0], hp[1]);      \
-                     *(uint2 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(lp[0], lp[1]);      \
-                     break;                                                                                       \
-        }                                                                                                         \
+        CLAIR_GATE_GAP(G, *(uint2 *)&hbuf[s & 1][0][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(hp[0], hp[1]);  \
+                          *(uint2 *)&hbuf[s & 1][1][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(lp[0], lp[1]);) \
     }
     // What goes into the gap after MFMA number M (0-based, NM per block) of block B: the previous block's gate
     // schedule from gap 1 on (the previous block's last MFMA needs 12 wait states before its result is read), and in block 0 the copy-out of h_{s-1}.
@@ -398,7 +411,7 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
     if (!FIRST && (M) == 3) load_seed(zq[B], s + 1, B);   /* after the keep-alive below: the refill can land in the very registers it replaces */ \
     if ((B) > 0 && (M) >= 1 && (M) <= 23) L32_GAP(M, ((B) > 0 ? (B) - 1 : 0))                                                     \
     if (!FIRST && (M) == 2) asm volatile("" :: "v"(zold));   /* the first MFMA's C registers stay untouched until here */ \
-    if (FIRST && (B) > 0 && (M) == 8) load_seed(xacc[(B) - 1], 0, (B) - 1);   /* the gates above read their accumulators in gaps 1-7: block B-1's restarts from its bias */ \
+    if (FIRST && (B) > 0 && (M) == 8) load_seed(xacc[(B) - 1], 0, (B) - 1);   /* the gates above read their accumulators in gaps 1-6: block B-1's restarts from its bias */ \
     if ((B) == 0) {   /* at s = 0 this copies the (uninitialised) other h buffer to row t(0); step 1 overwrites it */ \
         if ((M) == 1) copy_read(s_prev);                                                                          \
         if ((M) >= 4 && (M) < 12) copy_cvt((M) - 4);   /* two units per MFMA shadow */                            \
@@ -431,7 +444,7 @@ _Pragma("unroll")                                                               
 
     // Layer 1: the x-part of the NEXT step (K = 32 = two k-steps per block, 24 MFMAs; Wx1 fragments from LDS) does not depend on
     // h, so it runs after block 3 and the last block's gate math hides behind it exactly as the other blocks' gates hide behind
-    // the following block.  Block 3's accumulator is read by gaps 1-7 and restarts from its bias in gap 8; its own x-part is the
+    // the following block.  Block 3's accumulator is read by gaps 1-6 and restarts from its bias in gap 8; its own x-part is the
     // last six MFMAs.
 #define L32_XTAIL(GATES)                                                                                          \
     _Pragma("unroll") for (int q = 0; q < 24; ++q) {                                                              \
@@ -454,7 +467,7 @@ _Pragma("unroll")                                                               
         }
     };
     unsigned hp[2], lp[2];   // packed fp16 pairs of h: hi plane, lo plane
-    float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
+    float eg[4], ei[4], ef[4], eo[4], tt[4], ng[4], hh[4];
     if (FIRST) {   // bias + x-part of step 0
 #pragma unroll
         for (int b = 0; b < 4; ++b) load_seed(xacc[b], 0, b);
@@ -502,19 +515,6 @@ _Pragma("unroll")                                                               
 #undef L32_ACC
 #undef L32_AFTER_MFMA
 #undef L32_GAP
-#undef L32_OP_E
-#undef L32_OP_A
-#undef L32_OP_R
-#undef L32_OP_K
-#undef L32_OP_T
-#undef L32_OP_C
-#undef L32_OP_M
-#undef L32_OP_X
-#undef L32_OP_H
-#undef L32_OP_HP
-#undef L32_OP_LP
-#undef L32_OP_D
-#undef L32_PIN
     copy_read(T_POS - 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) copy_cvt(i);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x16 zq[4];         // seeds: [b] = block b of the next step (of whichever tile comes next) it is needed in
     f16x8 hf[8][2];       // B fragments of the current tile's h_{s-1}: [kk][plane]
     unsigned hp[2], lp[2];
-    float eg[4], ei[4], ef[4], eo[4], tt[4], m2[4], hh[4];
+    float eg[4], ei[4], ef[4], eo[4], tt[4], ng[4], hh[4];
 
     // h_{-1} = 0 for both tiles
     for (int i = tid; i < 2 * L32_TILE * HP_ROW / 8; i += 256) {
@@ -119,53 +119,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 16; ++i) acc[1][i] = 0.0f;
     asm volatile("" : "+v"(acc[1]));
 
-#define P2_PIN(x) asm volatile("" : "+v"(x));
-#define P2_OP_E(R, C, e) { R[e] = __builtin_amdgcn_exp2f(Z[4 * (e) + (C)]); P2_PIN(R[e]) }
-#define P2_OP_A(R, e) { R[e] += 1.0f; P2_PIN(R[e]) }
-#define P2_OP_R(R, e) { R[e] = fast_rcp(R[e]); P2_PIN(R[e]) }
-#define P2_OP_K(e) { eg[e] = fmaf(eg[e], -2.0f * GATE_K2, GATE_K2); P2_PIN(eg[e]) }
-#define P2_OP_T(e) { tt[e] = ei[e] * eg[e]; P2_PIN(tt[e]) }
-#define P2_OP_C(e) { C_[e] = fmaf(ef[e], C_[e], tt[e]); P2_PIN(C_[e]) }
-#define P2_OP_M(e) { m2[e] = -2.0f * eo[e]; P2_PIN(m2[e]) }
-#define P2_OP_X(e) { ei[e] = __builtin_amdgcn_exp2f(C_[e]); P2_PIN(ei[e]) }
-#define P2_OP_H(e) { hh[e] = fmaf(ei[e], m2[e], eo[e]); P2_PIN(hh[e]) }
-#define P2_OP_HP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp[q]) : "v"(hh[2 * (q)]), "v"(hh[2 * (q) + 1]));
-#define P2_OP_D(e) { if ((e) & 1) asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); \
-                     else asm volatile("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(tt[e]) : "v"(hh[e]), "v"(hp[(e) >> 1])); }
-#define P2_OP_LP(q) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp[q]) : "v"(tt[2 * (q)]), "v"(tt[2 * (q) + 1]));
-    // gap G of the gate schedule (lstm32.hip.h: L32_GAP) for block PB of tile TL, whose h goes to step parity PAR of that tile
+    // gap G of the shared gate schedule (lstm32.hip.h: CLAIR_GATE_GAP) for block PB of tile TL, whose h goes to step parity PAR of that tile
 #define P2_GAP(G, TL, PB, PAR)                                                                                    \
     {                                                                                                             \
         const f32x16 &Z = acc[(PB) & 1];                                                                          \
         float (&C_)[4] = cst[TL][PB];                                                                             \
-        switch (G) {                                                                                              \
-            case 1: P2_OP_E(eg, 1, 0) P2_OP_E(eg, 1, 1) P2_OP_E(eg, 1, 2) break;                                  \
-            case 2: P2_OP_E(eg, 1, 3) P2_OP_E(ei, 0, 0) P2_OP_E(ei, 0, 1) P2_OP_A(eg, 0) break;                   \
-            case 3: P2_OP_E(ei, 0, 2) P2_OP_E(ei, 0, 3) P2_OP_A(eg, 1) P2_OP_A(eg, 2) break;                      \
-            case 4: P2_OP_E(ef, 2, 0) P2_OP_E(ef, 2, 1) P2_OP_A(eg, 3) P2_OP_A(ei, 0) break;                      \
-            case 5: P2_OP_E(ef, 2, 2) P2_OP_E(ef, 2, 3) P2_OP_A(ei, 1) P2_OP_A(ei, 2) break;                      \
-            case 6: P2_OP_E(eo, 3, 0) P2_OP_E(eo, 3, 1) P2_OP_R(eg, 0) P2_OP_A(ei, 3) break;                      \
-            case 7: P2_OP_E(eo, 3, 2) P2_OP_E(eo, 3, 3) P2_OP_R(eg, 1) P2_OP_A(ef, 0) break;                      \
-            case 8: P2_OP_R(eg, 2) P2_OP_R(eg, 3) P2_OP_A(ef, 1) P2_OP_A(ef, 2) break;                            \
-            case 9: P2_OP_R(ei, 0) P2_OP_R(ei, 1) P2_OP_A(ef, 3) P2_OP_A(eo, 0) break;                            \
-            case 10: P2_OP_R(ei, 2) P2_OP_R(ei, 3) P2_OP_A(eo, 1) P2_OP_A(eo, 2) break;                           \
-            case 11: P2_OP_R(ef, 0) P2_OP_R(ef, 1) P2_OP_A(eo, 3) P2_OP_K(0) break;                               \
-            case 12: P2_OP_R(ef, 2) P2_OP_R(ef, 3) P2_OP_K(1) P2_OP_K(2) break;                                   \
-            case 13: P2_OP_R(eo, 0) P2_OP_R(eo, 1) P2_OP_K(3) P2_OP_T(0) break;                                   \
-            case 14: P2_OP_R(eo, 2) P2_OP_R(eo, 3) P2_OP_T(1) P2_OP_T(2) break;                                   \
-            case 15: P2_OP_T(3) P2_OP_C(0) P2_OP_C(1) P2_OP_M(0) P2_OP_M(1) break;                                \
-            case 16: P2_OP_C(2) P2_OP_C(3) P2_OP_X(0) P2_OP_X(1) P2_OP_M(2) break;                                \
-            case 17: P2_OP_X(2) P2_OP_X(3) P2_OP_A(ei, 0) P2_OP_A(ei, 1) P2_OP_M(3) break;                        \
-            case 18: P2_OP_A(ei, 2) P2_OP_A(ei, 3) P2_OP_R(ei, 0) P2_OP_R(ei, 1) break;                           \
-            case 19: P2_OP_R(ei, 2) P2_OP_R(ei, 3) P2_OP_H(0) P2_OP_H(1) break;                                   \
-            case 20: P2_OP_H(2) P2_OP_H(3) P2_OP_HP(0) break;                                                     \
-            case 21: P2_OP_HP(1) P2_OP_D(0) P2_OP_D(1) break;                                                     \
-            case 22: P2_OP_D(2) P2_OP_D(3) P2_OP_LP(0) break;                                                     \
-            default: P2_OP_LP(1)   /* gap 23 */                                                                    \
-                     *(uint2 *)&hbuf[TL][PAR][0][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(hp[0], hp[1]);    \
-                     *(uint2 *)&hbuf[TL][PAR][1][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(lp[0], lp[1]);    \
-                     break;                                                                                       \
-        }                                                                                                         \
+        CLAIR_GATE_GAP(G, *(uint2 *)&hbuf[TL][PAR][0][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(hp[0], hp[1]);  \
+                          *(uint2 *)&hbuf[TL][PAR][1][cand][w * 32 + (PB) * 8 + hq * 4] = make_uint2(lp[0], lp[1]);) \
     }
     // One block of tile X's step s (X, Y = 1 - X compile-time): 24 MFMAs (k-step kk: w_lo.h_hi, w_hi.h_lo, w_hi.h_hi) and what rides in
     // their shadows.  sy = the step the other tile runs next (its seeds are fetched here, its fragments read in block 3);
@@ -242,19 +202,6 @@ _Pragma("unroll")                                                               
 #undef P2_HALF
 #undef P2_BLOCK
 #undef P2_GAP
-#undef P2_OP_E
-#undef P2_OP_A
-#undef P2_OP_R
-#undef P2_OP_K
-#undef P2_OP_T
-#undef P2_OP_C
-#undef P2_OP_M
-#undef P2_OP_X
-#undef P2_OP_H
-#undef P2_OP_HP
-#undef P2_OP_LP
-#undef P2_OP_D
-#undef P2_PIN
 }
 
 }  // namespace clair

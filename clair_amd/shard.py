@@ -505,8 +505,8 @@ class NodeGroup(object):
             status = self._star.allgather(mine)
             bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
             if bad:
-                if not mine:
-                    lib.clair_comm_destroy(h)
+                if not mine:          # a peer never came up: abort, do not destroy (ncclCommDestroy may wait for it)
+                    getattr(lib, "clair_comm_abort", lib.clair_comm_destroy)(h)
                 self._fall_back("clair_comm_create failed on %d of %d ranks -- %s" % (len(bad), self.world, "; ".join(bad)))
                 return
             self._lib, self._comm = lib, h

@@ -27,7 +27,7 @@ extern "C" {
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
  * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3).
  * 4: + the clair_frontend_* device front end; clair_submit_ex takes device pointers (round 3).
- * 5: + clair_device_pci_bus_id (round 5: a rank finds the NUMA node of ITS GPU, clair_amd/shard.py). */
+ * 5: + clair_device_pci_bus_id (round 5: a rank finds the NUMA node of ITS GPU, clair_amd/shard.py), clair_comm_abort. */
 #define CLAIR_ABI_VERSION 5
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
@@ -231,6 +231,10 @@ int clair_comm_preflight(int device);
 int clair_comm_unique_id(uint8_t *id /*[CLAIR_COMM_ID_BYTES]*/);                 /* ncclGetUniqueId */
 int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_comm_t **out);   /* ncclCommInitRank */
 void clair_comm_destroy(clair_comm_t *c);
+/* Tear-down that does not wait for the peers (ncclCommAbort): for a communicator that came up on this rank while a peer's
+ * clair_comm_create failed.  Only fast, symmetric start-up failures fall back to the socket transport (clair_amd/shard.py);
+ * a rank that hangs inside ncclCommInitRank still ends the job at the bootstrap's timeout. */
+void clair_comm_abort(clair_comm_t *c);
 const char *clair_comm_last_error(const clair_comm_t *c);                         /* c may be NULL: failure of create / unique_id */
 int clair_comm_barrier(clair_comm_t *c);
 int clair_comm_allreduce_f64(clair_comm_t *c, double *values /*in place*/, int count, int op /*enum clair_comm_op*/);

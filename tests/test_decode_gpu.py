@@ -100,6 +100,7 @@ def test_call_records_survive_a_fused_launch_failure(synth_weights, monkeypatch)
     raw, infos = synth.synthetic_candidates(1024, "ont", seed=41)
     counts, centre = raw.astype(np.int16), _hostapi.centre_bytes(infos)
     want = None
+    monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", "1")        # the fused launch is opt-in since round 5
     for fault in (None, "2"):
         if fault is None:
             monkeypatch.delenv("CLAIR_AMD_FUSED_FAULT", raising=False)

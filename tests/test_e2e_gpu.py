@@ -136,9 +136,8 @@ def test_call_var_with_bam_lookups_through_fake_pysam(tmp_path):
 
 
 def test_call_var_vcf_does_not_depend_on_the_kernel_selection(tmp_path):
-    """call_var over 5 000 candidates at batch 1024 -- the size at which its two-slot handle runs layer 2 as one fused launch --
-    writes the same VCF bytes with the fused launch forced off, with the two-tile LSTM2 forced on, and from text, plain text and
-    binary records of the same candidates."""
+    """call_var over 5 000 candidates at batch 1024 writes the same VCF bytes with layer 2 as one fused launch (opt-in since round 5),
+    with the two-tile LSTM2 forced on, and from text, plain text and binary records of the same candidates."""
     import gzip
     from clair_amd import synth, tensor_binary
     tmp = str(tmp_path)
@@ -155,14 +154,14 @@ def test_call_var_vcf_does_not_depend_on_the_kernel_selection(tmp_path):
         f.write(tensor_binary.MAGIC)
         f.write(tensor_binary.pack_records(infos[0][0], [int(i[1]) for i in infos], [i[2] for i in infos], raw))
     outs = {}
-    for name, source, env in (("default", text_gz, {}), ("unfused", text_gz, {"CLAIR_AMD_LSTM2_FUSED": "0"}),
+    for name, source, env in (("default", text_gz, {}), ("unfused", text_gz, {"CLAIR_AMD_LSTM2_FUSED": "0"}), ("fused", text_gz, {"CLAIR_AMD_LSTM2_FUSED": "1", "CLAIR_AMD_SLOTS": "2"}),
                               ("pair", text_gz, {"CLAIR_AMD_LSTM2_FUSED": "0", "CLAIR_AMD_LSTM2_PAIR": "1"}), ("plain", plain, {}), ("binary", binary, {})):
         out = os.path.join(tmp, name + ".vcf")
         _run(["clair_amd.call_var", "--chkpnt_fn", ck, "--tensor_fn", source, "--call_fn", out, "--batch_size", "1024", "--sampleName", "S", "--showRef"],
              env=dict(os.environ, **env))
         outs[name] = open(out).read()
     assert len(outs["default"].splitlines()) > 4000
-    for name in ("unfused", "pair", "plain", "binary"):
+    for name in ("unfused", "fused", "pair", "plain", "binary"):
         assert outs[name] == outs["default"], name
 
 

@@ -174,12 +174,23 @@ def test_fused_launch_failure_degrades_to_the_two_launch_path(synth_weights, mon
         want = [np.concatenate(eng.predict(x), axis=1) for x in xs]
     finally:
         eng.close()
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
+    try:
+        assert eng.kernel_workgroups(n)["proj2"] > 0            # (forced off above; without the variable it is off as well: opt-in since round 5)
+    finally:
+        eng.close()
     monkeypatch.delenv("CLAIR_AMD_LSTM2_FUSED")
+    eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
+    try:
+        assert eng.kernel_workgroups(n)["proj2"] > 0            # the default path of every handle is the two launches
+    finally:
+        eng.close()
+    monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", "1")
     monkeypatch.setenv("CLAIR_AMD_FUSED_FAULT", "2")
     eng = _capi.Engine(device=0, max_batch=n, n_slots=1)
     try:
         eng.load_weights(synth_weights)
-        assert eng.kernel_workgroups(n)["proj2"] == 0           # the fused launch is this handle's default
+        assert eng.kernel_workgroups(n)["proj2"] == 0           # asked for: the fused launch
         got = [np.concatenate(eng.predict(x), axis=1) for x in xs]
         assert eng.counter("fused_launches") == 2 and eng.counter("fused_recoveries") == 1
         assert eng.kernel_workgroups(n)["proj2"] > 0            # latched: two launches from now on
@@ -211,7 +222,7 @@ def test_fused_launch_failure_degrades_to_the_two_launch_path(synth_weights, mon
 
 
 @pytest.mark.parametrize("n_slots", [1, 2])
-def test_an_odd_full_batch_does_not_touch_the_fused_error_word(synth_weights, n_slots):
+def test_an_odd_full_batch_does_not_touch_the_fused_error_word(synth_weights, monkeypatch, n_slots):
     """the kernel that writes a batch's results into page-locked host memory copies whole 16-byte vectors, so for an odd n
     the last one reaches 8 bytes past n * 360 -- onto the fused launch's error word when n == max_batch and the word sat right behind
     the rows.  The word now lives past the last vector a full batch can write (engine.hip: h_word_offset): a full odd batch on a handle
@@ -225,6 +236,7 @@ def test_an_odd_full_batch_does_not_touch_the_fused_error_word(synth_weights, n_
         want = ref.predict(x)
     finally:
         ref.close()
+    monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", "1")        # keeps the ticket / error words (and, for even batches, the fused launch itself)
     eng = _capi.Engine(device=0, max_batch=n, n_slots=n_slots)
     try:
         eng.load_weights(synth_weights)
@@ -239,7 +251,7 @@ def test_an_odd_full_batch_does_not_touch_the_fused_error_word(synth_weights, n_
         eng.close()
 
 
-def test_outputs_do_not_depend_on_the_execution_mode(synth_weights):
+def test_outputs_do_not_depend_on_the_execution_mode(synth_weights, monkeypatch):
     """The same 16 384 candidates through every slots x batch-size combination (which selects the kernels: two launches or the fused
     one, one- or two-tile LSTM2, 128 or 256 projection workgroups), three passes each: every output must equal the first pass of
     the first mode BIT for bit -- a candidate's arithmetic does not depend on the batch it sits in (tools/gpu/cross_mode_stress.py
@@ -248,7 +260,8 @@ def test_outputs_do_not_depend_on_the_execution_mode(synth_weights):
     n = 16384
     x, _ = synth.synthetic_input(n, "ont", seed=4242)
     ref = None
-    for slots, batch in ((3, 1024), (3, 4096), (1, 1024), (2, 2048), (1, 4096), (3, 8192), (2, 1024), (3, 512)):
+    for slots, batch, fused in ((3, 1024, 0), (3, 4096, 0), (1, 1024, 1), (2, 2048, 1), (1, 4096, 0), (3, 8192, 0), (2, 1024, 1), (3, 512, 0), (1, 1024, 0), (4, 1024, 0)):
+        monkeypatch.setenv("CLAIR_AMD_LSTM2_FUSED", str(fused))       # the fused launch is opt-in (round 5): asked for where it used to be the default
         eng = _capi.Engine(device=0, max_batch=batch, n_slots=slots)
         try:
             eng.load_weights(synth_weights)
