@@ -95,6 +95,30 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
     const int n0 = blk * L34_CAND;
     const int cg0 = split * L34_WALK;
     if (tid == 0) psync = 0u;
+    // a2 tile -> LDS.  Row q = t*64 + cand is the 32 bytes a2[cg][t][n0 + cand][0 .. 7]; one DMA piece moves 32 rows = one contiguous KiB of
+    // the group-major tensor (lane l: row 32*piece + l/2, 16-byte slot l%2).  Slot s of a row holds channel half s ^ ((cand >> 3) & 1): the
+    // fragment gather reads 16 bytes of every 32-byte row, and the swizzle puts candidates c and c + 8 on different banks.
+    // Candidates beyond n_pad (the ragged half of the last block) re-read the last row; their partials are never used.
+    // Four waves share a tile; wave q's pieces are q, q + 4, ...: always the same half of the 64 candidates (piece parity = q & 1), so the
+    // per-lane part of the source address is one 32-bit offset for the kernel's life and a piece costs scalar arithmetic only (glds16_s:
+    // wave-uniform base in SGPRs).  Round 5: the FIRST tile is issued by the producers (q = w), every later one by the CONSUMERS
+    // (q = w - 4) from inside their MFMA stream -- 17 pieces were 1.7 k ticks of the producers' 13.8 k per unit, the critical path of the
+    // kernel (tools/gpu/l34_stamps.py), and the consumers wait a third of every unit anyway.
+    constexpr int L34_NPIECE = T_POS * L34_CAND / 32;   // 66: piece = 2 t + (candidate half)
+    const int q4 = w & 3;
+    const unsigned lds_a2 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)a2buf);
+    const int dcand = (q4 & 1) * 32 + (lane >> 1);
+    const unsigned dma_lane_off = (unsigned)((min(n0 + dcand, p.n_pad - 1) * L34_CH + (((lane & 1) ^ ((dcand >> 3) & 1)) * 4)) * (int)sizeof(float));
+    auto issue_pieces = [&](int cg, int first, int count) {      // pieces q4 + 4 * i, i in [first, first + count), of channel group cg's tile
+        const char *base = (const char *)(p.a2 + ((size_t)cg * T_POS + (q4 >> 1)) * p.n_pad * L34_CH);
+        const size_t step = (size_t)2 * p.n_pad * L34_CH * sizeof(float);          // two positions on
+        for (int i = first; i < first + count && q4 + 4 * i < L34_NPIECE; ++i) {
+            const size_t at = (size_t)(base + (size_t)i * step);        // wave-uniform by construction; said so to the register allocator
+            const void *sbase = (const void *)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)at));
+            glds16_s(dma_lane_off, sbase, lds_a2 + (q4 + 4 * i) * 1024);
+        }
+    };
+    constexpr int L34_MY_PIECES = (L34_NPIECE + 3) / 4;   // 17 (waves 0, 1) or 16 (waves 2, 3): issue_pieces stops at the tile's end
 
     if (w < 4) {
         // =================================== producers: a2 tile -> L3 -> selu + split -> l3 tile ===================================
@@ -103,28 +127,9 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
         // they win the issue arbitration of their SIMD, the consumers' MFMAs fill the gaps.
         __builtin_amdgcn_s_setprio(3);
         const int cq = w >> 1, mb3 = w & 1;
-        const unsigned lds_a2 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)a2buf);
-        // a2 tile -> LDS.  Row q = t*64 + cand is the 32 bytes a2[cg][t][n0 + cand][0 .. 7]; one DMA piece moves 32 rows = one contiguous KiB of
-        // the group-major tensor (lane l: row 32*piece + l/2, 16-byte slot l%2).  Slot s of a row holds channel half s ^ ((cand >> 3) & 1): the
-        // fragment gather reads 16 bytes of every 32-byte row, and the swizzle puts candidates c and c + 8 on different banks.
-        // Candidates beyond n_pad (the ragged half of the last block) re-read the last row; their partials are never used.
-        // A wave's pieces are w, w + 4, ...: always the same half of the 64 candidates (piece parity = w & 1), so the per-lane part of the source
-        // address is one 32-bit offset for the kernel's life and a piece costs scalar arithmetic only (glds16_s: wave-uniform base in SGPRs).
-        const int dcand = (w & 1) * 32 + (lane >> 1);
-        const unsigned lane_off = (unsigned)((min(n0 + dcand, p.n_pad - 1) * L34_CH + (((lane & 1) ^ ((dcand >> 3) & 1)) * 4)) * (int)sizeof(float));
-        auto issue_tile = [&](int cg) {
-            constexpr int NPIECE = T_POS * L34_CAND / 32;   // 66: piece = 2 t + (candidate half)
-            const char *base = (const char *)(p.a2 + ((size_t)cg * T_POS + (w >> 1)) * p.n_pad * L34_CH);
-            const size_t step = (size_t)2 * p.n_pad * L34_CH * sizeof(float);          // two positions on
-            for (int piece = w, i = 0; piece < NPIECE; piece += 4, ++i) {
-                const size_t at = (size_t)(base + (size_t)i * step);        // wave-uniform by construction; said so to the register allocator
-                const void *sbase = (const void *)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)at));
-                glds16_s(lane_off, sbase, lds_a2 + piece * 1024);
-            }
-        };
         const int cand = mb3 * 32 + l32;
         const float *arow = a2buf + (size_t)cand * 8 + ((cq ^ ((cand >> 3) & 1)) * 4);     // + t * 512 floats
-        issue_tile(cg0);
+        issue_pieces(cg0, 0, L34_MY_PIECES);
         f16x8 wf0[4][2], wf1[4][2], wf2[4][2];   // W3 fragments of k-step 0 / 1 / 2: [channel][plane]; k-step 0 of the NEXT unit is fetched a phase ahead
         {
             const f16x8 *wp = (const f16x8 *)p.w3s + (size_t)(cg0 * L34_CH + cq * 4) * (3 * 2 * 64) + lane;   // + ((cc*3 + kk)*2 + plane)*64
@@ -199,13 +204,12 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
             }
             asm volatile("" : "+v"(acc3[3]));
             L34_STAMP(2 + 3 * g)
-            // the four producers are done reading the a2 buffer (their ds_reads have returned) before any of them lets the next tile in
+            // this producer is done reading the a2 buffer (its ds_reads have returned): once all four have said so the consumers let the next
+            // tile in (the count is only ever read by them: no rendezvous among the producers any more)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&psync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(&psync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(g + 1)) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             if (g + 1 < L34_WALK) {
-                issue_tile(cg + 1);
                 const f16x8 *wn = (const f16x8 *)p.w3s + (size_t)((cg + 1) * L34_CH + cq * 4) * (3 * 2 * 64) + lane;
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
@@ -236,8 +240,8 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
                         *(uint2 *)&l3h[1][cand][u * L34_CH + cq * 4] = lo[a][r];
                     }
                 }
-            CLAIR_VMWAIT(0);                        // this wave's pieces of the next a2 tile (and its W3 fragments) have landed
-            l34_barrier();                          // B2: the l3 tile is complete, the next a2 tile is in LDS
+            CLAIR_VMWAIT(0);                        // this wave's W3 fragments of the next unit have landed
+            l34_barrier();                          // B2: the l3 tile is complete, the next a2 tile is in LDS (the consumers waited for their pieces)
             L34_STAMP(4 + 3 * g)
         }
         l34_barrier();                              // E1, E2: the consumers' K-half exchange
@@ -258,6 +262,19 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
                 for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.0f;
         L34_STAMP(1)
         l34_barrier();                              // Bp
+        // The a2 tile of unit t (t >= 1) may enter the buffer once the four producers have finished the L3 product of unit t - 1
+        // (psync >= 4 t); it has to be there when they start unit t, right after barrier B2 of unit t - 1.  Tile 1: issued in front of
+        // unit 0's barriers (the consumers have nothing else to do yet); tile g + 2: in the shadows of unit g's MFMAs, four pieces per
+        // k-step from the moment the count allows it, the rest (a producer that was late) right behind the loop.
+        int dma_done = L34_MY_PIECES;               // pieces of the tile in flight / being issued that this wave has issued
+        auto dma_ready = [&](int t) -> bool {       // one LDS word: the same answer in every lane, said so to the compiler (a scalar branch)
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&psync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 4u * (unsigned)t;
+        };
+        if (L34_WALK > 1) {
+            while (!dma_ready(1)) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            issue_pieces(cg0 + 1, 0, L34_MY_PIECES);
+        }
 #pragma unroll 1
         for (int g = 0; g < L34_WALK; ++g) {
             const int cg = cg0 + g;
@@ -273,7 +290,10 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
                     for (int pl = 0; pl < 2; ++pl) bq[i][nb][pl] = bsrc[((size_t)(ks0 + i) * 6 + nb) * 128 + pl * 64];
             l34_barrier();                          // B1: this wave is done reading the previous l3 tile
             L34_STAMP(2 + 3 * g)
-            l34_barrier();                          // B2: the l3 tile of unit g is complete
+            CLAIR_VMWAIT(0);                        // this wave's pieces of the a2 tile of unit g + 1 have landed (and the W4 fragments above)
+            l34_barrier();                          // B2: the l3 tile of unit g is complete, the producers may start on the next a2 tile
+            const bool more = g + 2 < L34_WALK;     // unit g + 2's tile goes in during this unit's MFMAs
+            dma_done = more ? 0 : L34_MY_PIECES;
             L34_STAMP(3 + 3 * g)
             if (p.dbg) {   // debug tap: this unit's 64 x (30 u x 8 channels) slice of l3
                 for (int f = tid - 256; f < L34_CAND * L34_K; f += 256) {
@@ -309,9 +329,20 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
                     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                         for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma32h(a[mb][0], bq[i % PF][nb][0], acc[mb][nb]);
+                    if (i >= 2 && dma_done < L34_MY_PIECES && dma_ready(g + 2)) {   // wave-uniform; the producers need ~3 k-steps for their L3 product
+                        asm volatile("" ::: "memory");
+                        issue_pieces(cg + 2, dma_done, 4);
+                        dma_done += 4;
+                    }
                 }
             }
             asm volatile("" : "+v"(acc[1][2]));
+            if (dma_done < L34_MY_PIECES) {          // what the k-steps did not get to
+                while (!dma_ready(g + 2)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                issue_pieces(cg + 2, dma_done, L34_MY_PIECES - dma_done);
+                dma_done = L34_MY_PIECES;
+            }
             L34_STAMP(4 + 3 * g)
         }
         // the two K halves meet in LDS (fixed order: lower + upper), then go out as this split's partial, fragment-major:

@@ -408,9 +408,24 @@ def test_an_unsorted_slab_from_a_direct_caller_is_tallied_right_and_reported():
     f = _capi.Frontend(0, case["ref"], case["ref0"], lo, hi)
     f.add_arrays(r, o, e, q)
     g = _capi.Frontend(0, case["ref"], case["ref0"], lo, hi)
+    # the same alignments in shuffled order, the slab laid out the way a packer would lay it out for THAT order (operations and their element
+    # prefix follow the alignments; the bases stay where they are, every record names its own offset)
     perm = np.random.default_rng(5).permutation(len(r))
     assert (np.diff(r["pos0"][perm].astype(np.int64)) < 0).any()
-    g.add_arrays(r[perm], o, e, q)          # the records keep pointing at their own operations and bases: only the order of starts changes
+    per_op = np.diff(e.astype(np.int64))
+    r2, pieces, counts = r[perm].copy(), [], []
+    at = 0
+    for k, rec in enumerate(r[perm]):
+        a, n = int(rec["op0"]), int(rec["n_ops"])
+        piece = o[a:a + n].copy()
+        piece["read"] = k                      # an operation names its alignment by its index in the slab
+        pieces.append(piece); counts.append(per_op[a:a + n])
+        r2["op0"][k] = at
+        at += n
+    o2 = np.concatenate(pieces)
+    e2 = np.concatenate([[0], np.cumsum(np.concatenate(counts))]).astype(np.uint32)
+    assert len(o2) == len(o) and e2[-1] == e[-1]
+    g.add_arrays(r2, o2, e2, q)
     assert f.stats()["anomalies"] == 0 and g.stats()["anomalies"] == fe.A_UNSORTED
     for x in (f, g):
         x.find_candidates(min_coverage=3, threshold=0.1)

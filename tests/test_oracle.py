@@ -183,9 +183,14 @@ def test_oracle_matches_the_tf113_golden_vectors_when_present():
     summation orders; the oracle's own float32 / float64 twins differ by 4e-6 on this set)."""
     if not os.path.isfile(TF_GOLDEN):
         pytest.skip(TF_GOLDEN_ABSENT)
+    check_oracle_against_minted_file(TF_GOLDEN)
+
+
+def check_oracle_against_minted_file(path):
+    """What the test above does with the committed file; tests/test_mint_tool.py runs it on a file minted under the stand-in TensorFlow."""
     m = _mint()
     w, x = m.recipe_weights(), m.golden_input()
-    with np.load(TF_GOLDEN) as z:
+    with np.load(path) as z:
         assert str(z["recipe"]) == m.RECIPE
         assert abs(float(z["weights_checksum"]) - sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values())) < 1e-6
         outs, inter = c_oracle.forward(w, x, keep_intermediates=True)

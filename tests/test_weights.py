@@ -242,6 +242,14 @@ def test_reader_on_a_checkpoint_written_by_tensorflow_itself_when_present():
     if not os.path.isfile(prefix + ".index"):
         pytest.skip("tests/golden/tf113_mini.* absent: no checkpoint written by TensorFlow itself has been read yet -- "
                     "`python tools/mint_tf_golden.py --mini-checkpoint` under tensorflow==1.13.2 mints it")
+    check_reader_against_minted_checkpoint(prefix)
+
+
+def check_reader_against_minted_checkpoint(prefix):
+    """What the test above does with the committed files; tests/test_mint_tool.py runs it on a checkpoint minted under the stand-in TensorFlow."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = json.load(open(prefix + ".json"))
     got = tf_bundle.read_tensors(prefix)
     floats = {n: v for n, v in doc["variables"].items() if v["dtype"] == "float32"}

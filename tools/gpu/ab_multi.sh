@@ -6,7 +6,8 @@
 cd "$(dirname "$0")/../.."
 ROUNDS=3
 ARGS="--steps 200 --warmup 8 --sustained-seconds 2"
-while getopts r:a: o; do case $o in r) ROUNDS=$OPTARG;; a) ARGS=$OPTARG;; esac; done
+BOUNDARY="--boundary-slots 0"          # -b: keep the host-array boundary legs (value_boundary, value_boundary_int16)
+while getopts r:a:b o; do case $o in r) ROUNDS=$OPTARG;; a) ARGS=$OPTARG;; b) BOUNDARY="";; esac; done
 shift $((OPTIND - 1))
 i=1
 while [ $i -le $ROUNDS ]; do
@@ -15,12 +16,13 @@ while [ $i -le $ROUNDS ]; do
     lib=${rest%%,*}; envs=""
     case $rest in *,*) envs=$(echo "${rest#*,}" | tr ',' ' ');; esac
     [ "$lib" = "-" ] && libenv="" || libenv="CLAIR_AMD_LIB=$PWD/$lib"
-    out=$(env $libenv $envs timeout 300 python bench.py $ARGS --no-cpu-baseline --gt-candidates 0 --boundary-slots 0 --full-candidates 0 2>/dev/null | python -c "
+    out=$(env $libenv $envs timeout 300 python bench.py $ARGS --no-cpu-baseline --gt-candidates 0 --full-candidates 0 $BOUNDARY 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 g=d['gpu_state'].get('value_sustained') or d['gpu_state'].get('value') or {}
-print('value %.0f sustained %s ms/step %s power %s W sclk %s MHz parity %.2e alone %s' % (d['value'], d.get('value_sustained'), (d.get('sustained') or {}).get('ms_per_step'), g.get('power_w'), g.get('sclk_mhz'), d['parity_max_abs_err'],
-      {k: v for k, v in d['kernels_alone_ms'].items() if v}))")
+b=d.get('boundary') or {}
+print('value %.0f sustained %s ms/step %s power %s W sclk %s MHz parity %.2e boundary f32 %s i16 %s alone %s' % (d['value'], d.get('value_sustained'), (d.get('sustained') or {}).get('ms_per_step'), g.get('power_w'), g.get('sclk_mhz'), d['parity_max_abs_err'],
+      (b.get('float32') or {}).get('value'), (b.get('int16') or {}).get('value'), {k: v for k, v in d['kernels_alone_ms'].items() if v}))")
     echo "round $i $name: $out"
   done
   i=$((i + 1))
