@@ -264,7 +264,7 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
         l34_barrier();                              // Bp
         // The a2 tile of unit t (t >= 1) may enter the buffer once the four producers have finished the L3 product of unit t - 1
         // (psync >= 4 t); it has to be there when they start unit t, right after barrier B2 of unit t - 1.  Tile 1: issued in front of
-        // unit 0's barriers (the consumers have nothing else to do yet); tile g + 2: in the shadows of unit g's MFMAs, four pieces per
+        // unit 0's barriers (the consumers have nothing else to do yet); tile g + 2: in the shadows of unit g's MFMAs, nine pieces per
         // k-step from the moment the count allows it, the rest (a producer that was late) right behind the loop.
         int dma_done = L34_MY_PIECES;               // pieces of the tile in flight / being issued that this wave has issued
         auto dma_ready = [&](int t) -> bool {       // one LDS word: the same answer in every lane, said so to the compiler (a scalar branch)
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
                         for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = mfma32h(a[mb][0], bq[i % PF][nb][0], acc[mb][nb]);
                     if (i >= 2 && dma_done < L34_MY_PIECES && dma_ready(g + 2)) {   // wave-uniform; the producers need ~3 k-steps for their L3 product
                         asm volatile("" ::: "memory");
-                        issue_pieces(cg + 2, dma_done, 4);
-                        dma_done += 4;
+                        issue_pieces(cg + 2, dma_done, 9);      // the wave's 16-17 pieces over two k-steps: four per k-step left the tile landing 2 k ticks
+                        dma_done += 9;                           // after the producers wanted it (tools/gpu/l34_stamps.py, profiles/r05_l34_stamps.txt)
                     }
                 }
             }
