@@ -83,7 +83,7 @@ def main():
 def phases_from(per, bench_json):
     import json
     line = [l for l in open(bench_json).read().splitlines() if l.lstrip().startswith("{")][-1]
-    phases = json.loads(line).get("launch_phases") or []
+    phases = [(name, n) for name, n in (json.loads(line).get("launch_phases") or []) if n is not None]      # a leg on a handle of its own (the GT concordance) has no count
     total = sum(n for _, n in phases)
     cols = [(name, [(r[2] - r[1]) / 1e3 for r in rs]) for name, rs in per.items() if len(rs) == total]
     print("#\n# per leg of bench.py, in launch order (mean us per launch; `launch_phases` of %s, %d forward passes)" % (bench_json.split("/")[-1], total))
