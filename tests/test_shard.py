@@ -480,3 +480,27 @@ def test_eight_ranks_bind_themselves_next_to_their_gpus(tmp_path):
     # world size 1 is left alone unless asked (no behavioural change for the single-GPU runs)
     assert shard.want_binding(1) is False and shard.want_binding(8) is True
     assert shard.NodeGroup(transport="tcp", rank=0, world=1, local_rank=0).affinity is None
+
+
+def test_run_workers_arrive_at_the_same_split_without_talking(tmp_path, monkeypatch):
+    """callVarBamParallel --run workers never talk to each other: each looks up every worker's GPU itself (shard.bind_worker) and must
+    arrive at the same partition of the node's cores.  sysfs and the PCI look-up are faked; nothing is applied to this process."""
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 4:
+        pytest.skip("fewer than four cores")
+    half = len(cores) // 2
+    lists = [",".join(map(str, cores[:half])), ",".join(map(str, cores[half:]))]
+    sysfs = tmp_path / "sys"
+    _fake_sysfs(sysfs, {"0000:%02x:00.0" % (0x10 + k): (k // 2, lists[k // 2]) for k in range(4)}, {0: lists[0], 1: lists[1]})
+    monkeypatch.setattr(shard, "local_pci_bus_id", lambda d_: "0000:%02x:00.0" % (0x10 + int(d_)))
+    recs = [shard.bind_worker(d_, [3, 1, 0, 2], sysfs_root=str(sysfs), apply=False) for d_ in range(4)]
+    got = [shard.parse_cpulist(r["cpus_bound"]) for r in recs]
+    assert sorted(got[0] + got[1]) == cores[:half] and sorted(got[2] + got[3]) == cores[half:] and all(got)
+    assert [r["numa_node"] for r in recs] == [0, 0, 1, 1]
+    # one GPU in use: left alone unless asked for; a device that is not among the workers': nothing
+    assert shard.bind_worker(0, [0], sysfs_root=str(sysfs), apply=False) is None
+    assert shard.bind_worker(5, [0, 1], sysfs_root=str(sysfs), apply=False) is None
+    monkeypatch.setenv("CLAIR_AMD_BIND", "1")
+    assert shard.parse_cpulist(shard.bind_worker(0, [0], sysfs_root=str(sysfs), apply=False)["cpus_bound"]) == cores[:half]
+    monkeypatch.setenv("CLAIR_AMD_BIND", "0")
+    assert shard.bind_worker(0, [0, 1, 2, 3], sysfs_root=str(sysfs), apply=False) is None
