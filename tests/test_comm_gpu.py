@@ -51,7 +51,7 @@ def test_bench_under_torch_distributed_run_one_rank_and_own_spawner(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    tail = ["bench.py", "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-cpu-baseline"]
+    tail = ["bench.py", "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--gt-candidates", "0", "--sustained-seconds", "0.2"]
     for cmd in ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                  "--master-port", str(port)] + tail, [sys.executable] + tail):
         r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)

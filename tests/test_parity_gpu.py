@@ -487,7 +487,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_WARM_STEPS="16")
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "24", "--warmup", "4", "--cpu-seconds", "2"], cwd=root, env=env,
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "24", "--warmup", "4", "--cpu-seconds", "2", "--gt-candidates", "6000", "--sustained-seconds", "0.3"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -544,6 +544,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert set(state[leg]) == {"sclk_mhz", "power_w", "samples"}, leg
     assert state["value_full_config"]["sclk_mhz"] is None or 500 < state["value_full_config"]["sclk_mhz"] < 3000
     assert state["value_full_config"]["power_w"] is None or 100 < state["value_full_config"]["power_w"] < 2000
+    # round 5: the sustained leg (here 0.3 s; the default is 2.5 s), timed like `value`, and the GT concordance count of tools/gt_concordance.py
+    # per platform profile (here 6 000 candidates each; the default is 200 000)
+    sus = d["sustained"]
+    assert d["value_sustained"] == sus["value"] and sus["steps"] >= 24 and sus["seconds"] >= 0.25 and 0.8 * d["value"] < d["value_sustained"] < 1.25 * d["value"]
+    assert abs(d["value_sustained"] - sus["steps"] * d["config"]["batch"] / sus["seconds"]) < 0.01 * d["value_sustained"]
+    assert set(d["config"]["rates"]) == {"value", "value_full_config", "value_sustained"} and "value_sustained" in state and state["period_ms"] == 10.0
+    gt = d["gt_concordance_200k"]
+    assert gt["candidates_per_platform"] == 6000 and sorted(gt["platforms"]) == ["illumina", "ont", "pacbio_ccs"]
+    for plat in gt["platforms"].values():
+        assert plat["candidates"] == 6000 and plat["gt_flips"] <= 1 and plat["max_abs_dp"] < 1e-5 and plat["excursions_beyond_1e-5"] == 0
+        assert plat["flips_resolved_by_float64_the_hip_way"] <= plat["gt_flips"]
+    assert d["per_rank"][0]["affinity"] is None             # one rank: placed by the launcher, as before
 
 
 def test_bench_strong_scaling_counts_one_ranks_share_of_the_whole_genome_set():
@@ -555,7 +567,7 @@ def test_bench_strong_scaling_counts_one_ranks_share_of_the_whole_genome_set():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_WARM_STEPS="16")
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--candidates", "625000", "--warmup", "4", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--candidates", "625000", "--warmup", "4", "--no-cpu-baseline", "--gt-candidates", "0"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
