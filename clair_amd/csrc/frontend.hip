@@ -8,7 +8,7 @@
 // filter runs over the tallies, one thread per read base counts the windows it lies in and scatters the inserted bases (pass 2), and
 // the windows are assembled from 33 table columns each.  Why that is the same result -- and when it is not (a tuple budget that
 // binds, unsorted input, bases outside the IUPAC alphabet: reported as CLAIR_FE_* bits, the caller then runs the sequential host
-// code) -- is in oracle/frontend_np.py, the NumPy restatement these kernels are tested against, and in DESIGN.md 6b.
+// code) -- is in oracle/frontend_np.py, the NumPy restatement these kernels are tested against, and in LABNOTES.md part B section 3 / 6b.
 //
 // All integer work, HBM/atomic bound: nothing here is a matrix product.  Tables are sized for the whole region and the packed reads
 // stay resident (a 10 Mb region at 50x: ~0.7 GB of tables, 1.3 - 2.1 GB of reads; a whole chromosome fits the 288 GB many times over), so

@@ -44,7 +44,7 @@ typedef struct clair_op {
 
 enum { CLAIR_OP_M = 0, CLAIR_OP_I = 1, CLAIR_OP_D = 2 };
 
-/* What takes a run out of the regime the device front end reproduces exactly; the caller then runs the sequential
+/* What takes a run out of the regime the device front end reproduces exactly (LABNOTES.md part B 6b); the caller then runs the sequential
  * host code (clair_host_evc_*, clair_host_pileup_*), which reproduces the reference there too, errors included. */
 enum {
     CLAIR_FE_UNSORTED = 1,        /* start positions decrease */
