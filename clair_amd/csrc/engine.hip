@@ -107,7 +107,7 @@ struct clair_engine {
                                // (CLAIR_AMD_LSTM2_FUSED=1): its zx hand-off is ordered by the L2 of ONE XCD -- the producer's stores retired into it, then
                                // its ticket -- which is how the hardware works and what every launch checks its placement for, but it is not a release
                                // the HIP memory model has a name for, and the release it does have (buffer_wbl2 per publication) costs more than the
-                               // launch saves (LABNOTES.md A3: 0.5 us per write-back and XCD; even one per (direction, t) group leaves the launch
+                               // launch saves (0.5 us per write-back and XCD; even one per (direction, t) group leaves the launch
                                // slower than the two it replaces).  The default path of every handle is therefore the two launches, ordered by the
                                // stream.  What the fused launch bought on one- and two-slot handles: 104 us instead of 47 + 78 at batch 1024.
     int fused_groups = 4;      // projection workgroup groups per XCD inside the fused launch (CLAIR_AMD_FUSED_GROUPS)

@@ -2,7 +2,7 @@
 // by side, the recurrent workgroups consuming each zx block as soon as the projection has written it (clair/model.py:443-450).
 // What it buys is TIME on handles with one or two slots (104 us instead of 47 + 78 at batch 1024); the bytes still make the trip:
 // the L2 does not allocate a full-line store that misses, so the block goes to memory and the reader's first touch brings it back
-// (fetch 208 MB + write 174 MB per 1024-batch against 186 + 173 for the two launches; LABNOTES.md part B section 6,
+// (fetch 208 MB + write 174 MB per 1024-batch against 186 + 173 for the two launches; DESIGN.md section 6,
 // profiles/r02_lstm2_fused.txt).
 //
 //   * workgroups [0, P) are projection workgroups, [P, P + C) recurrent ones.  Workgroups reach the CUs in id order and the
