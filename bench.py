@@ -356,7 +356,11 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    group = shard.NodeGroup()          # RCCL through the C ABI when WORLD_SIZE > 1
+    # RCCL through the C ABI when WORLD_SIZE > 1.  BENCH_SHARE_DEVICE=1 (a TEST of the multi-rank flow on a box with one GPU, never a
+    # measurement): every rank runs on device 0 and the ranks talk over the socket transport -- no rank holds an RCCL communicator, so the
+    # line says n_gpus 0 and the exit code is non-zero, as for any run without RCCL.
+    share = os.environ.get("BENCH_SHARE_DEVICE") == "1"
+    group = shard.NodeGroup(transport="tcp", device=0) if share else shard.NodeGroup()
     try:
         rc = run_ranked(args, group, json_fd)
     except BaseException:
@@ -368,7 +372,7 @@ def main():
 
 def run_ranked(args, group, json_fd):
     t_start = time.perf_counter()
-    rank, world, local_rank = group.rank, group.world, group.local_rank
+    rank, world, local_rank = group.rank, group.world, group.device          # the HIP device of this rank (= LOCAL_RANK unless BENCH_SHARE_DEVICE)
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d\n" % (args.gpus, world, world))
 

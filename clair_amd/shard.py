@@ -448,10 +448,11 @@ class NodeGroup(object):
     bind: pin this process to the host cores of its GPU's NUMA node (None: when WORLD_SIZE > 1 and the transport is not the CPU one, or
     CLAIR_AMD_BIND=1; `sysfs_root` / `bdf` exist for the CPU tests); the record is `self.affinity`."""
 
-    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None, bind=None, sysfs_root="/sys", bdf=None):
+    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None, bind=None, sysfs_root="/sys", bdf=None, device=None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank))) if local_rank is None else int(local_rank)
+        self.device = self.local_rank if device is None else int(device)      # the HIP device of this rank
         if not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
         self.transport = "none"
@@ -462,10 +463,10 @@ class NodeGroup(object):
         self._star = _TcpStar(self.rank, self.world, rendezvous_path(), timeout)
         # every rank next to its own GPU (see bind_to_gpu), before any buffer of the engine is allocated and first touched
         self.affinity = None
-        if bind is None:
-            bind = want_binding(self.world) and transport != "tcp"
+        if bind is None:          # over the CPU transport (tests without a GPU) only when asked for by name
+            bind = want_binding(self.world) and (transport != "tcp" or os.environ.get("CLAIR_AMD_BIND") == "1")
         if bind:
-            self.affinity = bind_to_gpu(self.local_rank, self._star.allgather if self.world > 1 else None, self.rank, sysfs_root=sysfs_root, bdf=bdf)
+            self.affinity = bind_to_gpu(self.device, self._star.allgather if self.world > 1 else None, self.rank, sysfs_root=sysfs_root, bdf=bdf)
         if self.world == 1:
             return
         if transport is None:
@@ -480,7 +481,7 @@ class NodeGroup(object):
             lib = _capi.load()
             # Pre-flight over the sockets, BEFORE anything collective: a rank whose device ordinal is out of range or that cannot
             # load librccl would otherwise raise alone and leave the others inside ncclCommInitRank for ever.
-            mine = "" if lib.clair_comm_preflight(self.local_rank) == 0 else lib.clair_comm_last_error(None).decode()
+            mine = "" if lib.clair_comm_preflight(self.device) == 0 else lib.clair_comm_last_error(None).decode()
             status = self._star.allgather(mine)
             bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
             if bad:
@@ -501,7 +502,7 @@ class NodeGroup(object):
                 return
             uid = (ctypes.c_uint8 * 128).from_buffer_copy(got[1])
             h = ctypes.c_void_p()
-            mine = "" if lib.clair_comm_create(self.local_rank, self.rank, self.world, uid, ctypes.byref(h)) == 0 else lib.clair_comm_last_error(None).decode()
+            mine = "" if lib.clair_comm_create(self.device, self.rank, self.world, uid, ctypes.byref(h)) == 0 else lib.clair_comm_last_error(None).decode()
             status = self._star.allgather(mine)
             bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
             if bad:

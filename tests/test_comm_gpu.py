@@ -61,3 +61,35 @@ def test_bench_under_torch_distributed_run_one_rank_and_own_spawner(tmp_path):
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["steps"] == 12 and len(d["per_rank"]) == 1 and d["per_rank"][0]["steps"] == 12
         assert d["roofline"]["bound"] == "mfma" and d["roofline"]["kernel"].split()[0] in ("proj2", "l4", "lstm1", "lstm2")
+
+
+def test_bench_two_ranks_share_the_one_gpu_over_the_socket_transport():
+    """The N > 1 flow of bench.py with REAL engines (round 5): two ranks, both on device 0 (BENCH_SHARE_DEVICE=1), the barrier, the max over
+    ranks, the weight blob and the per-rank records over the socket transport; every rank bound to its share of the cores next to the GPU
+    (CLAIR_AMD_BIND=1: the same NUMA node, split in two).  A test of the plumbing, not a measurement: no rank holds an RCCL communicator, so
+    the line says n_gpus 0 and rank 0 exits non-zero -- a multi-GPU number is only ever reported over RCCL."""
+    import json
+    import os
+    import sys
+    from clair_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_WARM_STEPS="16", BENCH_SHARE_DEVICE="1", CLAIR_AMD_BIND="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "4", "--no-cpu-baseline", "--gt-candidates", "0",
+           "--sustained-seconds", "0.3", "--full-candidates", "8192"]
+    procs = shard.spawn_ranks(cmd, 2, env=env, stderr_pipe=True)
+    out = procs[0].stdout.read().decode()
+    errs = [p.stderr.read().decode() for p in procs]
+    rcs = [p.wait(timeout=600) for p in procs]
+    assert rcs == [1, 0], errs
+    assert "0 of 2 ranks hold an RCCL communicator" in errs[0]
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 0 and d["config"]["transport"] == "tcp" and len(d["per_rank"]) == 2
+    assert d["config"]["candidates_total"] == 2 * 40 * 1024 and d["value"] > 1e6 and d["value_sustained"] > 1e6 and d["parity_max_abs_err"] < 1e-5
+    aff = [r["affinity"] for r in d["per_rank"]]
+    assert aff[0]["pci"] == aff[1]["pci"] and aff[0]["pci"] and aff[0]["numa_node"] == aff[1]["numa_node"]
+    if aff[0]["cpus_bound"]:          # the kernel knows the GPU's node: the two ranks took disjoint halves of its cores
+        a, b = (set(shard.parse_cpulist(x["cpus_bound"])) for x in aff)
+        assert a and b and not (a & b)
+    for r in d["per_rank"]:           # each rank sampled the GPU's clock and power during its legs
+        assert set(r["gpu_state"]["value_sustained"]) == {"sclk_mhz", "power_w", "samples"}
+    assert d["boundary"]["bit_identical_to_resident"] is True
