@@ -129,6 +129,30 @@ def test_two_ranks_under_torch_distributed_run_cross_checked_with_gloo(tmp_path)
     _check(out, res.stdout)
 
 
+def test_eight_ranks_under_torch_distributed_run_cross_checked_with_gloo(tmp_path):
+    """The driver's launcher at the world size of its scaling run: `python -m torch.distributed.run --nproc-per-node 8`, the rendezvous file
+    named after MASTER_PORT and the launcher's pid, NodeGroup's reductions cross-checked against torch.distributed's gloo backend inside the
+    eight workers."""
+    out = str(tmp_path / "gathered.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "out": out, "gloo": True})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("CLAIR_AMD_RDZV", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT")][0]
+    assert line.split()[1:5] == ["37", "8.0", "37", "tcp"]
+    from clair_amd import synth, weights
+    from oracle import c_oracle
+    want = np.concatenate(c_oracle.forward(weights.synthetic_weights(seed=5), synth.synthetic_input(37, "ont", seed=9)[0], threads=1), axis=1)
+    assert np.array_equal(np.load(out), want)
+
+
 def test_bench_gpus_2_spawns_two_ranks_that_fail_loudly_without_a_device():
     from clair_amd import _capi
     if _capi.load().clair_device_count() > 0:
