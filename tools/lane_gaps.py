@@ -14,12 +14,16 @@ WGS = {"lstm32_kernel<true>": None, "lstm32_kernel<false>": None, "gemm_split": 
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 0.5
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     rows = db.execute("select name, start, end, grid_x, workgroup_x%s from kernels order by start" % (", " + qcol if qcol else "")).fetchall()
     rows = [r for r in rows if any(k in r[0] for k in WGS)]
-    rows = rows[int(len(rows) * frac):int(len(rows) * 0.95)]
+    if "--passes" in sys.argv:          # forward passes [a, b) in launch order (five kernels each): e.g. the timed leg behind bench.py's warm-up
+        a, b = (int(v) for v in sys.argv[sys.argv.index("--passes") + 1:sys.argv.index("--passes") + 3])
+        rows = rows[5 * a:5 * b]
+    else:
+        rows = rows[int(len(rows) * frac):int(len(rows) * 0.95)]
     if not rows:
         print("no forward-pass kernels in", sys.argv[1])
         return
@@ -32,6 +36,12 @@ def main():
         gaps = np.array([max(0, b[1] - a[2]) for a, b in zip(rs, rs[1:])]) / 1e3
         busy = sum(r[2] - r[1] for r in rs) / 1e3
         span = (rs[-1][2] - rs[0][1]) / 1e3
+        by = {}
+        for a, b in zip(rs, rs[1:]):
+            key = "%s -> %s" % (a[0].split("(")[0].replace("void clair::", "").replace("clair::", "")[:22], b[0].split("(")[0].replace("void clair::", "").replace("clair::", "")[:22])
+            by.setdefault(key, []).append(max(0, b[1] - a[2]) / 1e3)
+        for key, v in sorted(by.items()):
+            print("    %-50s n %4d  gap median %6.2f us  mean %6.2f" % (key, len(v), float(np.median(v)), float(np.mean(v))))
         print("queue %s: %d kernels, busy %.0f us of %.0f (%.1f %%), gap between consecutive kernels: median %.2f us, mean %.2f, p90 %.2f; gaps = %.1f %% of the lane's time"
               % (q, len(rs), busy, span, 100 * busy / span, np.median(gaps), gaps.mean(), np.percentile(gaps, 90), 100 * gaps.sum() / span))
     # occupancy: workgroups resident is unknown per instant, but an upper bound per kernel is its grid; integrate min(256, sum of grids of running kernels)
