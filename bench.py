@@ -108,9 +108,23 @@ def load_pmc(batch, fused):
     return table, "%s (kernel sources %s)" % (entry.get("source"), here)
 
 
+def load_rocprof_ms(batch):
+    """{kernel: mean ms in the timed leg} from the committed `rocprofv3 --kernel-trace --stats` summary of this configuration, when
+    profiles/pmc_traffic.json carries one stamped with the digest of the kernel sources this run executes; else None."""
+    from clair_amd import build
+    try:
+        entry = json.load(open(PMC_TABLE)).get("entries", {}).get(str(batch))
+    except (OSError, ValueError):
+        return None
+    if not entry or entry.get("csrc_digest") != build.csrc_digest():
+        return None
+    return entry.get("kernel_ms_rocprof")
+
+
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
 PEAK_F16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: f16/bf16 MFMA dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+ACHIEVABLE_FABRIC_TBS = 6.29            # MI355X_MICROARCH.md: what a streaming copy achieves through L2 <-> fabric <-> HBM
 # energy roofline of the 2-way fp16 split (DESIGN.md section 6): MFMAs executed per candidate (three per fp32-grade product block of 32 x 32 x 16;
 # L3's K padded 33 -> 48), the joules one costs, the board's power cap and idle draw
 MFMA_PER_CANDIDATE = (64 * 4 * 33 * (120 + 96) + (17301504 + 2 * 1474560 + 2 * 82368) * 1024 * 3 // 32768 + 253440 * 2 * 1024 * 3 * 48 // 33 // 32768) / 1024.0
@@ -135,8 +149,10 @@ def parse_args(argv=None):
     ap.add_argument("--boundary-slots", type=int, default=6, help="batches in flight at the host-array boundary (0: skip the boundary legs)")
     ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the value_sustained leg (0: skip)")
     ap.add_argument("--gt-candidates", type=int, default=200000, help="candidates PER PLATFORM PROFILE of the GT concordance count against the oracle (N=1 only; 0: skip)")
-    ap.add_argument("--gt-seconds", type=float, default=240.0, help="time budget of that count: platforms are cut short (and say so) beyond it")
+    ap.add_argument("--gt-seconds", type=float, default=240.0, help="time budget of that count, enforced inside each platform's loop: platform k of 3 starts no chunk after "
+                    "k/3 of it and says `truncated` (200 000 candidates take 50-60 s per platform on the GPU boxes seen so far)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check and the 1 024-candidate decode (timing-only builds whose results are garbage: tools/gpu/nozx_variants.sh)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -202,28 +218,34 @@ def cpu_baseline(w, x, seconds):
 
 def gt_concordance_at_scale(device, w, n_per_platform, budget_s):
     """tools/gt_concordance.py's count, in the bench line: per platform profile, the VCF rows (CHROM/POS/REF/ALT/GT) that differ between the
-    decode of the HIP probabilities and the decode of the float32 oracle's on the same `n_per_platform` synthetic candidates, each flip
-    re-examined with the float64 evaluation.  The oracle (test infrastructure, here as the checker) runs at a few thousand candidates per
-    second on the host cores, so the count has a time budget: a platform that would start beyond it is skipped and says so."""
+    decode of the HIP probabilities and the decode of the float32 oracle's on the same `n_per_platform` synthetic candidates; every flip
+    analysed by tools/gt_ties.py (is the pair one float32 cannot decide, and does float64 decide it the HIP way: `flips_not_excused` must
+    be 0), beside the number of candidates that are inherently ambiguous (`near_ties`: winner and runner-up closer than a perturbation eps
+    of the probabilities moves them, eps = 0 / 3e-6 / 1e-5).  The oracle (test infrastructure, here as the checker) runs at a few thousand
+    candidates per second on the host cores, so the count has a time budget ENFORCED INSIDE each platform's loop: platform k of 3 starts
+    no 32 768-candidate chunk after k/3 of the budget, says `truncated` and reports the candidates it did compare."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gt_concordance", os.path.join(ROOT, "tools", "gt_concordance.py"))
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
     eng = _capi.Engine(device=device, max_batch=4096, n_slots=1)
     eng.load_weights(w)
-    out, t0 = {"candidates_per_platform": n_per_platform, "platforms": {}, "tool": "tools/gt_concordance.py: concordance(seed 777, one slot, batch 4096)"}, time.perf_counter()
+    out, t0 = {"candidates_per_platform": n_per_platform, "budget_s": budget_s, "platforms": {},
+               "tool": "tools/gt_concordance.py: concordance(seed 777, one slot, batch 4096); flips analysed by tools/gt_ties.py"}, time.perf_counter()
+    names = ("ont", "pacbio_ccs", "illumina")
     try:
-        for platform in ("ont", "pacbio_ccs", "illumina"):
-            spent = time.perf_counter() - t0
-            done = len(out["platforms"])
-            if done and spent + spent / done > budget_s:
-                out["platforms"][platform] = {"skipped": "time budget of %.0f s (--gt-seconds) would be exceeded" % budget_s}
-                continue
-            r = tool.concordance(eng, w, platform, n_per_platform, 777, log=lambda *a: None)
+        for k, platform in enumerate(names):
+            r = tool.concordance(eng, w, platform, n_per_platform, 777, log=lambda *a: None, deadline=t0 + budget_s * (k + 1) / len(names))
             out["platforms"][platform] = {"candidates": r["candidates"], "vcf_rows": r["vcf_rows"], "gt_flips": r["gt_flips"], "max_abs_dp": r["max_abs_dp"],
                                           "excursions_beyond_1e-5": len(r["excursions"]),
-                                          "flips_resolved_by_float64_the_hip_way": sum(1 for f in r["flips"] if f["oracle64_rounded"] is not None
-                                                                                        and tool.key(f["oracle64_rounded"]) == tool.key(f["hip"]))}
+                                          "flips_resolved_by_float64_the_hip_way": sum(1 for f in r["flips"] if f["float64_sides_with_hip"] or f["float64_tie"]),
+                                          "flips_not_excused": r["flips_not_excused"], "near_ties": r["near_ties"],
+                                          "flips_among_near_ties_at_1e-5": r["flips_among_near_ties_at_1e-5"],
+                                          "flips": [{"position": f["hip"].split("\t")[1] if f["hip"] else None, "hip": f["hip_outcome"], "oracle32": f["oracle32_outcome"],
+                                                     "oracle64": f["oracle64_outcome"], "margin_o32": f.get("margin_o32"), "margin_o64_towards_hip": f.get("margin_o64_towards_hip"),
+                                                     "eps_o32_vs_o64": f["eps_o32_vs_o64"], "sensitivity": f.get("sensitivity"), "excused": f["excused"]} for f in r["flips"]]}
+            if "truncated" in r:
+                out["platforms"][platform]["truncated"] = r["truncated"]
     finally:
         eng.close()
     out["seconds"] = round(time.perf_counter() - t0, 1)
@@ -360,13 +382,17 @@ def main():
     # measurement): every rank runs on device 0 and the ranks talk over the socket transport -- no rank holds an RCCL communicator, so the
     # line says n_gpus 0 and the exit code is non-zero, as for any run without RCCL.
     share = os.environ.get("BENCH_SHARE_DEVICE") == "1"
-    group = shard.NodeGroup(transport="tcp", device=0) if share else shard.NodeGroup()
+    # BENCH_SHARE_TRANSPORT=rccl (with a stand-in librccl, CLAIR_AMD_RCCL_LIBRARY: real RCCL refuses two ranks on one GPU): the RCCL
+    # bring-up itself under test -- tests/test_comm_gpu.py hangs it and expects the line all the same
+    group = shard.NodeGroup(transport=os.environ.get("BENCH_SHARE_TRANSPORT", "tcp"), device=0) if share else shard.NodeGroup()
     try:
         rc = run_ranked(args, group, json_fd)
     except BaseException:
         group.close(barrier=False)     # unwinding: the peers may be gone, do not wait for them
         raise
     group.close()
+    if group.rccl_abandoned:           # a helper thread is still inside a hung RCCL bring-up: the line is out, do not wait for librccl's tear-down
+        group.exit_process(rc)
     return rc
 
 
@@ -496,7 +522,7 @@ def run_ranked(args, group, json_fd):
 
     # parity spot check of one resident batch against the oracle (outside the timed region)
     parity = concord = None
-    if rank == 0:
+    if rank == 0 and not args.no_parity:
         from clair_amd import call_var as cvar
         from oracle import c_oracle
         ns = min(1024, batch * nuniq)
@@ -538,6 +564,7 @@ def run_ranked(args, group, json_fd):
         if fused:
             design["lstm2"] = 33 * 256 * 4 + 33 * 1024 * 4 + 33 * 256 * 4
         pmc, pmc_note = load_pmc(batch, fused)
+        rocprof_ms = load_rocprof_ms(batch)
         kern = {k: {"ms_mean": (round(ms / cnt, 5) if cnt else None), "launches": cnt} for k, (ms, cnt) in times.items()}
         kern_iso = {k: round(alone_ms[k], 5) if k in alone_ms else None for k in times_iso}
 
@@ -554,7 +581,10 @@ def run_ranked(args, group, json_fd):
                              "chip_time_share_alone": round(chip_time[k] / max(sum(chip_time.values()), 1e-12), 3),
                              "traffic": round(pmc[k]) if pmc and k in pmc else None, "design_bytes_per_launch": design[k] * batch}
         dom = dominant
-        dom_ms_mean = dom_ms / max(dom_cnt, 1)                        # in the multi-stream run, events on this kernel only
+        # ONE duration for the dominant kernel: its mean over the timed loop repeated with HIP events on every kernel (table `kernels`,
+        # the same number as kernels[dom].in_flight_ms).  The loop with events around this kernel only is kept as `kernel_ms_with_events_on_it_only`.
+        dom_ms_mean = times[dom][0] / max(times[dom][1], 1)
+        dom_ms_only = dom_ms / max(dom_cnt, 1)
         flop = kflop[dom] * batch
         tf = flop / (dom_ms_mean * 1e-3) / 1e12
         tf_alone = flop / (alone_ms[dom] * 1e-3) / 1e12
@@ -567,9 +597,12 @@ def run_ranked(args, group, json_fd):
             "traffic_source": pmc_note,
             "definition": "dominant kernel = most chip time (stand-alone HIP-event duration x share of the 256 CUs its grid occupies) in this run's own "
                           "table (`kernels`); frac = SURVEY.md 8(d) algorithmic FLOP of that kernel per launch (%d per candidate x batch) / its mean "
-                          "HIP-event duration with %d batches in flight (the timed loop repeated with events around this kernel only) / dense f16 MFMA peak"
-                          % (kflop[dom], streams),
-            "kernel_ms": round(dom_ms_mean, 5), "launches": dom_cnt, "algorithmic_flop_per_launch": flop,
+                          "HIP-event duration with %d batches in flight (the timed loop repeated with HIP events on every kernel: the same number as "
+                          "kernels[dominant].in_flight_ms and .frac) / dense f16 MFMA peak; the rocprofv3 mean of the same kernel in the same loop is "
+                          "`kernel_ms_rocprof` when profiles/pmc_traffic.json was stamped on these kernel sources" % (kflop[dom], streams),
+            "kernel_ms": round(dom_ms_mean, 5), "launches": times[dom][1], "algorithmic_flop_per_launch": flop,
+            "kernel_ms_with_events_on_it_only": round(dom_ms_only, 5),
+            "kernel_ms_rocprof": rocprof_ms.get(dom) if rocprof_ms else None,
             "executed_frac": round(tf * SPLIT_TERMS / PEAK_F16_MFMA_TFLOPS, 4),
             "executed_note": "matmuls run as a 2-way fp16 split: 3 v_mfma_f32_32x32x16_f16 per algorithmic fp32 product block",
             "alone_kernel_ms": round(alone_ms[dom], 5), "alone_frac": round(tf_alone / PEAK_F16_MFMA_TFLOPS, 4),
@@ -639,6 +672,12 @@ def run_ranked(args, group, json_fd):
                               "algorithmic_hbm_gbs": round(value / world * BYTES_PER_CANDIDATE / 1e9, 2),
                               "algorithmic_hbm_frac": round(value / world * BYTES_PER_CANDIDATE / 1e9 / PEAK_HBM_GBS, 6),
                               "measured_traffic_bytes_per_candidate": round(sum(pmc[k] for k in active if k in pmc) / batch) if pmc else None,
+                              # the closest roof of the whole line: every intermediate crosses the L2 <-> fabric boundary (PMC FETCH_SIZE + WRITE_SIZE per
+                              # candidate x the sustained rate) against what a streaming copy achieves (profiles/r06_fabric_sensitivity.txt: what it costs)
+                              "fabric_tb_s": round(sum(pmc[k] for k in active if k in pmc) / batch * (sustained["value"] if sustained else value) / world / 1e12, 3) if pmc else None,
+                              "fabric_frac_of_achievable": round(sum(pmc[k] for k in active if k in pmc) / batch * (sustained["value"] if sustained else value) / world / 1e12
+                                                                 / ACHIEVABLE_FABRIC_TBS, 4) if pmc else None,
+                              "fabric_achievable_tb_s": ACHIEVABLE_FABRIC_TBS,
                               # the board is at its power cap whatever runs: what the formulation's MFMAs alone would allow
                               "energy_bound": {"mfma_per_candidate": MFMA_PER_CANDIDATE, "nj_per_mfma": NJ_PER_MFMA, "cap_w": BOARD_CAP_W, "idle_w": BOARD_IDLE_W,
                                                "candidates_per_s_per_gpu": round((BOARD_CAP_W - BOARD_IDLE_W) / (MFMA_PER_CANDIDATE * NJ_PER_MFMA * 1e-9), 1),

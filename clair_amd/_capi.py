@@ -21,7 +21,7 @@ SYMBOLS = (
     "clair_run_resident", "clair_sync",
     "clair_timing_enable", "clair_kernel_times", "clair_timing_reset", "clair_kernel_workgroups",
     "clair_debug_read", "clair_engine_counter",
-    "clair_comm_preflight", "clair_comm_unique_id", "clair_comm_create", "clair_comm_destroy", "clair_comm_abort", "clair_comm_last_error", "clair_comm_barrier",
+    "clair_comm_preflight", "clair_comm_unique_id", "clair_comm_create", "clair_comm_create_timed", "clair_comm_destroy", "clair_comm_abort", "clair_comm_last_error", "clair_comm_barrier",
     "clair_comm_allreduce_f64", "clair_comm_broadcast", "clair_comm_allgather", "clair_comm_allgather_device",
     "clair_frontend_create", "clair_frontend_destroy", "clair_frontend_last_error", "clair_frontend_add_reads",
     "clair_frontend_find_candidates", "clair_frontend_set_candidates", "clair_frontend_get_candidates", "clair_frontend_build_windows",
@@ -96,6 +96,8 @@ def load(path=None):
     lib.clair_comm_preflight.argtypes = [c_int]
     lib.clair_comm_unique_id.argtypes = [c_vp]
     lib.clair_comm_create.argtypes = [c_int, c_int, c_int, c_vp, ctypes.POINTER(c_vp)]
+    if not older_ok or hasattr(lib, "clair_comm_create_timed"):
+        lib.clair_comm_create_timed.argtypes = [c_int, c_int, c_int, c_vp, c_int, ctypes.POINTER(c_vp)]
     lib.clair_comm_destroy.argtypes = [c_vp]
     lib.clair_comm_destroy.restype = None
     if not older_ok or hasattr(lib, "clair_comm_abort"):

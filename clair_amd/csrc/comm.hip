@@ -9,10 +9,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and prototypes only; the entry points are resolved at run time
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 
 namespace {
 
@@ -34,8 +40,11 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r = [] {
         Rccl q;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // CLAIR_AMD_RCCL_LIBRARY: another build of RCCL -- or the stand-in whose ncclCommInitRank never returns on one rank
+        // (tests/test_comm_gpu.py: the deadline of clair_comm_create_timed against a real hang)
+        const char *names[] = {getenv("CLAIR_AMD_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
+            if (!n || !*n) continue;
             q.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (q.handle) break;
         }
@@ -91,6 +100,56 @@ int cfail(clair_comm *c, const char *fmt, ...) {
         if (res__ != ncclSuccess) return cfail((c), "%s failed: %s (%s:%d)", #call, rccl().GetErrorString(res__), __FILE__, __LINE__); \
     } while (0)
 
+std::string fmt(const char *f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+// ncclCommInitRank and the communicator's stream; with `first_collective` also one all-reduce of a double (RCCL connects its
+// transports on first use: a fresh communicator's first collective is where a broken xGMI / bootstrap set-up shows).  Errors go
+// to `err` (this may run on a helper thread whose thread-local error text nobody reads).
+int comm_init(int device, int rank, int world, const uint8_t *id, bool first_collective, clair_comm **out, std::string &err) {
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) { err = fmt("rank %d / world %d out of range", rank, world); return 1; }
+    int ndev = 0;
+    hipError_t herr = hipGetDeviceCount(&ndev);
+    if (herr != hipSuccess || ndev <= 0) { err = fmt("no HIP device available (hipGetDeviceCount: %s); RCCL needs one GPU per rank", hipGetErrorString(herr)); return 1; }
+    if (device < 0 || device >= ndev) { err = fmt("device %d out of range [0,%d)", device, ndev); return 1; }
+    if (!rccl().error.empty()) { err = rccl().error; return 1; }
+    if ((herr = hipSetDevice(device)) != hipSuccess) { err = fmt("hipSetDevice(%d) failed: %s", device, hipGetErrorString(herr)); return 1; }
+    clair_comm *c = new clair_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclResult_t res = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (res != ncclSuccess) {
+        err = fmt("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(res));
+        delete c;
+        return 1;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        err = "hipStreamCreate failed for the communicator stream";
+        (void)rccl().CommDestroy(c->comm);
+        delete c;
+        return 1;
+    }
+    if (first_collective) {
+        double one = 1.0;
+        if (clair_comm_allreduce_f64(c, &one, 1, CLAIR_COMM_SUM) || one != (double)world) {
+            err = fmt("first all-reduce on the new communicator failed on rank %d of %d: %s", rank, world,
+                      c->error.empty() ? fmt("sum of ones = %g", one).c_str() : c->error.c_str());
+            clair_comm_abort(c);
+            return 1;
+        }
+    }
+    *out = c;
+    return 0;
+}
+
 int need_scratch(clair_comm *c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return 0;
     if (c->scratch) (void)hipFree(c->scratch);
@@ -135,31 +194,57 @@ int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_
     if (!out) return cfail(nullptr, "out is NULL");
     *out = nullptr;
     if (!id) return cfail(nullptr, "id is NULL");
-    if (world < 1 || rank < 0 || rank >= world) return cfail(nullptr, "rank %d / world %d out of range", rank, world);
-    int ndev = 0;
-    hipError_t err = hipGetDeviceCount(&ndev);
-    if (err != hipSuccess || ndev <= 0)
-        return cfail(nullptr, "no HIP device available (hipGetDeviceCount: %s); RCCL needs one GPU per rank", hipGetErrorString(err));
-    if (device < 0 || device >= ndev) return cfail(nullptr, "device %d out of range [0,%d)", device, ndev);
-    if (!rccl().error.empty()) return cfail(nullptr, "%s", rccl().error.c_str());
-    COMM_HIP(nullptr, hipSetDevice(device));
-    clair_comm *c = new clair_comm();
-    c->device = device; c->rank = rank; c->world = world;
-    ncclUniqueId u;
-    memcpy(&u, id, sizeof u);
-    ncclResult_t res = rccl().CommInitRank(&c->comm, world, u, rank);
-    if (res != ncclSuccess) {
-        cfail(nullptr, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(res));
-        delete c;
-        return 1;
-    }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        cfail(nullptr, "hipStreamCreate failed for the communicator stream");
-        (void)rccl().CommDestroy(c->comm);
-        delete c;
-        return 1;
-    }
+    std::string err;
+    clair_comm *c = nullptr;
+    if (comm_init(device, rank, world, id, /*first_collective=*/false, &c, err)) return cfail(nullptr, "%s", err.c_str());
     *out = c;
+    return 0;
+}
+
+// The same with a deadline.  ncclCommInitRank is collective and blocking: a peer that never joins, a bootstrap interface that
+// swallows packets or a driver that never completes the xGMI set-up leave it waiting for ever, and the first collective on a fresh
+// communicator (transports are connected lazily) can hang the same way.  Both run on a helper thread; the caller waits for it up
+// to `timeout_ms`.  On expiry the caller gets CLAIR_COMM_TIMED_OUT and goes on WITHOUT this communicator (clair_amd/shard.py: every
+// rank hears of it over the bootstrap sockets and all of them use the socket transport); the helper thread is left to itself, and
+// if RCCL ever returns there the communicator is aborted on the spot (ncclCommAbort) and freed.
+int clair_comm_create_timed(int device, int rank, int world, const uint8_t *id, int timeout_ms, clair_comm_t **out) {
+    if (!out) return cfail(nullptr, "out is NULL");
+    *out = nullptr;
+    if (!id) return cfail(nullptr, "id is NULL");
+    if (timeout_ms <= 0) return cfail(nullptr, "timeout_ms must be positive");
+    struct Pending {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false, abandoned = false;
+        int rc = 1;
+        std::string err;
+        clair_comm *c = nullptr;
+        uint8_t id[CLAIR_COMM_ID_BYTES];
+    };
+    auto st = std::make_shared<Pending>();
+    memcpy(st->id, id, CLAIR_COMM_ID_BYTES);
+    std::thread([st, device, rank, world] {
+        std::string err;
+        clair_comm *c = nullptr;
+        const int rc = comm_init(device, rank, world, st->id, /*first_collective=*/true, &c, err);
+        std::unique_lock<std::mutex> lk(st->m);
+        if (st->abandoned) {          // nobody is waiting any more: this communicator must not outlive the decision to do without it
+            lk.unlock();
+            if (c) clair_comm_abort(c);
+            return;
+        }
+        st->rc = rc; st->err = err; st->c = c; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->m);
+    if (!st->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return st->done; })) {
+        st->abandoned = true;
+        cfail(nullptr, "ncclCommInitRank + first all-reduce of rank %d of %d did not return within %.1f s: abandoned on its helper thread "
+                       "(aborted there if it ever returns)", rank, world, timeout_ms / 1e3);
+        return CLAIR_COMM_TIMED_OUT;
+    }
+    if (st->rc) return cfail(nullptr, "%s", st->err.c_str());
+    *out = st->c;
     return 0;
 }
 

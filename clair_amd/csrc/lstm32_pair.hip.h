@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * L32_HBUF_BYTES];
     _Float16 (*hbuf)[2][2][L32_TILE][HP_ROW] = (_Float16 (*)[2][2][L32_TILE][HP_ROW])lds_raw;   // [tile][step parity][plane][cand][unit]
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;      // not const: re-defined (to itself) in front of the epilogue, see there
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cand = lane & 31, hq = lane >> 5;
@@ -189,6 +189,11 @@ _Pragma("unroll")                                                               
         for (int g = 1; g <= 23; ++g) P2_GAP(g, 1, 3, s & 1)
     }
     __syncthreads();
+    // The epilogue's per-thread offsets (chunk g = 256 j + tid and what follows from it) are pure functions of tid: hipcc computed them in
+    // the prologue and carried them across the step loop, where every one of the 256 VGPRs is taken -- three of them went to scratch
+    // (16 B per lane, the only scratch of the whole pass; profiles/r05_kernel_resource_usage.txt).  An opaque re-definition of tid here
+    // makes them values of the epilogue.
+    asm volatile("" : "+v"(tid));
 #pragma unroll
     for (int tl = 0; tl < 2; ++tl)
 #pragma unroll

@@ -204,6 +204,17 @@ def _compress_cpulist(cpus):
     return ",".join(out)
 
 
+def rccl_init_timeout(socket_timeout=180.0):
+    """Seconds the collective part of the RCCL bring-up (ncclCommInitRank + the first all-reduce) may take on a rank before that rank
+    gives it up: CLAIR_AMD_RCCL_INIT_TIMEOUT, default 60 s, and never more than a third of the bootstrap sockets' own timeout (the
+    ranks that did come up wait on a socket for the one that is still counting)."""
+    try:
+        v = float(os.environ.get("CLAIR_AMD_RCCL_INIT_TIMEOUT", "60"))
+    except ValueError:
+        v = 60.0
+    return max(0.001, min(v, socket_timeout / 3.0))
+
+
 def want_binding(world):
     v = os.environ.get("CLAIR_AMD_BIND", "")
     return v == "1" or (v != "0" and world > 1)
@@ -448,7 +459,8 @@ class NodeGroup(object):
     bind: pin this process to the host cores of its GPU's NUMA node (None: when WORLD_SIZE > 1 and the transport is not the CPU one, or
     CLAIR_AMD_BIND=1; `sysfs_root` / `bdf` exist for the CPU tests); the record is `self.affinity`."""
 
-    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None, bind=None, sysfs_root="/sys", bdf=None, device=None):
+    def __init__(self, transport=None, timeout=180.0, rank=None, world=None, local_rank=None, bind=None, sysfs_root="/sys", bdf=None, device=None,
+                 init_timeout=None):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank))) if local_rank is None else int(local_rank)
@@ -457,6 +469,7 @@ class NodeGroup(object):
             raise ValueError("rank %d outside world of %d" % (self.rank, self.world))
         self.transport = "none"
         self.rccl_failure = None          # why an asked-for RCCL communicator is not there (then transport == "tcp")
+        self.rccl_abandoned = False       # this rank's RCCL bring-up ran into its deadline: a helper thread may still sit inside librccl
         self._lib = None
         self._comm = None
         self.timeout = timeout
@@ -487,10 +500,12 @@ class NodeGroup(object):
             if bad:
                 self._star.close()
                 raise _capi.EngineError("RCCL start-up refused on %d of %d ranks -- %s" % (len(bad), self.world, "; ".join(bad)))
-            # From here on a failure is RCCL's own start-up (no usable bootstrap interface, a library / driver mismatch): every rank learns
-            # of it over the sockets and ALL of them go on with the "tcp" transport -- the data path has no collective, what is carried is
-            # the timing barrier, one max and the 9.5 MB of weights.  Said on stderr and in bench.py's line (`config.transport`,
-            # `config.rccl_failure`); a rank that HANGS inside ncclCommInitRank still ends the job at `timeout`.
+            # From here on a failure is RCCL's own start-up (no usable bootstrap interface, a library / driver mismatch, a bring-up that
+            # HANGS): every rank learns of it over the sockets and ALL of them go on with the "tcp" transport -- the data path has no
+            # collective, what is carried is the timing barrier, one max and the 9.5 MB of weights.  Said on stderr and in bench.py's
+            # line (`config.transport`, `config.rccl_failure`).  The collective part -- ncclCommInitRank and the first all-reduce on the
+            # new communicator -- runs under a deadline of its own (clair_comm_create_timed, `init_timeout`): a rank whose RCCL never
+            # returns reports "timed out" like any other failure, well inside the sockets' `timeout`.
             uid = (ctypes.c_uint8 * 128)()
             first = None
             if self.rank == 0:
@@ -502,7 +517,16 @@ class NodeGroup(object):
                 return
             uid = (ctypes.c_uint8 * 128).from_buffer_copy(got[1])
             h = ctypes.c_void_p()
-            mine = "" if lib.clair_comm_create(self.device, self.rank, self.world, uid, ctypes.byref(h)) == 0 else lib.clair_comm_last_error(None).decode()
+            init_timeout = rccl_init_timeout(timeout) if init_timeout is None else float(init_timeout)
+            timed = getattr(lib, "clair_comm_create_timed", None)
+            if timed is not None:
+                rc = timed(self.device, self.rank, self.world, uid, max(1, int(init_timeout * 1000)), ctypes.byref(h))
+            else:                     # an older build of the library (CLAIR_AMD_LIB): no deadline
+                rc = lib.clair_comm_create(self.device, self.rank, self.world, uid, ctypes.byref(h))
+            mine = "" if rc == 0 else lib.clair_comm_last_error(None).decode()
+            if rc == 2:               # CLAIR_COMM_TIMED_OUT: a helper thread of this process is still inside RCCL (see close_process)
+                self.rccl_abandoned = True
+                mine = "init timed out on rank %d after %g s (%s)" % (self.rank, init_timeout, mine)
             status = self._star.allgather(mine)
             bad = ["rank %d: %s" % (r, m) for r, m in enumerate(status) if m]
             if bad:
@@ -623,6 +647,16 @@ class NodeGroup(object):
             self._lib.clair_comm_destroy(self._comm)
             self._comm = None
         self._star.close()
+
+    def exit_process(self, rc):
+        """Leave the PROCESS with `rc` once the caller has written its results.  Normally sys.exit; after an abandoned RCCL bring-up
+        (`rccl_abandoned`) a helper thread still sits inside librccl, whose own threads and static destructors may wait for it for ever:
+        then stdout / stderr are flushed and the process ends with os._exit -- the N-rank line is already out."""
+        if self.rccl_abandoned:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(int(rc))
+        sys.exit(int(rc))
 
 
 def spawn_ranks(argv, world, env=None, rdzv_dir=None, stderr_pipe=False):

@@ -27,8 +27,9 @@ extern "C" {
 /* 1: round-1 surface.  2: + clair_slot_input, clair_submit_counts, clair_kernel_workgroups (added late in round 1 without a
  * bump), the clair_comm_* communicator (round 2).  3: + clair_engine_counter, clair_comm_preflight, clair_submit_ex, clair_decode, clair_pinned_alloc / _free and kernel id CLAIR_K_DECODE (round 3).
  * 4: + the clair_frontend_* device front end; clair_submit_ex takes device pointers (round 3).
- * 5: + clair_device_pci_bus_id (round 5: a rank finds the NUMA node of ITS GPU, clair_amd/shard.py), clair_comm_abort. */
-#define CLAIR_ABI_VERSION 5
+ * 5: + clair_device_pci_bus_id (round 5: a rank finds the NUMA node of ITS GPU, clair_amd/shard.py), clair_comm_abort.
+ * 6: + clair_comm_create_timed (round 6: a hung RCCL bring-up ends at a deadline, not at the job's). */
+#define CLAIR_ABI_VERSION 6
 
 /* geometry: shared/param.py:9-11 (33 x 8 x 4 input), clair/task/main.py:10-29 (head sizes) */
 #define CLAIR_POSITIONS 33
@@ -232,9 +233,15 @@ int clair_comm_unique_id(uint8_t *id /*[CLAIR_COMM_ID_BYTES]*/);                
 int clair_comm_create(int device, int rank, int world, const uint8_t *id, clair_comm_t **out);   /* ncclCommInitRank */
 void clair_comm_destroy(clair_comm_t *c);
 /* Tear-down that does not wait for the peers (ncclCommAbort): for a communicator that came up on this rank while a peer's
- * clair_comm_create failed.  Only fast, symmetric start-up failures fall back to the socket transport (clair_amd/shard.py);
- * a rank that hangs inside ncclCommInitRank still ends the job at the bootstrap's timeout. */
+ * clair_comm_create failed, and for the helper thread of clair_comm_create_timed when RCCL returns after its deadline. */
 void clair_comm_abort(clair_comm_t *c);
+/* clair_comm_create with a deadline (round 6; ABI 6): ncclCommInitRank AND the first collective on the new communicator (one
+ * all-reduce: RCCL connects its transports lazily) run on a helper thread; 0 = up and proven, 1 = failed (clair_comm_last_error(NULL)),
+ * CLAIR_COMM_TIMED_OUT = neither returned within `timeout_ms`.  On a time-out no communicator exists for the caller: the helper thread
+ * is abandoned and aborts its communicator should RCCL ever return.  clair_amd/shard.py then tells the peers over the bootstrap
+ * sockets and every rank goes on over the socket transport -- a hung RCCL bring-up still yields the N-rank line (`rccl_failure`). */
+#define CLAIR_COMM_TIMED_OUT 2
+int clair_comm_create_timed(int device, int rank, int world, const uint8_t *id, int timeout_ms, clair_comm_t **out);
 const char *clair_comm_last_error(const clair_comm_t *c);                         /* c may be NULL: failure of create / unique_id */
 int clair_comm_barrier(clair_comm_t *c);
 int clair_comm_allreduce_f64(clair_comm_t *c, double *values /*in place*/, int count, int op /*enum clair_comm_op*/);

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_tensor_table():
     lib = _capi.load()
-    assert lib.clair_abi_version() == 5
+    assert lib.clair_abi_version() == 6
     text = open(HEADER).read()
     ids = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"CLAIR_T_([A-Z0-9_]+)\s*=\s*(\d+)", text))
     assert ids.pop("COUNT") == len(weights.TENSOR_TABLE) == 22

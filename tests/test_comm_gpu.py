@@ -77,9 +77,7 @@ def test_bench_two_ranks_share_the_one_gpu_over_the_socket_transport():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "4", "--no-cpu-baseline", "--gt-candidates", "0",
            "--sustained-seconds", "0.3", "--full-candidates", "8192"]
     procs = shard.spawn_ranks(cmd, 2, env=env, stderr_pipe=True)
-    out = procs[0].stdout.read().decode()
-    errs = [p.stderr.read().decode() for p in procs]
-    rcs = [p.wait(timeout=600) for p in procs]
+    out, errs, rcs = _collect(procs, 600)
     assert rcs == [1, 0], errs
     assert "0 of 2 ranks hold an RCCL communicator" in errs[0]
     d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
@@ -93,3 +91,96 @@ def test_bench_two_ranks_share_the_one_gpu_over_the_socket_transport():
     for r in d["per_rank"]:           # each rank sampled the GPU's clock and power during its legs
         assert set(r["gpu_state"]["value_sustained"]) == {"sclk_mhz", "power_w", "samples"}
     assert d["boundary"]["bit_identical_to_resident"] is True
+
+
+def _collect(procs, timeout):
+    """stdout of rank 0 and every rank's stderr, read CONCURRENTLY (a rank that fills one pipe while the test waits on another would
+    block for ever: HIP / RCCL / AMD_LOG_LEVEL output easily exceeds the 64 KB a pipe holds), then the exit codes."""
+    import threading
+    bufs = {}
+
+    def drain(key, pipe):
+        bufs[key] = pipe.read().decode(errors="replace")
+
+    threads = [threading.Thread(target=drain, args=(("err", r), p.stderr), daemon=True) for r, p in enumerate(procs) if p.stderr is not None]
+    threads.append(threading.Thread(target=drain, args=(("out", 0), procs[0].stdout), daemon=True))
+    for t in threads:
+        t.start()
+    rcs = [p.wait(timeout=timeout) for p in procs]
+    for t in threads:
+        t.join(timeout=30)
+    return bufs.get(("out", 0), ""), [bufs.get(("err", r), "") for r in range(len(procs))], rcs
+
+
+def _fake_rccl(tmp_path):
+    import os
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl.c")
+    so = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", src, "-o", so])
+    return so
+
+
+def test_comm_create_timed_gives_up_on_an_rccl_that_never_returns(tmp_path):
+    """clair_comm_create_timed against a librccl whose ncclCommInitRank sleeps for ever (tests/fake_rccl.c, CLAIR_AMD_RCCL_LIBRARY):
+    CLAIR_COMM_TIMED_OUT at the deadline, no communicator, an error text that says so -- and when RCCL returns AFTER the deadline the
+    abandoned helper thread aborts the communicator it got (ncclCommAbort, marked by the stand-in)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mark = str(tmp_path / "abort_mark")
+    code = textwrap.dedent("""
+        import ctypes, sys, time
+        sys.path.insert(0, %r)
+        from clair_amd import _capi
+        lib = _capi.load()
+        uid = (ctypes.c_uint8 * 128)()
+        assert lib.clair_comm_unique_id(uid) == 0 and bytes(uid)[:4] == b"\\x07" * 4        # the stand-in's id: it IS the library in use
+        h = ctypes.c_void_p()
+        t0 = time.time()
+        rc = lib.clair_comm_create_timed(0, 0, 2, uid, 1500, ctypes.byref(h))
+        dt = time.time() - t0
+        print("RC", rc, bool(h.value), round(dt, 2), lib.clair_comm_last_error(None).decode())
+        time.sleep(float(sys.argv[1]))
+    """ % root)
+    env = dict(os.environ, CLAIR_AMD_RCCL_LIBRARY=_fake_rccl(tmp_path), CLAIR_FAKE_RCCL_HANG="all", CLAIR_FAKE_RCCL_ABORT_MARK=mark)
+    r = subprocess.run([sys.executable, "-c", code, "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = [ln for ln in r.stdout.splitlines() if ln.startswith("RC ")][0].split(" ", 4)
+    assert f[1] == "2" and f[2] == "False" and 1.4 <= float(f[3]) < 5.0 and "did not return within 1.5 s" in f[4] and "rank 0 of 2" in f[4]
+    assert not os.path.exists(mark)
+    # RCCL returns 3 s after the call, 1.5 s after the deadline: nobody waits for it any more, the helper thread aborts what it got
+    r = subprocess.run([sys.executable, "-c", code, "4"], env=dict(env, CLAIR_FAKE_RCCL_LATE="3"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("RC ")][0].split()[1] == "2"
+    assert open(mark).read() == "aborted\n"
+
+
+def test_bench_prints_its_two_rank_line_although_the_rccl_bring_up_hangs(tmp_path):
+    """VERDICT r05 item 4 on the GPU box, with real engines: two ranks (both on device 0) ask for the RCCL transport, the library's
+    ncclCommInitRank never returns on either rank.  Each rank gives up at CLAIR_AMD_RCCL_INIT_TIMEOUT, tells the other over the bootstrap
+    sockets, both go on over the socket transport; rank 0 prints the ONE JSON line with `rccl_failure`: "... init timed out on rank ...",
+    n_gpus 0, and the ranks leave (os._exit: a helper thread is still inside the library) with the exit codes of any run without RCCL."""
+    import json
+    import os
+    import sys
+    import time
+    from clair_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_WARM_STEPS="16", BENCH_SHARE_DEVICE="1", BENCH_SHARE_TRANSPORT="rccl", CLAIR_AMD_RCCL_LIBRARY=_fake_rccl(tmp_path),
+               CLAIR_FAKE_RCCL_HANG="all", CLAIR_AMD_RCCL_INIT_TIMEOUT="3")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4", "--no-cpu-baseline", "--gt-candidates", "0",
+           "--sustained-seconds", "0.2", "--full-candidates", "4096", "--boundary-slots", "0"]
+    t0 = time.time()
+    procs = shard.spawn_ranks(cmd, 2, env=env, stderr_pipe=True)
+    out, errs, rcs = _collect(procs, 600)
+    assert rcs == [1, 0], errs
+    assert time.time() - t0 < 300
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 0 and d["config"]["transport"] == "tcp" and d["config"]["ranks_with_rccl_communicator"] == 0
+    why = d["config"]["rccl_failure"]
+    assert "clair_comm_create failed on 2 of 2 ranks" in why and "init timed out on rank 0 after 3 s" in why and "init timed out on rank 1 after 3 s" in why
+    assert "RCCL start-up failed" in errs[0] and "0 of 2 ranks hold an RCCL communicator" in errs[0]
+    assert len(d["per_rank"]) == 2 and d["config"]["candidates_total"] == 2 * 20 * 1024 and d["value"] > 1e6 and d["parity_max_abs_err"] < 1e-5

@@ -337,6 +337,63 @@ def test_a_failing_rccl_start_up_sends_every_rank_to_the_socket_transport(tmp_pa
             assert "clair_comm_create failed on 1 of 2 ranks -- rank 1:" in line and (" 1 |" in line) == (r == 0)      # rank 0's communicator was destroyed
 
 
+RCCL_HANGS_WORKER = textwrap.dedent("""
+    import os, sys, time, numpy as np
+    sys.path.insert(0, %(root)r)
+    from clair_amd import _capi, shard
+
+    class Lib(object):
+        # A libclair_amd whose RCCL bring-up HANGS on rank 1: clair_comm_create_timed comes back with CLAIR_COMM_TIMED_OUT after its deadline.
+        aborted = 0
+        def clair_device_count(self): return 2
+        def clair_comm_preflight(self, local_rank): return 0
+        def clair_comm_unique_id(self, uid): return 0
+        def clair_comm_create(self, *a): raise AssertionError("the blocking create must not be used when the timed one exists")
+        def clair_comm_create_timed(self, local_rank, rank, world, uid, timeout_ms, h):
+            Lib.timeout_ms = timeout_ms
+            if rank == 1:
+                time.sleep(timeout_ms / 1000.0)
+                return 2
+            h._obj.value = 1234
+            return 0
+        def clair_comm_abort(self, h): Lib.aborted += 1
+        def clair_comm_destroy(self, h): raise AssertionError("a communicator whose peer never came up is aborted, not destroyed")
+        def clair_comm_last_error(self, comm): return b"ncclCommInitRank + first all-reduce of rank 1 of 2 did not return within 1.5 s"
+    lib = Lib()
+    _capi.load = lambda *a, **k: lib
+    t0 = time.time()
+    g = shard.NodeGroup(transport="rccl", timeout=30.0)
+    g.barrier()
+    top = g.max_float(10.0 + g.rank)
+    w = g.broadcast_array(np.arange(5, dtype=np.float32) * (1 if g.rank == 0 else 0))
+    with open(%(out)r + str(g.rank), "w") as f:
+        print("RANK", g.rank, g.transport, top, w.tolist(), Lib.aborted, g.rccl_abandoned, Lib.timeout_ms, round(time.time() - t0, 1), "|", g.rccl_failure, file=f)
+    g.close()
+    g.exit_process(3)
+""")
+
+
+def test_an_rccl_bring_up_that_hangs_on_one_rank_ends_at_its_deadline_and_every_rank_goes_on_over_the_sockets(tmp_path):
+    """the first place RCCL with N > 1 ranks ever runs is the driver's scaling job.  clair_comm_create_timed gives the
+    collective part of the bring-up a deadline (CLAIR_AMD_RCCL_INIT_TIMEOUT, here 1.5 s); the rank it expires on says so over the
+    bootstrap sockets, the rank whose communicator did come up aborts it, both fall back to the socket transport, and the process that
+    abandoned a helper thread inside RCCL leaves with os._exit once its results are written (exit code kept)."""
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_HANGS_WORKER % {"root": ROOT, "out": str(tmp_path / "rank")})
+    procs = shard.spawn_ranks([sys.executable, str(script)], 2, env=dict(os.environ, CLAIR_AMD_RCCL_INIT_TIMEOUT="1.5"))
+    assert [p.wait(timeout=60) for p in procs] == [3, 3]
+    for r in (0, 1):
+        f = (tmp_path / ("rank%d" % r)).read_text().split()
+        assert f[:3] == ["RANK", str(r), "tcp"] and f[3] == "11.0"
+        line = " ".join(f)
+        assert "[0.0, 1.0, 2.0, 3.0, 4.0]" in line and " 1500 " in line
+        assert "clair_comm_create failed on 1 of 2 ranks -- rank 1: init timed out on rank 1 after 1.5 s" in line and "did not return within" in line
+        took = float(line.split(" | ")[0].split()[-1])
+        assert 1.4 <= took < 15.0
+        assert ((" 1 False " in line) if r == 0 else (" 0 True " in line)), line      # rank 0 aborted its communicator; rank 1 abandoned its helper thread
+    assert shard.rccl_init_timeout(180.0) == 60.0 and shard.rccl_init_timeout(30.0) == 10.0
+
+
 BENCH_WORKER = textwrap.dedent("""
     import sys, numpy as np
     sys.path.insert(0, %(root)r)

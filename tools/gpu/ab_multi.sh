@@ -21,7 +21,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 g=d['gpu_state'].get('value_sustained') or d['gpu_state'].get('value') or {}
 b=d.get('boundary') or {}
-print('value %.0f sustained %s ms/step %s power %s W sclk %s MHz parity %.2e boundary f32 %s i16 %s alone %s' % (d['value'], d.get('value_sustained'), (d.get('sustained') or {}).get('ms_per_step'), g.get('power_w'), g.get('sclk_mhz'), d['parity_max_abs_err'],
+print('value %.0f sustained %s ms/step %s power %s W sclk %s MHz parity %.2e boundary f32 %s i16 %s alone %s' % (d['value'], d.get('value_sustained'), (d.get('sustained') or {}).get('ms_per_step'), g.get('power_w'), g.get('sclk_mhz'), d['parity_max_abs_err'] if d['parity_max_abs_err'] is not None else float('nan'),
       (b.get('float32') or {}).get('value'), (b.get('int16') or {}).get('value'), {k: v for k, v in d['kernels_alone_ms'].items() if v}))")
     echo "round $i $name: $out"
   done

@@ -2,8 +2,10 @@
 """VCF GT concordance at scale on the GPU box: decode the HIP probabilities and the float32 oracle's probabilities of the
 same synthetic candidates with the same decoder (clair/call_var.py:733-762: arg-max over float32 products with
 exact-equality membership tests) and count the rows whose CHROM/POS/REF/ALT/GT differ.  Every flip is then re-examined with
-the float64 evaluation: a flip whose two candidate calls are within float32 noise of each other in float64 is a tie the
-reference itself would break differently from run to run (multithreaded Eigen, no fixed reduction order).
+the float64 evaluation and with tools/gt_ties.py: a flip is EXCUSED only when the float32 oracle's margin between the two calls is
+smaller than its own distance from float64 can move it (float32 cannot decide the pair) and float64 decides it the HIP way.  The
+count of such inherently ambiguous candidates (`near_ties`, at eps = 0 / 3e-6 / 1e-5 on the probabilities) is printed beside the flips:
+the reference itself (multithreaded Eigen, no fixed reduction order) would not be bit-stable on them either.
 
 Instrumented (round 3; one of nine round-2 runs showed chunks beyond the 1e-5 tolerance on a box nobody recorded):
   * the box is identified first (GPU unique id, PCI bus, clocks, power, ECC/RAS counters, kernel selection of the handle);
@@ -14,6 +16,7 @@ Instrumented (round 3; one of nine round-2 runs showed chunks beyond the 1e-5 to
     is written to <dump-dir>/excursion_<platform>_<chunk>.npz, which comes back in gpurun_out/.
 
 Usage:  python tools/gt_concordance.py [--n 200000] [--platforms ont,pacbio_ccs,illumina] [--json out.json] [--taps] [--dump-dir gpurun_out]
+        [--tightest 8 --ties gpurun_out/gt_ties.npz]     (the recipe of tests/golden/gt_ties.npz)
 """
 import argparse
 import glob
@@ -27,6 +30,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 from clair_amd import _capi, call_var as cvar, synth, weights  # noqa: E402
 
@@ -158,12 +162,28 @@ def dissect(eng, w, platform, c0, x, got, want, batch, taps, dump_dir, log, wors
     return {"chunk_start": int(c0), "candidates_beyond_tol": int(len(bad)), "worst": float(err.max()), "verdict": verdict}
 
 
-def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print, keep_taps=False, dump_dir=None):
+NEAR_TIE_EPS = (0.0, 3e-6, 1e-5)     # tools/gt_ties.py: multiplication order alone | the worst |dp| ever measured | the stated tolerance
+
+
+def _pack(a4):
+    return np.concatenate([np.asarray(a).reshape(-1) for a in a4])
+
+
+def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print, keep_taps=False, dump_dir=None, deadline=None, tightest=0):
+    """Decode the HIP probabilities and the float32 oracle's of the same `n` synthetic candidates, count the differing calls, and say of
+    every one whether float32 can decide it at all (tools/gt_ties.py).  `deadline` (time.perf_counter() value): no chunk STARTS after
+    it -- the result then says `truncated` and how many candidates were compared.  `tightest` > 0: also keep that many candidates with
+    the smallest winner / runner-up margins (inputs and all three evaluations), for tests/golden/gt_ties.npz."""
+    import gt_ties
     from oracle import c_oracle
     dec = cvar.VariantDecoder(cvar.OutputConfig(True, False, False, False, False, None))
-    flips, rows_total, worst, excursions = [], 0, 0.0, []
+    flips, rows_total, worst, excursions, done = [], 0, 0.0, [], 0
+    near = {eps: 0 for eps in NEAR_TIE_EPS}
+    kept = []                                   # (margin, record) of the tightest candidates seen so far
     t0 = time.time()
     for c0 in range(0, n, chunk):
+        if deadline is not None and c0 and time.perf_counter() > deadline:
+            break
         m = min(chunk, n - c0)
         raw, infos = synth.synthetic_candidates(m, platform, seed=seed + c0, start=100000 + 7 * c0)
         x = synth.to_model_input(raw)
@@ -181,21 +201,68 @@ def concordance(eng, w, platform, n, seed, batch=4096, chunk=32768, log=print, k
         if chunk_worst > PROB_TOL:
             excursions.append(dissect(eng, w, platform, c0, x, got, want, batch, taps, dump_dir, log))
         worst = max(worst, chunk_worst)
+        counts, masks, margins = gt_ties.near_tie_counts(want, infos, NEAR_TIE_EPS)
+        for eps in NEAR_TIE_EPS:
+            near[eps] += counts[eps]
         rows_g = dec.decode_batch(x, infos, got)
         rows_w = dec.decode_batch(x, infos, want)
         assert len(rows_g) == len(rows_w)
         rows_total += len(rows_w)
+        by_pos = None
+
+        def record(idx, kind):
+            o64 = c_oracle.forward(w, x[idx:idx + 1], dtype=np.float64)
+            o64r = [o.astype(np.float32) for o in o64]
+            one = lambda Y: dec.decode_batch(x[idx:idx + 1], infos[idx:idx + 1], Y)  # noqa: E731
+            row_h, row_w, row_d = one([g[idx:idx + 1] for g in got]), one([t[idx:idx + 1] for t in want]), one(o64r)
+            rec = gt_ties.analyse_flip(dec, x[idx], infos[idx], [g[idx] for g in got], [t[idx] for t in want], [o[0] for o in o64])
+            rec.update({"kind": kind, "platform": platform, "chunk_start": int(c0), "index": int(idx), "first_margin_o32": float(margins[idx]),
+                        "hip": row_h[0] if row_h else None, "oracle32": row_w[0] if row_w else None, "oracle64_rounded": row_d[0] if row_d else None,
+                        "max_abs_dp": max(float(np.abs(g[idx] - t[idx]).max()) for g, t in zip(got, want)),
+                        "near_tie_at": [eps for eps in NEAR_TIE_EPS if masks[eps][idx]], "excused": gt_ties.flip_is_excused(rec),
+                        "arrays": {"x": x[idx].copy(), "info": list(infos[idx]), "hip": _pack([g[idx] for g in got]), "o32": _pack([t[idx] for t in want]),
+                                   "o64": _pack([o[0] for o in o64])}})
+            return rec
+
         for j, (a, b) in enumerate(zip(rows_g, rows_w)):
             if key(a) != key(b):
-                pos = int(a.split("\t")[1])
-                idx = [i for i, inf in enumerate(infos) if int(inf[1]) == pos][0]
-                o64 = c_oracle.forward(w, x[idx:idx + 1], dtype=np.float64)
-                row64 = dec.decode_batch(x[idx:idx + 1], infos[idx:idx + 1], [o.astype(np.float32) for o in o64])
-                flips.append({"hip": a, "oracle32": b, "oracle64_rounded": row64[0] if row64 else None,
-                              "max_abs_dp": max(float(np.abs(g[idx] - t[idx]).max()) for g, t in zip(got, want))})
-        log("%s: %d / %d candidates, %d rows, %d flips, max |dp| %.2e, %.0f s  [%s]" % (platform, c0 + m, n, rows_total, len(flips), worst, time.time() - t0, gpu_state()))
-    return {"platform": platform, "candidates": n, "vcf_rows": rows_total, "gt_flips": len(flips), "max_abs_dp": worst, "flips": flips,
-            "excursions": excursions}
+                if by_pos is None:
+                    by_pos = {int(inf[1]): i for i, inf in enumerate(infos)}
+                flips.append(record(by_pos[int(a.split("\t")[1])], "flip"))
+        if tightest:
+            ok = np.flatnonzero(masks[NEAR_TIE_EPS[-1]])
+            flipped = {f["index"] for f in flips if f["chunk_start"] == c0}
+            for idx in [i for i in ok[np.argsort(margins[ok])] if int(i) not in flipped][:tightest]:
+                kept.append((float(margins[idx]), record(int(idx), "tight")))
+            kept = sorted(kept, key=lambda t: t[0])[:tightest]
+        done = c0 + m
+        log("%s: %d / %d candidates, %d rows, %d flips, near-ties %s, max |dp| %.2e, %.0f s  [%s]" % (
+            platform, done, n, rows_total, len(flips), [near[e] for e in NEAR_TIE_EPS], worst, time.time() - t0, gpu_state()))
+    out = {"platform": platform, "candidates": done, "vcf_rows": rows_total, "gt_flips": len(flips), "max_abs_dp": worst, "flips": flips,
+           "excursions": excursions, "near_ties": {"eps_%g" % eps: near[eps] for eps in NEAR_TIE_EPS},
+           "flips_excused": sum(1 for f in flips if f["excused"]), "flips_not_excused": sum(1 for f in flips if not f["excused"]),
+           "flips_among_near_ties_at_1e-5": sum(1 for f in flips if NEAR_TIE_EPS[-1] in f["near_tie_at"] or f["outcomes_tried"] != [0, 0]),
+           "tightest": [r for _, r in kept]}
+    if done < n:
+        out["truncated"] = "time budget reached after %d of %d candidates" % (done, n)
+    return out
+
+
+def strip_arrays(rec):
+    return {k: v for k, v in rec.items() if k != "arrays"}
+
+
+def save_ties(path, results):
+    """tests/golden/gt_ties.npz: every flip and the tightest margins of a run -- inputs, the three evaluations, the three calls and the analysis."""
+    import json as _json
+    recs = [r for res in results for r in res["flips"] + res["tightest"]]
+    meta = [strip_arrays(r) for r in recs]
+    np.savez_compressed(path, meta=np.array(_json.dumps(meta)),
+                        x=np.stack([r["arrays"]["x"] for r in recs]).astype(np.float32) if recs else np.zeros((0, 33, 8, 4), np.float32),
+                        info=np.array([_json.dumps(r["arrays"]["info"]) for r in recs]),
+                        hip=np.stack([r["arrays"]["hip"] for r in recs]).astype(np.float32) if recs else np.zeros((0, 90), np.float32),
+                        o32=np.stack([r["arrays"]["o32"] for r in recs]).astype(np.float32) if recs else np.zeros((0, 90), np.float32),
+                        o64=np.stack([r["arrays"]["o64"] for r in recs]).astype(np.float64) if recs else np.zeros((0, 90), np.float64))
 
 
 if __name__ == "__main__":
@@ -206,6 +273,8 @@ if __name__ == "__main__":
     ap.add_argument("--head-gain", type=float, default=4.0)
     ap.add_argument("--taps", action="store_true", help="keep every batch's LSTM1 / LSTM2 outputs until its chunk is checked (first diverging layer on an excursion)")
     ap.add_argument("--dump-dir", default=os.path.join(ROOT, "gpurun_out"))
+    ap.add_argument("--tightest", type=int, default=0, help="keep this many smallest-margin candidates per platform (with --ties)")
+    ap.add_argument("--ties", default=None, help="write every flip and the tightest margins as an .npz (the recipe of tests/golden/gt_ties.npz)")
     a = ap.parse_args()
     box = box_info()
     print("box: %s %s" % (box["host"], " ".join(box["unique_ids"])), flush=True)
@@ -216,12 +285,18 @@ if __name__ == "__main__":
     eng.load_weights(w)
     print("kernel selection at batch 4096, one slot: workgroups %s; env %s" % (eng.kernel_workgroups(4096),
           {k: v for k, v in os.environ.items() if k.startswith("CLAIR_AMD_")}), flush=True)
-    res = [concordance(eng, w, p, a.n, 777, keep_taps=a.taps, dump_dir=a.dump_dir, log=lambda *s: print(*s, flush=True)) for p in a.platforms.split(",")]
+    res = [concordance(eng, w, p, a.n, 777, keep_taps=a.taps, dump_dir=a.dump_dir, log=lambda *s: print(*s, flush=True), tightest=a.tightest)
+           for p in a.platforms.split(",")]
     eng.close()
+    if a.ties:
+        save_ties(a.ties, res)
     for r in res:
-        print(json.dumps({k: v for k, v in r.items() if k != "flips"}))
+        print(json.dumps({k: v for k, v in r.items() if k not in ("flips", "tightest")}))
         for f in r["flips"]:
-            print("  FLIP", json.dumps(f))
+            print("  FLIP", json.dumps(strip_arrays(f)))
+        for f in r["tightest"]:
+            print("  TIGHT", json.dumps(strip_arrays(f)))
+        r["flips"], r["tightest"] = [strip_arrays(f) for f in r["flips"]], [strip_arrays(f) for f in r["tightest"]]
     print("box: %s %s  excursions: %d" % (box["host"], " ".join(box["unique_ids"]), sum(len(r["excursions"]) for r in res)))
     if a.json:
         with open(a.json, "w") as f:

@@ -42,5 +42,32 @@ def main():
     print(path, os.path.getsize(path))
 
 
+def illumina300():
+    """tests/golden/nn_illumina300_64.npz: the input of the TRAINED-LIKE mint variant (tools/mint_tf_golden.py: VARIANTS["trained"]) --
+    64 synthetic candidates of the 300x Illumina profile (depth capped at 250 per position) as int16 counts, with this repository's
+    float32 and float64 oracle outputs on the trained-like recipe weights beside them (so that a drift of the restatement itself
+    shows without TensorFlow).  The recurrence amplifies float32 rounding here: the float32 / float64 distance is recorded in the file."""
+    import mint_tf_golden as m
+    from oracle import c_oracle
+    raw, _ = synth.synthetic_candidates(N, "illumina", seed=301)
+    x = synth.to_model_input(raw)
+    w = m.recipe_weights(trained=True)
+    o32, inter = c_oracle.forward(w, x, keep_intermediates=True)
+    o64 = c_oracle.forward(w, x, dtype=np.float64)
+    np_outs = model_np.forward(w, x)
+    dist = max(float(np.abs(a - b).max()) for a, b in zip(o32, o64))
+    assert max(float(np.abs(a - b).max()) for a, b in zip(o32, np_outs)) < max(2e-6, 2 * dist)          # the NumPy restatement agrees with the C one
+    path = os.path.join(ROOT, "tests", "golden", "nn_illumina300_64.npz")
+    np.savez_compressed(path, raw=raw.astype(np.int16), recipe=m.RECIPE + "-trained", f32_f64_distance=dist,
+                        gt21=o32[0], genotype=o32[1], len1=o32[2], len2=o32[3],
+                        gt21_f64=o64[0], genotype_f64=o64[1], len1_f64=o64[2], len2_f64=o64[3],
+                        a2_absmax=float(np.abs(inter["a2"]).max()), a1_absmax=float(np.abs(inter["a1"]).max()))
+    print(path, os.path.getsize(path), "float32 vs float64 oracle: %.3g; |a1| max %.3f, |a2| max %.3f; mean top probability per head %s"
+          % (dist, float(np.abs(inter["a1"]).max()), float(np.abs(inter["a2"]).max()), [round(float(o.max(axis=1).mean()), 3) for o in o32]))
+
+
 if __name__ == "__main__":
-    main()
+    if "--illumina300" in sys.argv:
+        illumina300()
+    else:
+        main()

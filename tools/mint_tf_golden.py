@@ -12,10 +12,17 @@ candidates and writes every intermediate to tests/golden/nn_tf113_64.npz.  tests
 that file when it is present (and skip, loudly, while it is not): the day it is committed the oracle is pinned to the real
 reference arithmetic and parity stops being "unpinned".
 
-    # Python 3.6/3.7, tensorflow==1.13.2, numpy<1.20; from the repository root:
-    python tools/mint_tf_golden.py                       # -> tests/golden/nn_tf113_64.npz (~0.6 MB)
+    # Python 3.6/3.7, tensorflow==1.13.2, numpy<1.20; from the repository root (tools/pin/run.sh does all of it in a container):
+    python tools/mint_tf_golden.py                       # -> tests/golden/nn_tf113_64.npz (~0.6 MB): fresh-init-like weights, ONT counts
+                                                         #    tests/golden/nn_tf113_trained_64.npz: TRAINED-LIKE weights (LSTM kernels x4, forget
+                                                         #    bias +1, head gain 6) on 300x Illumina counts -- the regime where the recurrence
+                                                         #    amplifies float32 rounding a thousandfold and a semantic slip cannot hide
     python tools/mint_tf_golden.py --mini-checkpoint     # + tests/golden/tf113_mini.{index,data-00000-of-00001,json}: a tf.train.Saver
                                                          #   checkpoint of a 4-unit version of the graph (real bundle format, real names)
+    python tools/mint_tf_golden.py --cudnn-checkpoint    # (tensorflow-gpu==1.13.x + a CUDA GPU) + tests/golden/tf113_cudnn.*: the two BiLSTM
+                                                         #   layers as tf.contrib.cudnn_rnn.CudnnLSTM (the reference's GPU branch, clair/model.py:281-296)
+                                                         #   saved through TF's own CudnnLSTMSaveable AND as the raw opaque buffers, with the
+                                                         #   layers' outputs: pins clair_amd/tf_bundle.py's names and its opaque -> canonical conversion
     python tools/mint_tf_golden.py --list-checkpoint /path/to/model-000016      # variable names / shapes of a REAL Clair model
 
 It is stand-alone on purpose (no import from clair_amd, nothing from /root/reference): the weights come from an integer hash
@@ -58,11 +65,19 @@ def tensor_shapes(h=H, l3=L3_UNITS, l4=L4_UNITS, l5=L5_UNITS):
     return shapes
 
 
-def recipe_weights(h=H, l3=L3_UNITS, l4=L4_UNITS, l5=L5_UNITS):
-    """The golden weight set: uniform with the scale each initialiser of clair/model.py would give (dense: variance 1.3 / fan_in,
+TRAINED_LSTM_GAIN, TRAINED_FORGET_BIAS, TRAINED_HEAD_GAIN = 4.0, 1.0, 6.0
+
+
+def recipe_weights(h=H, l3=L3_UNITS, l4=L4_UNITS, l5=L5_UNITS, trained=False):
+    """The golden weight set (trained=True: the TRAINED-LIKE variant, see below): uniform with the scale each initialiser of clair/model.py would give (dense: variance 1.3 / fan_in,
     LSTM kernels: 2 x Glorot), non-zero biases everywhere (a zero bias would hide a mis-wired one), head kernels x8 so that the
     softmaxes are peaky (mean top probability 0.55 .. 0.98 per head on the golden candidates).  LSTM outputs reach +-0.78 without
-    saturating: no dead gate hides an error either; the float32 oracle sits 4e-6 from its float64 twin on this set."""
+    saturating: no dead gate hides an error either; the float32 oracle sits 4e-6 from its float64 twin on this set.
+    trained=True is what training leaves behind and fresh initialisation never shows: LSTM kernels x4 (gates that saturate), +1 on the
+    forget-gate bias rows [2h, 3h) (a cell state that integrates over all 33 steps), head kernels x6 -- the cell of
+    tools/parity_sweep.py where float32 rounding is amplified ~1000x through the recurrence (the float32 oracle sits up to a few 1e-4
+    from float64 there on 300x counts), so that a wrong gate order, a missing forget bias or a transposed kernel is four orders of
+    magnitude above the noise instead of one."""
     w = {}
     for tag, (key, shape) in enumerate(tensor_shapes(h, l3, l4, l5), start=1):
         u = _uniform(tag, int(np.prod(shape))).reshape(shape)
@@ -71,17 +86,29 @@ def recipe_weights(h=H, l3=L3_UNITS, l4=L4_UNITS, l5=L5_UNITS):
         elif key.startswith("lstm"):
             scale = 2.0 * np.sqrt(6.0 / (shape[0] + shape[1]))
         else:
-            scale = np.sqrt(3.0 * 1.3 / shape[-2]) * (8.0 if key.startswith("head_") else 1.0)
+            scale = np.sqrt(3.0 * 1.3 / shape[-2]) * ((TRAINED_HEAD_GAIN if trained else 8.0) if key.startswith("head_") else 1.0)
         w[key] = (u * np.float32(scale)).astype(np.float32)
         if key.startswith("lstm1") and key.endswith("_kernel"):
             w[key][:F_IN] *= np.float32(0.1)           # rows that multiply raw pileup counts of 0..250: what training would leave
+        if trained and key.startswith("lstm"):
+            if key.endswith("_kernel"):
+                w[key] *= np.float32(TRAINED_LSTM_GAIN)
+            else:
+                w[key][2 * h:3 * h] += np.float32(TRAINED_FORGET_BIAS)     # gate order i, c~, f, o: the forget rows
     return w
 
 
-def golden_input():
-    """The 64 candidates of the committed fixture tests/golden/nn_forward_64.npz as the network sees them: float32 [64,33,8,4]
-    with channels 1..3 minus channel 0 (clair/utils.py:96-98)."""
-    with np.load(os.path.join(ROOT, "tests", "golden", "nn_forward_64.npz")) as z:
+INPUT_FIXTURES = {"ont": "nn_forward_64.npz", "illumina300": "nn_illumina300_64.npz"}
+# variant -> (trained-like weights?, input profile, output file, recipe tag)
+VARIANTS = {"fresh": (False, "ont", "nn_tf113_64.npz", RECIPE), "trained": (True, "illumina300", "nn_tf113_trained_64.npz", RECIPE + "-trained")}
+
+
+def golden_input(profile="ont"):
+    """64 candidates of a committed fixture as the network sees them: float32 [64,33,8,4] with channels 1..3 minus channel 0
+    (clair/utils.py:96-98).  "ont": tests/golden/nn_forward_64.npz (ONT-like depth ~50); "illumina300": tests/golden/
+    nn_illumina300_64.npz (300x coverage capped at 250 per position, clair/dataPrepScripts/CreateTensor.py:431 -- counts two orders
+    of magnitude above the weights' scale; tools/make_nn_golden.py --illumina300)."""
+    with np.load(os.path.join(ROOT, "tests", "golden", INPUT_FIXTURES[profile])) as z:
         x = z["raw"].astype(np.float32)
     x[:, :, :, 1:] -= x[:, :, :, 0:1]
     return x
@@ -163,11 +190,12 @@ def load_variables(tf, sess, w, h=H):
         raise SystemExit("TensorFlow did not create: %s ..." % ", ".join(missing[:5]))
 
 
-def mint(out_path):
+def mint(out_path, variant="fresh"):
     import tensorflow as tf
     if not tf.__version__.startswith("1.13"):
         sys.stderr.write("warning: TensorFlow %s, the reference pins 1.13.2 (README.md:127); the file records the version\n" % tf.__version__)
-    x_np, w = golden_input(), recipe_weights()
+    trained, profile, _, recipe = VARIANTS[variant]
+    x_np, w = golden_input(profile), recipe_weights(trained=trained)
     tf.reset_default_graph()
     x, t = build_graph(tf)
     cfg = tf.ConfigProto(intra_op_parallelism_threads=1, inter_op_parallelism_threads=1, device_count={"GPU": 0})
@@ -176,7 +204,7 @@ def mint(out_path):
         load_variables(tf, sess, w)
         a1, a2, l3, l4, l5, logits, outs = sess.run([t["a1"], t["a2"], t["l3"], t["l4"], t["l5"], t["logits"], t["outs"]], feed_dict={x: x_np})
     np.savez_compressed(
-        out_path, recipe=RECIPE, tf_version=tf.__version__, numpy_version=np.__version__,
+        out_path, recipe=recipe, variant=variant, tf_version=tf.__version__, numpy_version=np.__version__,
         weights_checksum=np.float64(sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values())),
         gt21=outs[0], genotype=outs[1], len1=outs[2], len2=outs[3],
         logits_gt21=logits[0], logits_genotype=logits[1], logits_len1=logits[2], logits_len2=logits[3],
@@ -212,6 +240,44 @@ def mini_checkpoint(prefix):
     print("%s.{index,data-00000-of-00001,json} written" % prefix)
 
 
+def cudnn_checkpoint(prefix, n=8):
+    """The reference's GPU branch (clair/model.py:281-296): each BiLSTM layer as ONE tf.contrib.cudnn_rnn.CudnnLSTM whose only variable
+    is the flat "opaque_kernel".  Needs tensorflow-gpu 1.13 and a CUDA GPU (CudnnLSTM has no CPU kernel).  Writes
+      <prefix>.{index,data-00000-of-00001}          tf.train.Saver().save: the layers' CudnnLSTMSaveable stores the CANONICAL per-direction
+                                                     kernel / bias tensors -- under whatever names TF gives them (the point of the exercise)
+      <prefix>_raw.{index,data-00000-of-00001}      the opaque buffers themselves (a Saver over a plain name -> variable dict: no saveable)
+      <prefix>.json                                  the opaque values, and a1 / a2 of the first `n` illumina300 candidates
+    tests/test_weights.py: clair_amd/tf_bundle.py must find the canonical tensors under its candidate names, its opaque -> canonical
+    conversion of <prefix>_raw must equal what the saveable wrote, and the oracle's BiLSTM with those tensors must reproduce a1 / a2."""
+    import tensorflow as tf
+    if hasattr(tf, "test") and not tf.test.is_gpu_available(cuda_only=True):
+        raise SystemExit("--cudnn-checkpoint needs tensorflow-gpu==1.13.x and a CUDA GPU: tf.contrib.cudnn_rnn.CudnnLSTM has no CPU kernel")
+    x_np = golden_input("illumina300")[:n].reshape(n, T, F_IN).transpose(1, 0, 2)          # time-major, as clair/model.py:403-418 feeds it
+    tf.reset_default_graph()
+    x = tf.placeholder(tf.float32, shape=(T, None, F_IN), name="X_time_major")
+    layers, prev = [], x
+    for name in ("LSTM1", "LSTM2"):
+        with tf.variable_scope(name):
+            lstm = tf.contrib.cudnn_rnn.CudnnLSTM(num_layers=1, num_units=H, direction="bidirectional", dtype=tf.float32,
+                                                  kernel_initializer=tf.random_uniform_initializer(-0.15, 0.15, seed=11),
+                                                  bias_initializer=tf.random_uniform_initializer(-0.5, 0.5, seed=12))
+            lstm.build(prev.get_shape())
+            prev, _ = lstm(prev)
+        layers.append(prev)
+    opaque = [v for v in tf.global_variables() if v.name.split(":")[0].endswith("opaque_kernel")]
+    if len(opaque) != 2:
+        raise SystemExit("expected one opaque_kernel per layer, TensorFlow created: %s" % [v.name for v in tf.global_variables()])
+    with tf.Session() as sess:
+        sess.run(tf.global_variables_initializer())
+        a1, a2 = sess.run(layers, feed_dict={x: x_np})
+        tf.train.Saver().save(sess, prefix, write_meta_graph=False)
+        tf.train.Saver(var_list={v.name.split(":")[0]: v for v in opaque}).save(sess, prefix + "_raw", write_meta_graph=False)
+        listing = {v.name.split(":")[0]: np.asarray(sess.run(v)).ravel().tolist() for v in opaque}
+    with open(prefix + ".json", "w") as f:
+        json.dump({"tf_version": tf.__version__, "n": n, "opaque": listing, "a1": np.asarray(a1).ravel().tolist(), "a2": np.asarray(a2).ravel().tolist()}, f)
+    print("%s{,_raw}.{index,data-00000-of-00001} and %s.json written" % (prefix, prefix))
+
+
 def list_checkpoint(prefix):
     import tensorflow as tf
     reader = tf.train.NewCheckpointReader(prefix)
@@ -227,13 +293,18 @@ def list_checkpoint(prefix):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "nn_tf113_64.npz"))
+    ap.add_argument("--out-dir", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--variant", default="both", choices=("fresh", "trained", "both"))
     ap.add_argument("--mini-checkpoint", action="store_true")
+    ap.add_argument("--cudnn-checkpoint", action="store_true")
     ap.add_argument("--list-checkpoint", default=None, metavar="PREFIX")
     a = ap.parse_args()
     if a.list_checkpoint:
         list_checkpoint(a.list_checkpoint)
     else:
-        mint(a.out)
+        for variant in (("fresh", "trained") if a.variant == "both" else (a.variant,)):
+            mint(os.path.join(a.out_dir, VARIANTS[variant][2]), variant)
         if a.mini_checkpoint:
-            mini_checkpoint(os.path.join(ROOT, "tests", "golden", "tf113_mini"))
+            mini_checkpoint(os.path.join(a.out_dir, "tf113_mini"))
+        if a.cudnn_checkpoint:
+            cudnn_checkpoint(os.path.join(a.out_dir, "tf113_cudnn"))
