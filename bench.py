@@ -145,6 +145,9 @@ def parse_args(argv=None):
     ap.add_argument("--unique-batches", type=int, default=8, help="distinct synthetic batches kept resident")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--candidates", type=int, default=5000000, help="--scaling strong: size of the fixed candidate set")
+    ap.add_argument("--shard-of", default=None, metavar="R/W", help="--scaling strong on ONE GPU: run exactly the block rank R of a W-rank job would be dealt "
+                    "(clair_amd/shard.py: shard_batches(--candidates, --batch, R, W), its ragged last batch included); per_rank[0] then reads as that "
+                    "rank's entry of the W-rank line would.  How configs[3] (5 M ONT candidates / 8 GPUs) and configs[4] (>= 1 M Illumina candidates, batch 8192 / 8 GPUs) are run on a one-GPU box")
     ap.add_argument("--full-candidates", type=int, default=200704, help="size of the untimed-by-contract leg over the whole candidate set of the config (0: skip)")
     ap.add_argument("--boundary-slots", type=int, default=6, help="batches in flight at the host-array boundary (0: skip the boundary legs)")
     ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the value_sustained leg (0: skip)")
@@ -411,8 +414,19 @@ def run_ranked(args, group, json_fd):
 
     steps = args.steps
     mine_candidates = args.steps * batch
+    stands_for = None
     if args.scaling == "strong":
-        _, mine_candidates = shard.shard_batches(args.candidates, batch, rank, world)
+        as_rank, as_world = rank, world
+        if args.shard_of:
+            if world != 1:
+                raise SystemExit("--shard-of runs one rank's block on one GPU: use it with --gpus 1")
+            as_rank, as_world = (int(v) for v in args.shard_of.split("/"))
+            if not 0 <= as_rank < as_world:
+                raise SystemExit("--shard-of R/W needs 0 <= R < W")
+            stands_for = {"rank": as_rank, "world": as_world, "of_candidates": args.candidates}
+        first_candidate, mine_candidates = shard.shard_batches(args.candidates, batch, as_rank, as_world)
+        if stands_for:
+            stands_for["first_candidate"] = first_candidate
         steps = (mine_candidates + batch - 1) // batch
     steps_max = int(round(group.max_float(steps)))
     nuniq = max(1, min(args.unique_batches, steps_max + args.warmup))
@@ -654,9 +668,10 @@ def run_ranked(args, group, json_fd):
                        "device_warm_steps": device_warm,
                        "device_warm_note": "untimed steps before the contract's --warmup (clock ramp, first touch); BENCH_WARM_STEPS=0 removes them",
                        "collective": "none on the data path; RCCL (clair_comm_*) for the weight broadcast, barrier and timers" if world > 1 else "none (1 rank)",
+                       "stands_for": stands_for,          # --shard-of: this one-GPU run is rank R's block of a W-rank strong-scaling job
                        "transport": group.transport, "ranks_with_rccl_communicator": rccl_ranks if world > 1 else None,
                        "rccl_failure": getattr(group, "rccl_failure", None)},
-            "per_rank": [{"rank": r, "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None,
+            "per_rank": [{"rank": r if not stands_for else stands_for["rank"], "steps": s_, "candidates": c_, "seconds": round(t_, 6), "candidates_per_s": round(c_ / t_, 1) if t_ > 0 else None,
                           "affinity": rank_notes[r]["affinity"], "gpu_state": rank_notes[r]["gpu_state"] if world > 1 else "see gpu_state"}
                          for r, (s_, c_, t_) in enumerate(zip(per_rank_steps, per_rank_candidates, per_rank_s))],
             "boundary": boundary,

@@ -1567,7 +1567,10 @@ int clair_frontend_add_text(clair_frontend_t *f, const char *sam, int64_t len) {
                        (const uint32_t *)op0, (const uint32_t *)elem0, (const uint32_t *)seq0, d.reads, d.ops, d.op_elem, totals[0], totals[1]);
     hipLaunchKernelGGL(fe_text_seq_kernel, dim3(blocks_for(n_kept, 4)), dim3(256), 0, f->stream, (const uint8_t *)d_text, (const TextLine *)lines, (const int64_t *)kept, n_kept,
                        (const uint32_t *)seq0, d.seq);
-    if (launch_tally(f, d, (int64_t)totals[3], after.last_pos + (int64_t)totals[2])) return 1;
+    // the tiled tally bisects over the slab's start positions: once the packer has seen a start go backwards (this slab or an earlier
+    // one: the word is cumulative, and a start below the previous slab's last is exactly such a case) the per-base kernel is used, as
+    // clair_frontend_add_reads does -- an unsorted slab is flagged AND tallied correctly on both entry points
+    if (launch_tally(f, d, (int64_t)totals[3], after.last_pos + (int64_t)totals[2], !(after.anomalies & CLAIR_FE_UNSORTED))) return 1;
     FE_TRY(f, hipGetLastError());
     FE_TRY(f, hipStreamSynchronize(f->stream));
     return 0;

@@ -27,6 +27,7 @@ import socket
 import struct
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -102,9 +103,29 @@ def gpu_locality(bdf, sysfs_root="/sys"):
     return out
 
 
-def plan_affinity(localities, allowed):
+def physical_cores(cpus, sysfs_root="/sys"):
+    """`cpus` grouped by physical core, in the order of each core's lowest hardware thread: the kernel lists a node's cores as e.g.
+    "0-15,64-79" where 64-79 are the SMT siblings of 0-15 (devices/system/cpu/cpuN/topology/thread_siblings_list).  Without that file a
+    hardware thread is its own core."""
+    cpus = sorted(set(int(c) for c in cpus))
+    have, seen, groups = set(cpus), set(), []
+    for c in cpus:
+        if c in seen:
+            continue
+        try:
+            sib = parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "cpu", "cpu%d" % c, "topology", "thread_siblings_list")).read())
+        except OSError:
+            sib = []
+        grp = sorted(t for t in set(sib) | {c} if t in have and t not in seen)
+        seen.update(grp)
+        groups.append(grp)
+    return groups
+
+
+def plan_affinity(localities, allowed, sysfs_root="/sys"):
     """Per rank, the cores it should run on: its GPU's local cores that this process may use (`allowed`: the cgroup's / taskset's set),
-    split evenly among the ranks that share the same set (contiguous slices in rank order; a slice is never empty while there are cores).
+    split evenly among the ranks that share the same set -- in units of PHYSICAL cores (contiguous runs of cores in rank order, every
+    core with all its hardware threads: two ranks never share a core's SMT siblings; a slice is never empty while there are cores).
     None for a rank whose GPU has no known local cores inside `allowed`: that rank stays where the launcher put it."""
     allowed = set(allowed)
     usable = [tuple(c for c in loc.get("cpus", []) if c in allowed) for loc in localities]
@@ -112,13 +133,34 @@ def plan_affinity(localities, allowed):
     for cpus in set(u for u in usable if u):
         sharers = [r for r, u in enumerate(usable) if u == cpus]
         k = len(sharers)
+        cores = physical_cores(cpus, sysfs_root)
         for j, r in enumerate(sharers):
-            if len(cpus) >= k:
-                lo, hi = j * len(cpus) // k, (j + 1) * len(cpus) // k
-                plan[r] = list(cpus[lo:hi])
+            if len(cores) >= k:
+                lo, hi = j * len(cores) // k, (j + 1) * len(cores) // k
+                plan[r] = sorted(t for core in cores[lo:hi] for t in core)
             else:                        # more ranks than cores on this node: share all of them
                 plan[r] = list(cpus)
     return plan
+
+
+def set_affinity_of_process(cpus):
+    """sched_setaffinity for EVERY thread of this process (/proc/self/task), not just the caller: by the time a rank binds itself the HIP
+    runtime, the library's staging threads and NumPy's pool may exist, and a thread keeps the mask it was created with.  Threads that
+    vanish meanwhile are skipped; the calling thread's result decides (raises OSError when refused)."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = []
+    me = threading.get_native_id() if hasattr(threading, "get_native_id") else 0
+    for tid in tids:
+        if tid == me:
+            continue
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass
+    os.sched_setaffinity(0, cpus)
+    return len(tids)
 
 
 def local_pci_bus_id(device):
@@ -147,16 +189,16 @@ def bind_to_gpu(local_rank, peers_allgather=None, rank=0, sysfs_root="/sys", bdf
     everyone = peers_allgather([loc["pci"] or "", loc["numa_node"] if loc["numa_node"] is not None else -1, np.array(loc["cpus"], dtype=np.int64)]) if peers_allgather else None
     if everyone is not None:
         locs = [{"pci": e[0], "numa_node": e[1], "cpus": [int(c) for c in e[2]]} for e in everyone]
-        mine = plan_affinity(locs, allowed)[rank]
+        mine = plan_affinity(locs, allowed, sysfs_root)[rank]
     else:
-        mine = plan_affinity([loc], allowed)[0]
+        mine = plan_affinity([loc], allowed, sysfs_root)[0]
     rec = {"pci": loc["pci"], "numa_node": loc["numa_node"], "cpus_local": len(loc["cpus"]), "cpus_allowed": len(allowed), "cpus_bound": None, "note": None}
     if not mine:
         rec["note"] = "no local cores known for this GPU inside the allowed set: left where the launcher put it"
         return rec
     if apply:
         try:
-            os.sched_setaffinity(0, mine)
+            set_affinity_of_process(mine)
         except (AttributeError, OSError) as e:
             rec["note"] = "sched_setaffinity refused: %s" % e
             return rec
@@ -177,14 +219,14 @@ def bind_worker(device, all_devices, sysfs_root="/sys", apply=True):
     except (AttributeError, OSError):
         return None
     me = devices.index(int(device))
-    mine = plan_affinity(locs, allowed)[me]
+    mine = plan_affinity(locs, allowed, sysfs_root)[me]
     rec = {"pci": locs[me]["pci"], "numa_node": locs[me]["numa_node"], "cpus_local": len(locs[me]["cpus"]), "cpus_allowed": len(allowed), "cpus_bound": None, "note": None}
     if not mine:
         rec["note"] = "no local cores known for this GPU inside the allowed set"
         return rec
     if apply:
         try:
-            os.sched_setaffinity(0, mine)
+            set_affinity_of_process(mine)
         except (AttributeError, OSError) as e:
             rec["note"] = "sched_setaffinity refused: %s" % e
             return rec

@@ -100,6 +100,9 @@ class Tensor(object):
     def fn(self, f):
         self._fn = f
 
+    def get_shape(self):
+        return _Shape(self.static)
+
     def __ge__(self, other):
         return Tensor(lambda feed: self.fn(feed) >= np.float32(other), self.static)
 
@@ -248,6 +251,89 @@ def _dynamic_rnn(cell, inp, reverse):
     return Tensor(fn, [inp.static[0], inp.static[1], h])
 
 
+def random_uniform_initializer(minval, maxval, seed=None):
+    def init(count):
+        return np.random.default_rng(seed).uniform(minval, maxval, count).astype(np.float32)
+    return init
+
+
+def _opaque_layout(input_size, units):
+    """[TF-recall] cuDNN's canonical parameter order of ONE bidirectional LSTM layer, as index ranges into the flat buffer:
+    {(direction, "W"|"R", gate): (offset, rows, cols)} and {(direction, "bW"|"bR", gate): offset}; gates in cuDNN's order i, f, c, o;
+    all matrices (direction-major, W before R) come before all biases (direction-major, bW before bR)."""
+    mats, biases, at = {}, {}, 0
+    for d in ("fw", "bw"):
+        for kind, cols in (("W", input_size), ("R", units)):
+            for g in "ifco":
+                mats[(d, kind, g)] = (at, units, cols)
+                at += units * cols
+    for d in ("fw", "bw"):
+        for kind in ("bW", "bR"):
+            for g in "ifco":
+                biases[(d, kind, g)] = at
+                at += units
+    return mats, biases, at
+
+
+def _opaque_to_canonical(opaque, input_size, units):
+    """What CudnnLSTMSaveable stores: per direction the CudnnCompatibleLSTMCell kernel [input + units, 4 units] (gate columns in
+    LSTMBlockCell's order i, c~, f, o) and bias [4 units] = bW + bR.  Written independently of clair_amd/tf_bundle.py's conversion."""
+    mats, biases, total = _opaque_layout(input_size, units)
+    assert opaque.size == total
+    out = {}
+    for d in ("fw", "bw"):
+        cols, bias = [], []
+        for g in "icfo":
+            ow, r, c = mats[(d, "W", g)]
+            orr, r2, c2 = mats[(d, "R", g)]
+            cols.append(np.concatenate([opaque[ow:ow + r * c].reshape(r, c).T, opaque[orr:orr + r2 * c2].reshape(r2, c2).T], axis=0))
+            bias.append(opaque[biases[(d, "bW", g)]:biases[(d, "bW", g)] + units] + opaque[biases[(d, "bR", g)]:biases[(d, "bR", g)] + units])
+        out[(d, "kernel")] = np.concatenate(cols, axis=1).astype(np.float32)
+        out[(d, "bias")] = np.concatenate(bias).astype(np.float32)
+    return out
+
+
+class _CudnnLSTM(object):
+    """tf.contrib.cudnn_rnn.CudnnLSTM(num_layers=1, direction="bidirectional"): ONE variable, "<scope>/cudnn_lstm/opaque_kernel"."""
+
+    def __init__(self, num_layers, num_units, direction="bidirectional", dtype=None, kernel_initializer=None, bias_initializer=None, seed=None):
+        assert num_layers == 1 and direction == "bidirectional"
+        self.units, self.k_init, self.b_init, self.var = num_units, kernel_initializer, bias_initializer, None
+
+    def build(self, input_shape):
+        self.input_size = list(input_shape)[-1]
+        mats, biases, total = _opaque_layout(self.input_size, self.units)
+        n_w = total - 16 * self.units
+        value = np.concatenate([self.k_init(n_w), self.b_init(16 * self.units)]).astype(np.float32)
+        with variable_scope("cudnn_lstm"):
+            self.var = Variable(_scoped("opaque_kernel"), (total,), float32, value)
+        self.var.cudnn = (self.input_size, self.units)
+        self.var.scope = "/".join(_STATE["scopes"] + ["cudnn_lstm"])
+
+    def __call__(self, inp):
+        h, var = self.units, self.var
+
+        def run(x, kernel, bias, reverse):
+            if reverse:
+                x = x[::-1]
+            n = x.shape[1]
+            cs, hs, outs = np.zeros((n, h), np.float32), np.zeros((n, h), np.float32), []
+            for t in range(x.shape[0]):
+                z = (np.concatenate([x[t], hs], axis=1) @ kernel + bias).astype(np.float32)
+                i, ci, f, o = z[:, :h], z[:, h:2 * h], z[:, 2 * h:3 * h], z[:, 3 * h:]
+                cs = (_sigmoid(f) * cs + _sigmoid(i) * np.tanh(ci)).astype(np.float32)
+                hs = (_sigmoid(o) * np.tanh(cs)).astype(np.float32)
+                outs.append(hs)
+            y = np.stack(outs)
+            return y[::-1] if reverse else y
+
+        def fn(feed):
+            c = _opaque_to_canonical(var.value, self.input_size, h)
+            x = inp.fn(feed)
+            return np.concatenate([run(x, c[("fw", "kernel")], c[("fw", "bias")], False), run(x, c[("bw", "kernel")], c[("bw", "bias")], True)], axis=2)
+        return Tensor(fn, [inp.static[0], inp.static[1], 2 * h]), None
+
+
 def _stack_bidirectional_dynamic_rnn(cells_fw, cells_bw, inputs, dtype=None, time_major=False):
     assert time_major and dtype is float32
     prev = inputs
@@ -297,13 +383,31 @@ def _fixture_writer():
 
 
 class _Saver(object):
+    def __init__(self, var_list=None):
+        self.var_list = var_list
+
+    def _tensors(self):
+        """(name, variable dtype, array) of everything this Saver writes.  Default Saver: every global variable, a CudnnLSTM layer's opaque
+        buffer through its saveable -- the canonical per-direction tensors under the layer's scope [TF-recall: CudnnLSTMSaveable].  A Saver
+        over an explicit name -> variable dict writes those variables as they are (no saveable)."""
+        if self.var_list is not None:
+            return [(name, v.dtype, np.asarray(v.value)) for name, v in self.var_list.items()]
+        out = []
+        for v in global_variables():
+            if getattr(v, "cudnn", None):
+                for (d, kind), value in _opaque_to_canonical(v.value, *v.cudnn).items():
+                    out.append(("%s/stack_bidirectional_rnn/cell_0/bidirectional_rnn/%s/cudnn_compatible_lstm_cell/%s" % (v.scope, d, kind), float32, value))
+            else:
+                out.append((v.name.split(":")[0], v.dtype, np.asarray(v.value)))
+        return out
+
     def save(self, sess, prefix, write_meta_graph=True):
         import struct
         w = _fixture_writer()
         data, items = b"", [(b"", b"\x08\x01\x10\x00\x1a\x02\x08\x01")]
-        for v in sorted(global_variables(), key=lambda v_: v_.name.split(":")[0].encode()):
-            raw = np.ascontiguousarray(v.value, dtype="<f4" if v.dtype is float32 else "<i8").tobytes()
-            items.append((v.name.split(":")[0].encode(), w.entry(1 if v.dtype is float32 else 9, tuple(v.shape.dims), len(data), len(raw), w.masked(raw))))
+        for name, dtype, value in sorted(self._tensors(), key=lambda t: t[0].encode()):
+            raw = np.ascontiguousarray(value, dtype="<f4" if dtype is float32 else "<i8").tobytes()
+            items.append((name.encode(), w.entry(1 if dtype is float32 else 9, tuple(np.shape(value)), len(data), len(raw), w.masked(raw))))
             data += raw
         out = b""
 
@@ -347,7 +451,8 @@ def _global_step():
 
 contrib = types.SimpleNamespace(
     rnn=types.SimpleNamespace(stack_bidirectional_dynamic_rnn=_stack_bidirectional_dynamic_rnn),
-    cudnn_rnn=types.SimpleNamespace(CudnnCompatibleLSTMCell=_CudnnCompatibleLSTMCell))
+    cudnn_rnn=types.SimpleNamespace(CudnnCompatibleLSTMCell=_CudnnCompatibleLSTMCell, CudnnLSTM=_CudnnLSTM))
+test = types.SimpleNamespace(is_gpu_available=lambda cuda_only=False: True)
 layers = types.SimpleNamespace(dense=_dense)
 nn = types.SimpleNamespace(elu=_elu, softmax=_softmax)
 train = types.SimpleNamespace(Saver=_Saver, NewCheckpointReader=_CheckpointReader, get_or_create_global_step=_global_step)

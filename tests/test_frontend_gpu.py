@@ -433,6 +433,34 @@ def test_an_unsorted_slab_from_a_direct_caller_is_tallied_right_and_reported():
     f.close(); g.close()
 
 
+def test_unsorted_text_on_the_device_is_tallied_right_and_reported():
+    """The same on the text entry point (clair_frontend_add_text passed `sorted = true` to the tally even after its own packer had
+    raised CLAIR_FE_UNSORTED for the slab): alignment lines in shuffled order, in one chunk and in three -- the anomaly word says so and the
+    column tallies (hence the candidates and the windows built on them) equal those of the sorted text.  No depth cap here: the cap
+    walks the lines in file order and would keep different alignments."""
+    case = fc.synth(seed=78, n_reads=500, ref_len=3000)
+    lines = case["sam"].split(b"\n")
+    assert lines[-1] == b""
+    perm = np.random.default_rng(6).permutation(len(lines) - 1)
+    shuffled = dict(case, sam=b"\n".join(lines[i] for i in perm) + b"\n")
+    f = device_frontend_text(case, chunks=1, dcov=1 << 20)
+    assert f.text_stats()["anomalies"] == 0
+    n = f.find_candidates(min_coverage=3, threshold=0.1)
+    want = f.candidates()
+    f.build_windows(min_coverage=0, drop_non_iupac_centre=False)
+    want_windows = windows_of(f)
+    assert n > 20
+    for chunks in (1, 3):
+        g = device_frontend_text(shuffled, chunks=chunks, dcov=1 << 20)
+        assert g.text_stats()["anomalies"] & fe.A_UNSORTED
+        assert g.find_candidates(min_coverage=3, threshold=0.1) == n and np.array_equal(g.candidates(), want)
+        g.build_windows(min_coverage=0, drop_non_iupac_centre=False)
+        for a, b in zip(windows_of(g), want_windows):
+            assert np.array_equal(a, b)
+        g.close()
+    f.close()
+
+
 def test_differential_fuzz_with_leading_indels_on_the_device():
     """As tests/test_frontend.py::test_differential_fuzz_with_leading_indels, through both packing paths of the device front end."""
     silent = reported = 0

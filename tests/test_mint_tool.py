@@ -38,6 +38,12 @@ def test_the_mint_tool_runs_end_to_end_and_its_file_is_what_the_oracle_test_read
     # variables agree with the oracle's reading of the same tensors (a transposed L3 slice or a swapped L5 branch would show as 1e-1)
     import test_oracle
     test_oracle.check_oracle_against_minted_file(out)
+    # round 6: the TRAINED-LIKE variant (LSTM kernels x4, forget bias +1, head gain 6 on 300x Illumina counts) through the same consumer
+    out_t = str(tmp_path / "nn_tf113_trained_64.npz")
+    mint.mint(out_t, "trained")
+    with np.load(out_t) as z:
+        assert str(z["variant"]) == "trained" and str(z["recipe"]) == mint.RECIPE + "-trained" and float(np.abs(z["a2_first4"]).max()) > 0.99
+    test_oracle.check_oracle_against_minted_file(out_t)
 
 
 def test_the_mint_tool_finds_every_variable_under_the_loaders_names(mint):
@@ -80,3 +86,23 @@ def test_the_mini_checkpoint_is_what_the_reader_test_reads(mint, tmp_path, capsy
     mint.list_checkpoint(prefix)
     listing = capsys.readouterr().out
     assert "other  global_step" in listing and "model  L4/kernel" in listing and "variables;" in listing
+
+
+def test_the_cudnn_checkpoint_recipe_runs_and_is_what_the_reader_test_reads(mint, tmp_path):
+    """--cudnn-checkpoint (round 6): the reference's GPU branch -- one CudnnLSTM per BiLSTM layer, saved through the layer's saveable and as
+    raw opaque buffers, with the layers' outputs -- executed under the stand-in, then read by the consumer the committed files will go
+    through.  Circular by construction (stand-in and reader share the same recollection of cuDNN's parameter order, written twice); what it
+    proves is that the recipe runs, names its files and variables as the reader expects, and that the consumer's three checks execute."""
+    prefix = str(tmp_path / "tf113_cudnn")
+    mint.cudnn_checkpoint(prefix, n=3)
+    for ext in (".index", ".data-00000-of-00001", "_raw.index", "_raw.data-00000-of-00001", ".json"):
+        assert os.path.isfile(prefix + ext), ext
+    from clair_amd import tf_bundle
+    assert sorted(tf_bundle.read_index(prefix + "_raw.index")) == ["LSTM1/cudnn_lstm/opaque_kernel", "LSTM2/cudnn_lstm/opaque_kernel"]
+    names = sorted(tf_bundle.read_index(prefix + ".index"))
+    assert len(names) == 8 and names[0] == "LSTM1/cudnn_lstm/stack_bidirectional_rnn/cell_0/bidirectional_rnn/bw/cudnn_compatible_lstm_cell/bias"
+    import test_weights
+    test_weights.check_reader_against_cudnn_checkpoint(prefix)
+    # the loader proper: the same checkpoint's LSTM tensors through load_checkpoint's own name resolution (the dense layers are absent: refused by name)
+    with pytest.raises(Exception, match="L3/Unit_0/kernel|missing|not found"):
+        tf_bundle.load_checkpoint(prefix)

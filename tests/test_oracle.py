@@ -175,28 +175,54 @@ def test_tf_golden_recipe_is_pinned():
     outs = c_oracle.forward(w, x)
     assert abs(float(outs[0][0, 2]) - 0.27634575963020325) < 1e-5          # informative, peaky outputs (not a flat softmax)
     assert 0.5 < float(outs[0].max(axis=1).mean()) < 0.99
+    # round 6, the TRAINED-LIKE variant: LSTM kernels x4, +1 on the forget rows, head gain 6, on the 300x Illumina counts of
+    # tests/golden/nn_illumina300_64.npz (tools/make_nn_golden.py --illumina300), which also holds this oracle's outputs on it
+    wt = m.recipe_weights(trained=True)
+    assert np.array_equal(wt["lstm2_fw_kernel"], w["lstm2_fw_kernel"] * np.float32(4)) and np.array_equal(wt["l4_kernel"], w["l4_kernel"])
+    assert np.array_equal(wt["lstm1_bw_bias"][256:384], w["lstm1_bw_bias"][256:384] + np.float32(1)) and np.array_equal(wt["lstm1_bw_bias"][:256], w["lstm1_bw_bias"][:256])
+    assert abs(sum(float(np.abs(v.astype(np.float64)).sum()) for v in wt.values()) - 251055.0149521771) < 1e-6
+    xi = m.golden_input("illumina300")
+    assert xi.shape == (64, 33, 8, 4) and float(np.abs(xi).max()) > 150           # depths of the 300x profile
+    with np.load(os.path.join(ROOT, "tests", "golden", "nn_illumina300_64.npz")) as z:
+        assert str(z["recipe"]) == m.VARIANTS["trained"][3] and 1e-6 < float(z["f32_f64_distance"]) < 5e-5
+        o32, o64 = c_oracle.forward(wt, xi), c_oracle.forward(wt, xi, dtype=np.float64)
+        for a, b, key in zip(o32, o64, ("gt21", "genotype", "len1", "len2")):
+            assert np.abs(a - z[key]).max() <= 1e-7 and np.abs(b - z[key + "_f64"]).max() <= 1e-12, key
+        assert float(z["a2_absmax"]) > 0.99                                          # gates that saturate: the regime fresh init never reaches
 
 
-def test_oracle_matches_the_tf113_golden_vectors_when_present():
-    """THE pin of the oracle: outputs and intermediates TensorFlow 1.13 itself computed for the recipe weights on the 64
-    golden candidates.  Tolerances: 1e-5 on probabilities, 5e-6 on activations (two float32 evaluations with different
-    summation orders; the oracle's own float32 / float64 twins differ by 4e-6 on this set)."""
-    if not os.path.isfile(TF_GOLDEN):
-        pytest.skip(TF_GOLDEN_ABSENT)
-    check_oracle_against_minted_file(TF_GOLDEN)
+@pytest.mark.parametrize("variant", ["fresh", "trained"])
+def test_oracle_matches_the_tf113_golden_vectors_when_present(variant):
+    """THE pin of the oracle: outputs and intermediates TensorFlow 1.13 itself computed for the recipe weights on 64
+    golden candidates -- "fresh": fresh-init-like weights on ONT counts; "trained": trained-like weights (LSTM kernels x4, forget
+    bias +1, head gain 6) on 300x Illumina counts.  Tolerances: 1e-5 on probabilities, 5e-6 on activations, each widened to four times
+    the oracle's own float32 / float64 distance on that tensor (two float32 evaluations with different summation orders cannot
+    agree better than either agrees with float64: 4e-6 on the fresh set, 8e-6 on the trained one)."""
+    m = _mint()
+    path = os.path.join(ROOT, "tests", "golden", m.VARIANTS[variant][2])
+    if not os.path.isfile(path):
+        pytest.skip(TF_GOLDEN_ABSENT.replace("nn_tf113_64.npz", m.VARIANTS[variant][2]))
+    check_oracle_against_minted_file(path)
 
 
 def check_oracle_against_minted_file(path):
-    """What the test above does with the committed file; tests/test_mint_tool.py runs it on a file minted under the stand-in TensorFlow."""
+    """What the test above does with the committed file; tests/test_mint_tool.py runs it on files minted under the stand-in TensorFlow."""
     m = _mint()
-    w, x = m.recipe_weights(), m.golden_input()
     with np.load(path) as z:
-        assert str(z["recipe"]) == m.RECIPE
+        variant = str(z["variant"]) if "variant" in z.files else "fresh"
+        trained, profile, _, recipe = m.VARIANTS[variant]
+        w, x = m.recipe_weights(trained=trained), m.golden_input(profile)
+        assert str(z["recipe"]) == recipe
         assert abs(float(z["weights_checksum"]) - sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values())) < 1e-6
         outs, inter = c_oracle.forward(w, x, keep_intermediates=True)
-        for got, key in zip(outs, ("gt21", "genotype", "len1", "len2")):
-            assert np.abs(got - z[key]).max() <= 1e-5, key
-        assert np.abs(inter["a1"][:4].transpose(1, 0, 2) - z["a1_first4"]).max() <= 5e-6
-        assert np.abs(inter["a2"][:4].transpose(1, 0, 2) - z["a2_first4"]).max() <= 5e-6
-        assert np.abs(inter["l3"][:4] - z["l3_first4"]).max() <= 5e-6
-        assert np.abs(inter["l4"] - z["l4"]).max() <= 5e-6
+        outs64, inter64 = c_oracle.forward(w, x, keep_intermediates=True, dtype=np.float64)
+
+        def tol(base, a32, a64):
+            return max(base, 4.0 * float(np.abs(a32 - a64).max()))
+        for got, g64, key in zip(outs, outs64, ("gt21", "genotype", "len1", "len2")):
+            assert np.abs(got - z[key]).max() <= tol(1e-5, got, g64), key
+            assert np.abs(g64 - z[key]).max() <= tol(1e-5, got, g64), key            # and TensorFlow is as close to float64 as the oracle is
+        for key, mine, mine64, theirs in (("a1", inter["a1"][:4].transpose(1, 0, 2), inter64["a1"][:4].transpose(1, 0, 2), z["a1_first4"]),
+                                          ("a2", inter["a2"][:4].transpose(1, 0, 2), inter64["a2"][:4].transpose(1, 0, 2), z["a2_first4"]),
+                                          ("l3", inter["l3"][:4], inter64["l3"][:4], z["l3_first4"]), ("l4", inter["l4"], inter64["l4"], z["l4"])):
+            assert np.abs(mine - theirs).max() <= tol(5e-6, mine, mine64), key

@@ -735,20 +735,24 @@ def test_concordance_tool_configuration_twice_in_one_process(synth_weights):
         eng.close()
 
 
-def test_hip_matches_the_tf113_golden_vectors_when_present():
-    """The HIP path against what TensorFlow 1.13 itself computed (tools/mint_tf_golden.py -> tests/golden/nn_tf113_64.npz): the recipe
-    weights, the 64 golden candidates, probabilities within 1e-5, LSTM taps within 1e-5 of TF's.  Skips -- loudly -- until someone
-    with TF 1.13 has minted and committed the file; until then parity is pinned only to this repository's restatement."""
+@pytest.mark.parametrize("variant", ["fresh", "trained"])
+def test_hip_matches_the_tf113_golden_vectors_when_present(variant):
+    """The HIP path against what TensorFlow 1.13 itself computed (tools/mint_tf_golden.py -> tests/golden/nn_tf113_64.npz and
+    nn_tf113_trained_64.npz): the recipe weights (fresh-init-like / trained-like), the 64 golden candidates (ONT / 300x Illumina counts),
+    probabilities within 1e-5 and LSTM taps within 1e-5 of TF's -- each widened to four times the float32 / float64 distance of the
+    oracle on that tensor, as in tests/test_oracle.py.  Skips -- loudly -- until someone with TF 1.13 has minted and committed the
+    files (tools/pin/run.sh); until then parity is pinned only to this repository's restatement."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "tests", "golden", "nn_tf113_64.npz")
-    if not os.path.isfile(path):
-        pytest.skip("tests/golden/nn_tf113_64.npz is NOT in the repository (parity unpinned): run `python tools/mint_tf_golden.py` under tensorflow==1.13.2 and commit it")
     sys.path.insert(0, os.path.join(root, "tools"))
     import mint_tf_golden as m
+    trained, profile, name, _ = m.VARIANTS[variant]
+    path = os.path.join(root, "tests", "golden", name)
+    if not os.path.isfile(path):
+        pytest.skip("tests/golden/%s is NOT in the repository (parity unpinned): run tools/pin/run.sh (tensorflow==1.13.2 in a container) and commit it" % name)
     from clair_amd import _capi
-    w, x = m.recipe_weights(), m.golden_input()
+    w, x = m.recipe_weights(trained=trained), m.golden_input(profile)
     eng = _capi.Engine(device=0, max_batch=64, n_slots=1)
     try:
         eng.load_weights(w)
@@ -757,10 +761,19 @@ def test_hip_matches_the_tf113_golden_vectors_when_present():
         a2 = eng.debug_read(0, 2, (33, 64, 256))
     finally:
         eng.close()
+    o32, i32 = _oracle_with_taps(w, x, np.float32)
+    o64, i64 = _oracle_with_taps(w, x, np.float64)
     with np.load(path) as z:
-        for g, key in zip(got, ("gt21", "genotype", "len1", "len2")):
-            assert np.abs(g - z[key]).max() <= PROB_TOL, key
-        assert np.abs(a1[:, :4] - z["a1_first4"]).max() <= 1e-5 and np.abs(a2[:, :4] - z["a2_first4"]).max() <= 1e-5
+        for g, a, b, key in zip(got, o32, o64, ("gt21", "genotype", "len1", "len2")):
+            assert np.abs(g - z[key]).max() <= max(PROB_TOL, 4 * float(np.abs(a - b).max())), key
+        for tap, key in ((a1, "a1"), (a2, "a2")):
+            tol = max(1e-5, 4 * float(np.abs(i32[key] - i64[key]).max()))
+            assert np.abs(tap[:, :4] - z[key + "_first4"]).max() <= tol, key
+
+
+def _oracle_with_taps(w, x, dtype):
+    from oracle import c_oracle
+    return c_oracle.forward(w, x, keep_intermediates=True, dtype=dtype)
 
 
 def test_predict_larger_than_the_engine_batch_is_pipelined_over_the_slots(synth_weights):
@@ -781,3 +794,66 @@ def test_predict_larger_than_the_engine_batch_is_pipelined_over_the_slots(synth_
             assert np.abs(g[2040:2060] - w_).max() <= PROB_TOL
     finally:
         m.close()
+
+
+def test_bench_runs_one_ranks_block_of_the_eight_gpu_illumina_config():
+    """BASELINE.json configs[4] (Illumina 12345, 300x pileups, batch 8192, 8 GPUs) on the one GPU a box has: `--shard-of 7/8` runs exactly the
+    block rank 7 of an 8-rank strong-scaling job over 1 000 000 candidates would be dealt -- the last rank's, ragged last batch included --
+    and per_rank[0] reads as that rank's entry of the 8-rank line would (same fields, its rank number, its candidate count)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from clair_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_WARM_STEPS="16")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--scaling", "strong", "--candidates", "1000000", "--shard-of", "7/8", "--platform", "illumina", "--batch", "8192",
+                        "--warmup", "2", "--no-cpu-baseline", "--gt-candidates", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    first, mine = shard.shard_batches(1000000, 8192, 7, 8)
+    assert (first, mine) == (108 * 8192, 115264)           # 123 batches over 8 ranks: 3 ranks of 16, 5 of 15; the last rank's 15th batch holds 576 candidates
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 7 and pr[0]["candidates"] == mine and pr[0]["steps"] == 15 == d["steps"]
+    assert set(pr[0]) == {"rank", "steps", "candidates", "seconds", "candidates_per_s", "affinity", "gpu_state"}          # an N-rank line's entry has exactly these
+    assert d["config"]["stands_for"] == {"rank": 7, "world": 8, "of_candidates": 1000000, "first_candidate": first} and d["config"]["candidates_total"] == mine
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["batch"] == 8192 and "Illumina" in d["config"]["workload"]
+    assert abs(d["value"] - mine / (d["ms_per_step"] * 15e-3)) < 0.01 * d["value"] and d["value"] > 1e6 and d["parity_max_abs_err"] < 1e-5
+
+
+def test_one_ranks_share_of_the_eight_gpu_illumina_config4(synth_weights):
+    """configs[4] through the resident path at full size: one rank's eighth of >= 1 M 300x-Illumina candidates at batch 8192 (115 264 candidates =
+    15 launches, the last one ragged, two in flight; the two-tile LSTM2 kernel is the default at this size), checked by properties -- every row a distribution,
+    finite, bit-identical to the same candidates at other batch positions -- and against the oracle on a 1 024-candidate subsample."""
+    from clair_amd import _capi
+    from clair_amd import shard
+    total, world, batch = 1000000, 8, 8192
+    first, mine = shard.shard_batches(total, batch, 7, world)
+    uniq = 2 * batch
+    x, _ = synth.synthetic_input(uniq, "illumina", seed=20250928 + 7)
+    eng = _capi.Engine(device=0, max_batch=batch, n_slots=2)
+    try:
+        eng.load_weights(synth_weights)
+        assert eng.kernel_workgroups(batch)["lstm2"] == 2 * (batch // 64)        # the two-tile kernel: one workgroup per pair of tiles and direction
+        xd, od = eng.dataset_alloc(uniq * 2)
+        try:
+            eng.dataset_upload(xd, 0, x)
+            eng.dataset_upload(xd, uniq, np.roll(x, 5, axis=0))
+            n_batches = (mine + batch - 1) // batch
+            last_n = mine - (n_batches - 1) * batch
+            for b in range(n_batches):
+                eng.run_resident(b % 2, xd, od, (b % 4) * batch, last_n if b == n_batches - 1 else batch)
+            eng.sync()
+            out = eng.dataset_download(od, 0, uniq * 2)
+        finally:
+            eng.dataset_free(xd, od)
+        assert np.isfinite(out).all()
+        for a, b_ in ((0, 21), (21, 24), (24, 57), (57, 90)):
+            assert np.abs(out[:, a:b_].sum(axis=1) - 1).max() < 1e-5
+        assert np.array_equal(np.roll(out[:uniq], 5, axis=0), out[uniq:]), "outputs depend on the batch position of a candidate"
+        pick = np.linspace(0, uniq - 1, 1024).astype(np.int64)
+        want = _oracle(synth_weights, x[pick])
+        for g, w_ in zip(_capi.split_outputs(out[pick]), want):
+            assert np.abs(g - w_).max() <= PROB_TOL
+    finally:
+        eng.close()

@@ -521,6 +521,49 @@ def test_cpu_placement_follows_the_numa_node_of_each_ranks_gpu(tmp_path):
     assert shard.gpu_locality("", str(tmp_path))["cpus"] == [] and shard.gpu_locality("0000:99:00.0", str(tmp_path))["numa_node"] is None
 
 
+def test_ranks_that_share_a_node_are_dealt_whole_physical_cores(tmp_path):
+    """on an SMT host the kernel lists a node as "0-15,64-79" -- 64-79 are the sibling hardware threads of 0-15.  Contiguous
+    index slices would hand 0-15 to one rank and 64-79 to the other: the same 16 physical cores twice.  The plan deals whole cores
+    (devices/system/cpu/cpuN/topology/thread_siblings_list), so two ranks never meet on one core; and the mask goes to every thread the
+    process already has (the HIP runtime's, NumPy's), not only to the caller."""
+    devs = {"0000:10:00.0": (0, "0-15,64-79"), "0000:11:00.0": (0, "0-15,64-79")}
+    _fake_sysfs(tmp_path, devs, {0: "0-15,64-79"})
+    for c in range(16):
+        for t in (c, c + 64):
+            d = tmp_path / "devices" / "system" / "cpu" / ("cpu%d" % t) / "topology"
+            d.mkdir(parents=True)
+            (d / "thread_siblings_list").write_text("%d,%d\n" % (c, c + 64))
+    locs = [shard.gpu_locality(b, str(tmp_path)) for b in sorted(devs)]
+    assert shard.physical_cores(locs[0]["cpus"], str(tmp_path))[:2] == [[0, 64], [1, 65]] and len(shard.physical_cores(locs[0]["cpus"], str(tmp_path))) == 16
+    plan = shard.plan_affinity(locs, range(128), str(tmp_path))
+    assert [shard._compress_cpulist(p) for p in plan] == ["0-7,64-71", "8-15,72-79"]
+    cores_of = [set(t % 64 for t in p) for p in plan]
+    assert not (cores_of[0] & cores_of[1])
+    # three ranks on 16 cores: 5 + 5 + 6 cores, every core whole
+    plan3 = shard.plan_affinity(locs + [locs[0]], range(128), str(tmp_path))
+    assert [len(p) for p in plan3] == [10, 10, 12] and all(set(t % 64 for t in p) == set(t % 64 for t in p if t < 64) for p in plan3)
+    # a cgroup that grants only the first hardware thread of every core: cores of one thread each
+    assert [shard._compress_cpulist(p) for p in shard.plan_affinity(locs, range(16), str(tmp_path))] == ["0-7", "8-15"]
+    # every thread of the process takes the mask
+    import threading
+    stop = threading.Event()
+    seen = {}
+    def idle():
+        stop.wait(20)
+        seen["after"] = sorted(os.sched_getaffinity(0))
+    before = sorted(os.sched_getaffinity(0))
+    t = threading.Thread(target=idle)
+    t.start()
+    try:
+        n = shard.set_affinity_of_process(before[:1])
+        assert n >= 2
+    finally:
+        stop.set()
+        t.join()
+        os.sched_setaffinity(0, before)
+    assert seen["after"] == before[:1]
+
+
 AFFINITY_WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %(root)r)

@@ -261,3 +261,55 @@ def check_reader_against_minted_checkpoint(prefix):
     sys.path.insert(0, os.path.join(root, "tools"))
     import mint_tf_golden
     assert set(mint_tf_golden.tf_variable_names(h)) <= set(got)          # TF's names ARE the loader's names
+
+
+def test_reader_on_a_cudnn_checkpoint_written_by_tensorflow_gpu_when_present():
+    """tools/mint_tf_golden.py --cudnn-checkpoint, run under tensorflow-gpu 1.13 on a CUDA GPU, saves the two BiLSTM layers of the
+    reference's GPU branch (tf.contrib.cudnn_rnn.CudnnLSTM, /root/reference/clair/model.py:281-296) through TF's own CudnnLSTMSaveable AND
+    as raw opaque buffers, with the layers' outputs.  Until someone commits those files, the names under which a GPU-trained checkpoint
+    stores its LSTM tensors and the opaque -> canonical conversion of clair_amd/tf_bundle.py are [TF-recall]."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = os.path.join(root, "tests", "golden", "tf113_cudnn")
+    if not os.path.isfile(prefix + ".index"):
+        pytest.skip("tests/golden/tf113_cudnn.* absent: no CudnnLSTM checkpoint written by TensorFlow itself has been read yet -- "
+                    "`python tools/mint_tf_golden.py --cudnn-checkpoint` under tensorflow-gpu==1.13.x (tools/pin/run.sh --gpu) mints it")
+    check_reader_against_cudnn_checkpoint(prefix)
+
+
+def check_reader_against_cudnn_checkpoint(prefix):
+    """(1) every LSTM tensor of the loader's name table is in the saveable-written checkpoint under one of tf_bundle.candidate_names();
+    (2) tf_bundle.cudnn_opaque_to_canonical of the raw buffers equals what the saveable wrote; (3) the oracle's BiLSTM layers with those
+    tensors reproduce the CudnnLSTM layers' own outputs -- cuDNN and CudnnCompatibleLSTMCell compute the same function, which is what
+    lets the reference train on one and call on the other (clair/model.py:299-312)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import mint_tf_golden
+    from oracle import c_oracle
+    doc = json.load(open(prefix + ".json"))
+    canon, raw = tf_bundle.read_tensors(prefix), tf_bundle.read_tensors(prefix + "_raw")
+    assert sorted(raw) == sorted(doc["opaque"]) and len(raw) == 2
+    w = {k: np.zeros(shape, np.float32) for k, shape in weights.TENSOR_TABLE.items()}
+    for tf_name, (key, idx) in weights.tf_variable_names().items():
+        if not tf_name.startswith("LSTM"):
+            continue
+        found = [n for n in tf_bundle.candidate_names(tf_name, {}, {}) if n in canon]
+        assert found, "the saveable stored %s under none of %s; the checkpoint holds %s" % (tf_name, tf_bundle.candidate_names(tf_name, {}, {}), sorted(canon))
+        assert idx is None and canon[found[0]].shape == w[key].shape
+        w[key] = canon[found[0]]
+    for name, values in doc["opaque"].items():
+        layer = name.split("/")[0]
+        assert np.array_equal(raw[name].ravel(), np.asarray(values, dtype=np.float32))
+        parts = tf_bundle.cudnn_opaque_to_canonical(raw[name], 32 if layer == "LSTM1" else 256, 128)
+        for (d, kind), value in parts.items():
+            assert np.abs(value - w["lstm%s_%s_%s" % (layer[-1], d, kind)]).max() <= 1e-6, (name, d, kind)
+    n = doc["n"]
+    x = mint_tf_golden.golden_input("illumina300")[:n]
+    _, inter = c_oracle.forward(w, x, keep_intermediates=True)
+    _, inter64 = c_oracle.forward(w, x, keep_intermediates=True, dtype=np.float64)
+    for key in ("a1", "a2"):
+        theirs = np.asarray(doc[key], dtype=np.float32).reshape(33, n, 256).transpose(1, 0, 2)
+        assert np.abs(inter[key] - theirs).max() <= max(1e-5, 4 * float(np.abs(inter[key] - inter64[key]).max())), key

@@ -93,10 +93,24 @@ def phases_from(per, bench_json):
     short = [c[0].replace("clair::", "").replace("void ", "").split("(")[0][:22] for c in cols]
     print("%-66s %6s " % ("leg", "passes") + " ".join("%22s" % s_ for s_ in short))
     at = 0
+    timed = {}
     for name, n in phases:
         if n > 0:
             print("%-66s %6d " % (name[:66], n) + " ".join("%22.2f" % (sum(c[1][at:at + n]) / n) for c in cols))
+            if name.startswith("timed (value)"):          # the contract's timed region: what roofline.kernel_ms_rocprof quotes
+                for full, d in cols:
+                    kid = next((v for k, v in BENCH_IDS if k in full), None)
+                    if kid:
+                        timed[kid] = round(sum(d[at:at + n]) / n / 1e3, 5)
         at += n
+    if "--timed-json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--timed-json") + 1], "w") as f:
+            json.dump(timed, f)
+
+
+# substring of the traced kernel name -> bench.py's kernel id (clair_amd/_capi.py: KERNEL_NAMES)
+BENCH_IDS = (("lstm32_kernel<true>", "lstm1"), ("lstm32_kernelILb1", "lstm1"), ("gemm_split_kernel", "proj2"), ("lstm32_kernel<false>", "lstm2"), ("lstm32_kernelILb0", "lstm2"),
+             ("lstm32_pair_kernel", "lstm2"), ("lstm2_fused_kernel", "lstm2"), ("l3l4_kernel", "l4"), ("tail_kernel", "tail"))
 
 
 if __name__ == "__main__":
