@@ -48,21 +48,21 @@ class _PR(object):
         self.p, self.r = p, r
 
     def __mul__(self, other):
-        return _PR(self.p * other.p, self.r + other.r)
+        return _PR(self.p * other.p, None if self.r is None else self.r + other.r)
 
     def __getitem__(self, key):
-        return _PR(self.p[key], self.r[key])
+        return _PR(self.p[key], None if self.r is None else self.r[key])
 
     def reshape(self, *shape):
-        return _PR(self.p.reshape(*shape), self.r.reshape(*shape))
+        return _PR(self.p.reshape(*shape), None if self.r is None else self.r.reshape(*shape))
 
 
 def _larger(a, b):
     take = a.p >= b.p                        # np.maximum(a, b): the branch float32 takes carries its own factors
-    return _PR(np.where(take, a.p, b.p), np.where(take, a.r, b.r))
+    return _PR(np.where(take, a.p, b.p), None if a.r is None else np.where(take, a.r, b.r))
 
 
-def outcome_table(Y, ref_class, dtype=np.float32):
+def outcome_table(Y, ref_class, dtype=np.float32, sensitivities=True):
     """(P [n, 1179], R [n, 1179]) for the four heads' probabilities Y = (gt21, genotype, len1, len2).  `dtype` float32: the decoder's
     products, bit for bit, operand order of clair/call_var.py:589-690 as restated in clair_amd/call_var.py: OutcomeFamilies;
     float64: the same products without float32 rounding (for the float64 evaluation's margins).  R is float32 either way."""
@@ -71,7 +71,7 @@ def outcome_table(Y, ref_class, dtype=np.float32):
     rows = np.arange(n)
 
     def pr(a):
-        return _PR(a, (1.0 / np.maximum(a.astype(np.float64), 1e-300)).astype(np.float32))
+        return _PR(a, (1.0 / np.maximum(a.astype(np.float64), 1e-300)).astype(np.float32) if sensitivities else None)
 
     g = pr(gt21)
     p_ref, p_hom, p_het = pr(genotype[:, 0]), pr(genotype[:, 1]), pr(genotype[:, 2])
@@ -95,8 +95,8 @@ def outcome_table(Y, ref_class, dtype=np.float32):
     e3 = (p_het * g[:, task.IDX_INSDEL])[:, None, None]
     a = (ins1[:, :, None] * del2[:, None, :]) * e3          # len1 = +i, len2 = -j
     b = (del1[:, :, None] * ins2[:, None, :]) * e3          # len1 = -i, len2 = +j
-    fam[cvar.F_INSDEL] = _PR(np.stack([a.p, b.p], axis=-1).reshape(n, -1), np.stack([a.r, b.r], axis=-1).reshape(n, -1))
-    return np.concatenate([f.p for f in fam], axis=1), np.concatenate([f.r for f in fam], axis=1)
+    fam[cvar.F_INSDEL] = _PR(np.stack([a.p, b.p], axis=-1).reshape(n, -1), np.stack([a.r, b.r], axis=-1).reshape(n, -1) if sensitivities else None)
+    return np.concatenate([f.p for f in fam], axis=1), (np.concatenate([f.r for f in fam], axis=1) if sensitivities else None)
 
 
 def ref_classes(infos):
@@ -131,25 +131,95 @@ def first_iteration_margins(P, R):
     p2 = P[rows, r].astype(np.float64)
     P[rows, w] = keep
     margin = (p1 - p2) / np.maximum(p1, 1e-300)
-    return w, r, margin, R[rows, w].astype(np.float64) + R[rows, r].astype(np.float64)
+    return w, r, margin, (R[rows, w].astype(np.float64) + R[rows, r].astype(np.float64)) if R is not None else None
 
 
 def ambiguous(margin, rsum, eps):
     return margin <= eps * rsum + ROUNDING
 
 
-def near_tie_counts(Y, infos, eps_list, step=8192, callable_only=True):
+def _factor_table():
+    """For each of the 1 179 outcomes, the positions of its four factors in the packed 90-vector (gt21 | genotype | len1 | len2) -- what
+    outcome_table multiplies, as data: FACT[k] = four positions, ALT[k] = the two positions that replace FACT[k][:2] when the other branch
+    of np.maximum(z1 * x2, x1 * z2) is the larger one (-1: no such branch).  The reference-call outcome's gt21 factor depends on the
+    candidate (its reference base): FACT[0][3] = -1, filled in per candidate."""
+    G, Z, L1, L2 = (lambda i: i), (lambda c: 21 + c), (lambda c: 24 + c), (lambda c: 57 + c)
+    ins, dele = [int(c) for c in cvar._INS_COLS], [int(c) for c in cvar._DEL_COLS]
+    fact, alt = [], []
+
+    def add(f, a=(-1, -1)):
+        fact.append(f)
+        alt.append(a)
+    add((L1(16), L2(16), Z(0), -1))
+    for g in task.HOMO_SNP_IDX:
+        add((L1(16), L2(16), Z(1), G(g)))
+    for g in task.HETERO_SNP_IDX:
+        add((L1(16), L2(16), Z(2), G(g)))
+    for k in range(16):
+        add((L1(ins[k]), L2(ins[k]), Z(1), G(task.IDX_INSINS)))
+    for k in range(16):
+        for g in task.INS_BASE_IDX:
+            add((L1(16), L2(ins[k]), Z(2), G(g)), (L1(ins[k]), L2(16)))
+    for i in range(16):
+        for j in range(16):
+            add((L1(ins[i]), L2(ins[j]), Z(2), G(task.IDX_INSINS)))
+    for k in range(16):
+        add((L1(dele[k]), L2(dele[k]), Z(1), G(task.IDX_DELDEL)))
+    for k in range(16):
+        for g in task.DEL_BASE_IDX:
+            add((L1(16), L2(dele[k]), Z(2), G(g)), (L1(dele[k]), L2(16)))
+    for i in range(16):
+        for j in range(16):
+            if i != j:
+                add((L1(dele[i]), L2(dele[j]), Z(2), G(task.IDX_DELDEL)))
+    for i in range(16):
+        for j in range(16):
+            add((L1(ins[i]), L2(dele[j]), Z(2), G(task.IDX_INSDEL)))
+            add((L1(dele[i]), L2(ins[j]), Z(2), G(task.IDX_INSDEL)))
+    fact, alt = np.array(fact, dtype=np.int64), np.array(alt, dtype=np.int64)
+    assert fact.shape == (N_OUTCOMES, 4) and alt.shape == (N_OUTCOMES, 2)
+    return fact, alt
+
+
+_FACT, _ALT = _factor_table()
+
+
+def sensitivity_of(packed, k, ref_class):
+    """R_k = sum 1 / p over the factors of outcome k[i] of candidate i, from the packed [n, 90] float32 probabilities -- the same numbers as
+    outcome_table's R at those positions (tests/test_gt_ties.py), without building the other 1 178 columns."""
+    n = packed.shape[0]
+    rows = np.arange(n)
+    f = _FACT[k].copy()                                   # [n, 4]
+    f[:, 3] = np.where(f[:, 3] < 0, ref_class, f[:, 3])
+    a = _ALT[k]
+    has = a[:, 0] >= 0
+    if has.any():                                         # np.maximum(z1 * x2, x1 * z2): the branch float32 takes
+        r_ = rows[has]
+        first = packed[r_, f[has, 0]] * packed[r_, f[has, 1]]
+        other = packed[r_, a[has, 0]] * packed[r_, a[has, 1]]
+        swap = other > first
+        idx = np.flatnonzero(has)[swap]
+        f[idx, 0], f[idx, 1] = a[idx, 0], a[idx, 1]
+    p = np.maximum(packed[rows[:, None], f].astype(np.float64), 1e-300)
+    return (1.0 / p).sum(axis=1)
+
+
+def near_tie_counts(Y, infos, eps_list, step=1024, callable_only=True):   # small steps: the temporaries stay in cache (8192: 20x slower, page faults)
     """How many candidates of a batch are ambiguous at each eps (first arg-max only: a candidate whose first choices cannot be
     written as REF / ALT walks on to later maxima, which this count does not follow -- flips are analysed exactly, see analyse_flip).
+    The products of all 1 179 outcomes for everybody, the sensitivities of winner and runner-up only (sensitivity_of).
     -> ({eps: count}, boolean mask per eps, relative margins)."""
     n = len(infos)
     rc = ref_classes(infos)
     ok = np.array([inf[2][cvar.CENTER] in task.BASIC_BASES for inf in infos], dtype=bool) if callable_only else np.ones(n, bool)
     margins = np.empty(n, np.float64)
     rsum = np.empty(n, np.float64)
+    packed = np.concatenate([np.asarray(a, dtype=np.float32) for a in Y], axis=1)
     for i in range(0, n, step):
-        P, R = outcome_table([a[i:i + step] for a in Y], rc[i:i + step])
-        _, _, margins[i:i + step], rsum[i:i + step] = first_iteration_margins(P, R)
+        sl = slice(i, i + step)
+        P, _ = outcome_table([a[sl] for a in Y], rc[sl], sensitivities=False)
+        w, r, margins[sl], _ = first_iteration_margins(P, None)
+        rsum[sl] = sensitivity_of(packed[sl], w, rc[sl]) + sensitivity_of(packed[sl], r, rc[sl])
     masks = {eps: ok & ambiguous(margins, rsum, eps) for eps in eps_list}
     return {eps: int(m.sum()) for eps, m in masks.items()}, masks, margins
 
