@@ -526,6 +526,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # round 6: ONE fraction for the dominant kernel -- the contract figure is the table's own entry
     assert roof["frac"] == kernels[dom]["frac"] and abs(roof["kernel_ms"] - kernels[dom]["in_flight_ms"]) < 1e-4
     assert roof["kernel_ms_with_events_on_it_only"] > 0 and "kernel_ms_rocprof" in roof
+    if roof["kernel_ms_rocprof"] is not None:          # the committed trace was taken on these kernel sources: the un-instrumented duration and its fraction
+        assert abs(roof["frac_rocprof"] - flop / (roof["kernel_ms_rocprof"] * 1e-3) / 2.5e15) < 2e-4 and roof["frac_rocprof"] == kernels[dom]["frac_rocprof"]
+        assert 0.5 * roof["kernel_ms"] < roof["kernel_ms_rocprof"] < 1.2 * roof["kernel_ms"]
     path = d["roofline_path"]
     if roof["traffic"] is not None:
         assert abs(path["fabric_tb_s"] - path["measured_traffic_bytes_per_candidate"] * d["value_sustained"] / 1e12) < 0.02 * path["fabric_tb_s"]
