@@ -130,6 +130,14 @@ __device__ __forceinline__ void glds16(const f32x4 *gsrc, unsigned lds_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
 
+// glds16_s (below) with the nt bit: for data that is read exactly once (l3l4's a2 tiles) -- the line is not kept in the L2 at the expense of
+// what other kernels in flight re-read (round 6: +0.6 % of the pipeline at batch 1 024, profiles/r06_ab_cache_hints2.txt).
+__device__ __forceinline__ void glds16_s_nt(unsigned lane_off, const void *sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(sbase), "s"(lds_base) : "memory");
+}
+
 // The same with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset: a persistent kernel keeps its lane
 // offsets in registers for its whole life and only re-bases (scalar arithmetic) from piece to piece.
 __device__ __forceinline__ void glds16_s(unsigned lane_off, const void *sbase, unsigned lds_base) {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(L34_THREADS) void l3l4_kernel(L3L4Args p) {
         for (int i = first; i < first + count && q4 + 4 * i < L34_NPIECE; ++i) {
             const size_t at = (size_t)(base + (size_t)i * step);        // wave-uniform by construction; said so to the register allocator
             const void *sbase = (const void *)(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)at));
-            glds16_s(dma_lane_off, sbase, lds_a2 + (q4 + 4 * i) * 1024);
+            glds16_s_nt(dma_lane_off, sbase, lds_a2 + (q4 + 4 * i) * 1024);   // a2 is read once
         }
     };
     constexpr int L34_MY_PIECES = (L34_NPIECE + 3) / 4;   // 17 (waves 0, 1) or 16 (waves 2, 3): issue_pieces stops at the tile's end

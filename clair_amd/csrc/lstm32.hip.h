@@ -348,8 +348,11 @@ __device__ __forceinline__ void lstm32_body(const Lstm32Args &p, const int d, co
         if (FIRST) {
             const size_t plane = (size_t)T_POS * p.n_pad * (2 * HID);
             *(f16x8 *)(p.aout2 + (g >> 9) * plane + row0 + (size_t)((g >> 4) & 31) * (2 * HID) + (g & 15) * 8) = cp[j];
-        } else {   // a2 is channel-group-major for its only reader (dense.hip.h): [32 groups][33 t][n_pad][8]; a wave store = one group's 32 x 8 block, 1 KiB
-            *(f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile * L32_TILE) * 8) + (g & 63) * 4) = co[j];
+        } else {   // a2 is channel-group-major for its only reader (dense.hip.h): [32 groups][33 t][n_pad][8]; a wave store = one group's 32 x 8 block, 1 KiB.
+                   // Written once, read once by another kernel: non-temporal on both sides (round 6, with l3l4's nt LDS-DMA: +0.5 % at batch 1 024,
+                   // +1.0 % at 4 096, profiles/r06_ab_cache_hints*.txt).  NOT a1 above: the projection re-reads it four times per XCD and wants the caches
+                   // (its stores non-temporal: the projection alone 77 -> 85 us).
+            __builtin_nontemporal_store(co[j], (f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile * L32_TILE) * 8) + (g & 63) * 4));
         }
     };
 

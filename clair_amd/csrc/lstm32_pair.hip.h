@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto copy_write = [&](int tl, int s, int half, int j) {
         const int t = d ? T_POS - 1 - s : s;
         const int g = (half * 2 + j) * 256 + tid;
-        *(f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile_of[tl] * L32_TILE) * 8) + (g & 63) * 4) = co[j];   // group-major (lstm32.hip.h)
+        __builtin_nontemporal_store(co[j], (f32x4 *)(p.aout + ((((size_t)(d * 16 + (g >> 6)) * T_POS + t) * p.n_pad + (size_t)tile_of[tl] * L32_TILE) * 8) + (g & 63) * 4));   // group-major, non-temporal (lstm32.hip.h)
     };
 
     f32x16 acc[2];        // block b accumulates in acc[b & 1]
