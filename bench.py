@@ -30,16 +30,24 @@ and one leg over the whole candidate set BASELINE.json's config names (`--full-c
 `gpu_state.period_ms` milliseconds) during each of those legs, on every rank (`per_rank[r].gpu_state`; the top-level one is rank 0's).
 `gt_concordance_200k` (N=1 only, like cpu_baseline): tools/gt_concordance.py's count of VCF rows whose CHROM/POS/REF/ALT/GT differ between
 the decode of the HIP probabilities and the decode of the float32 oracle's, over `--gt-candidates` (200 000) candidates of each platform
-profile.
+profile; every differing row analysed by tools/gt_ties.py -- `flips_not_excused` (must be 0: a flip is excused only when float32 cannot decide
+the pair and float64 decides it the HIP way) and `near_ties`, the rows that are inherently ambiguous at eps = 0 / 3e-6 / 1e-5 on the
+probabilities.  The leg has a time budget enforced inside each platform's loop (`--gt-seconds`; a platform cut short says `truncated`).
+`--scaling strong --shard-of R/W` (one GPU): exactly the block rank R of a W-rank job over `--candidates` would run; per_rank[0] reads as that
+rank's entry of the W-rank line (configs[3] and configs[4] on a one-GPU box).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the dominant kernel = the one with the most chip time (stand-alone duration x share of the 256 CUs its grid
                   occupies) in THIS run's own per-kernel table: SURVEY.md 8(d) algorithmic FLOP per launch / its mean
                   HIP-event duration IN the multi-stream configuration of the timed loop / the 2.5 PFLOP/s dense f16 MFMA
-                  peak.  `executed_frac` counts the three fp16 MFMAs the 2-way split issues per product; `alone_*` is the
+                  peak (ONE number: `frac` == `kernels[dominant].frac`; `frac_rocprof` / `kernel_ms_rocprof` are the same from the committed
+                  rocprofv3 trace of this configuration -- no marker packets in the queues -- when it was taken on these kernel sources).
+                  `executed_frac` counts the three fp16 MFMAs the 2-way split issues per product; `alone_*` is the
                   same kernel with nothing else on the chip; `kernels` carries the same fractions for every kernel of the
                   pass; `traffic` comes from profiles/pmc_traffic.json and is null unless that table was measured on exactly
                   the kernel sources this run executes (clair_amd/build.py: csrc_digest).
+  roofline_path.fabric_tb_s -- measured L2 <-> fabric bytes per candidate x the sustained rate, and its fraction of the 6.29 TB/s a
+                  streaming copy achieves: the closest roof of the whole line (profiles/r06_fabric_sensitivity.txt: what it costs).
   cpu_baseline -- the blocked CPU port of the same forward pass (oracle/clair_cpu_port.c when present, else
                   oracle/clair_oracle.c) timed on the host cores of this box on a bounded sample (N=1 only).
 """
