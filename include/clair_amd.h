@@ -238,7 +238,8 @@ void clair_comm_abort(clair_comm_t *c);
 /* clair_comm_create with a deadline (round 6; ABI 6): ncclCommInitRank AND the first collective on the new communicator (one
  * all-reduce: RCCL connects its transports lazily) run on a helper thread; 0 = up and proven, 1 = failed (clair_comm_last_error(NULL)),
  * CLAIR_COMM_TIMED_OUT = neither returned within `timeout_ms`.  On a time-out no communicator exists for the caller: the helper thread
- * is abandoned and aborts its communicator should RCCL ever return.  clair_amd/shard.py then tells the peers over the bootstrap
+ * is abandoned and aborts its communicator should RCCL ever return (until then a thread of this process sits inside librccl: leave the
+ * process with _exit once the results are written -- exit() would run librccl's static destructors under it).  clair_amd/shard.py then tells the peers over the bootstrap
  * sockets and every rank goes on over the socket transport -- a hung RCCL bring-up still yields the N-rank line (`rccl_failure`). */
 #define CLAIR_COMM_TIMED_OUT 2
 int clair_comm_create_timed(int device, int rank, int world, const uint8_t *id, int timeout_ms, clair_comm_t **out);
