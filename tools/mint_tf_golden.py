@@ -15,8 +15,8 @@ reference arithmetic and parity stops being "unpinned".
     # Python 3.6/3.7, tensorflow==1.13.2, numpy<1.20; from the repository root (tools/pin/run.sh does all of it in a container):
     python tools/mint_tf_golden.py                       # -> tests/golden/nn_tf113_64.npz (~0.6 MB): fresh-init-like weights, ONT counts
                                                          #    tests/golden/nn_tf113_trained_64.npz: TRAINED-LIKE weights (LSTM kernels x4, forget
-                                                         #    bias +1, head gain 6) on 300x Illumina counts -- the regime where the recurrence
-                                                         #    amplifies float32 rounding a thousandfold and a semantic slip cannot hide
+                                                         #    bias +1, head gain 6) on 300x Illumina counts -- saturated gates, an integrating cell
+                                                         #    state: the regime fresh initialisation never reaches and a semantic slip cannot hide in
     python tools/mint_tf_golden.py --mini-checkpoint     # + tests/golden/tf113_mini.{index,data-00000-of-00001,json}: a tf.train.Saver
                                                          #   checkpoint of a 4-unit version of the graph (real bundle format, real names)
     python tools/mint_tf_golden.py --cudnn-checkpoint    # (tensorflow-gpu==1.13.x + a CUDA GPU) + tests/golden/tf113_cudnn.*: the two BiLSTM
@@ -74,10 +74,10 @@ def recipe_weights(h=H, l3=L3_UNITS, l4=L4_UNITS, l5=L5_UNITS, trained=False):
     softmaxes are peaky (mean top probability 0.55 .. 0.98 per head on the golden candidates).  LSTM outputs reach +-0.78 without
     saturating: no dead gate hides an error either; the float32 oracle sits 4e-6 from its float64 twin on this set.
     trained=True is what training leaves behind and fresh initialisation never shows: LSTM kernels x4 (gates that saturate), +1 on the
-    forget-gate bias rows [2h, 3h) (a cell state that integrates over all 33 steps), head kernels x6 -- the cell of
-    tools/parity_sweep.py where float32 rounding is amplified ~1000x through the recurrence (the float32 oracle sits up to a few 1e-4
-    from float64 there on 300x counts), so that a wrong gate order, a missing forget bias or a transposed kernel is four orders of
-    magnitude above the noise instead of one."""
+    forget-gate bias rows [2h, 3h) (a cell state that integrates over all 33 steps), head kernels x6 -- the cells of
+    tools/parity_sweep.py where the recurrence amplifies float32 rounding most (on the 300x counts |a1| and |a2| reach 1.000 and the
+    float32 oracle sits 7.9e-6 from float64 on the probabilities, twice the fresh set's distance), and where a forget bias that is
+    not applied, or applied twice, changes every output instead of hiding in a zero bias."""
     w = {}
     for tag, (key, shape) in enumerate(tensor_shapes(h, l3, l4, l5), start=1):
         u = _uniform(tag, int(np.prod(shape))).reshape(shape)
