@@ -313,3 +313,40 @@ def check_reader_against_cudnn_checkpoint(prefix):
     for key in ("a1", "a2"):
         theirs = np.asarray(doc[key], dtype=np.float32).reshape(33, n, 256).transpose(1, 0, 2)
         assert np.abs(inter[key] - theirs).max() <= max(1e-5, 4 * float(np.abs(inter[key] - inter64[key]).max())), key
+
+
+def test_snappy_decoder_against_googles_own_compressor():
+    """clair_amd/tf_bundle.py decodes the snappy blocks of a checkpoint's .index itself (python-snappy is not a dependency).  Its fixtures are
+    compressed by this repository's own encoder; here the streams come from Google's snappy library as pyarrow ships it -- an independent,
+    real implementation: literals of every length class, copies with 1-, 2- and 4-byte offsets, runs, incompressible data, 1 MB blocks."""
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("snappy"):
+        pytest.skip("this pyarrow build has no snappy codec")
+    rng = np.random.default_rng(7)
+    words = [bytes(rng.integers(97, 123, int(n)).astype(np.uint8)) for n in rng.integers(1, 12, 400)]
+    cases = [b"", b"a", b"ab" * 5, bytes(rng.integers(0, 256, 70000).astype(np.uint8)),                        # incompressible: literals > 60 and > 256 bytes
+             b"".join(words[int(i)] for i in rng.integers(0, 400, 60000)),                                       # text-like: short copies, 1- and 2-byte offsets
+             bytes(1 << 20),                                                                                      # one long run
+             bytes(rng.integers(0, 256, 3000).astype(np.uint8)) * 300,                                            # period 3000: 2-byte offsets, long copies
+             bytes(rng.integers(0, 4, 1 << 20).astype(np.uint8)),                                                 # low entropy
+             b"".join(bytes(rng.integers(0, 256, 100).astype(np.uint8)) + bytes(70000) for _ in range(3))]        # copies further than 65535 back
+    kinds = set()
+    for data in cases:
+        blob = pa.compress(data, codec="snappy", asbytes=True)
+        assert tf_bundle.snappy_decompress(blob) == data
+        at = 0
+        while blob[at] & 0x80:                                   # skip the varint length, then note the element kinds present
+            at += 1
+        at += 1
+        while at < len(blob):
+            tag = blob[at]
+            kind = tag & 3
+            kinds.add(kind)
+            if kind == 0:
+                n = tag >> 2
+                extra = max(0, n - 59) if n >= 60 else 0
+                n = (int.from_bytes(blob[at + 1:at + 1 + extra], "little") if extra else n) + 1
+                at += 1 + extra + n
+            else:
+                at += {1: 2, 2: 3, 3: 5}[kind]
+    assert {0, 1, 2} <= kinds                                     # literals, 1-byte-offset and 2-byte-offset copies all occurred
