@@ -428,7 +428,10 @@ def run_ranked(args, group, json_fd):
         if args.shard_of:
             if world != 1:
                 raise SystemExit("--shard-of runs one rank's block on one GPU: use it with --gpus 1")
-            as_rank, as_world = (int(v) for v in args.shard_of.split("/"))
+            try:
+                as_rank, as_world = (int(v) for v in args.shard_of.split("/"))
+            except ValueError:
+                raise SystemExit("--shard-of takes R/W (two integers), not %r" % args.shard_of)
             if not 0 <= as_rank < as_world:
                 raise SystemExit("--shard-of R/W needs 0 <= R < W")
             stands_for = {"rank": as_rank, "world": as_world, "of_candidates": args.candidates}
